@@ -1,0 +1,147 @@
+/*
+ * lsf.h -- C ABI of liblsf_hip.so: the MI355X (gfx950) implementation of the hot path of
+ * musheen/LevelSetFortran -- WENO5 Hamilton-Jacobi reinitialisation and min/max-flow smoothing
+ * on a uniform 3-D grid.
+ *
+ * The reference has no FFI: its seam is the Fortran module procedure `reinit`
+ * (subs.f90:717-725, called at set3d.f90:308 and :582) and the min/max loop written inline in the
+ * main program (set3d.f90:394-462).  Each entry point below names the reference interface it
+ * replaces.  levelsetfortran_amd/fortran/lsf_set_subs.f90 is the iso_c_binding shim that gives
+ * the reference host those procedures back under their original names.
+ *
+ * Conventions
+ *  - Plain C types only.  `int` is the reference's INTEGER*4, `double` its REAL under
+ *    -fdefault-real-8 (Makefile:4).
+ *  - Every field is Fortran-ordered exactly like `REAL phi(0:nx,0:ny,0:nz)` (subs.f90:721):
+ *    extents (nx+1, ny+1, nz+1), `i` unit stride, element (i,j,k) at i + (nx+1)*(j + (ny+1)*k).
+ *  - Functions without a `_device` suffix take HOST pointers owned by the caller; the library
+ *    copies in on entry and out on exit and is quiescent on return.  `_device` functions take
+ *    DEVICE pointers (HBM-resident fields, e.g. torch tensors) and a hipStream_t passed as void*
+ *    (NULL = the null stream); they enqueue work and, unless stated otherwise, return after the
+ *    stream has been synchronised.
+ *  - All functions return LSF_OK (0) or an LSF_ERR_* code; lsf_last_error() describes the last
+ *    failure on the calling thread.  There is no CPU fallback: without a usable gfx950 device the
+ *    compute entry points return LSF_ERR_NO_DEVICE.
+ */
+#ifndef LSF_H
+#define LSF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSF_VERSION 100 /* 0.1.0 */
+
+/* ---- return codes ---------------------------------------------------------------------- */
+#define LSF_OK 0
+#define LSF_ERR_NAN 1       /* RMS became NaN: the reference STOPs (subs.f90:926, set3d.f90:458) */
+#define LSF_ERR_INVALID 2   /* bad argument                                                      */
+#define LSF_ERR_HIP 3       /* HIP runtime failure                                               */
+#define LSF_ERR_NO_DEVICE 4 /* no HIP device / not gfx950                                        */
+
+/* ---- mode word: ordering | arithmetic ---------------------------------------------------- */
+/* ordering (low byte) */
+#define LSF_ORDER_GS 0     /* the reference's in-place Gauss-Seidel raster sweeps, reproduced      \
+                              exactly by a tiled hyperplane wavefront     */
+#define LSF_ORDER_JACOBI 1 /* double-buffered sweep: shards across GPUs, NOT reference-equal       */
+#define LSF_ORDER_MASK 0xff
+/* arithmetic (bit 8) */
+#define LSF_ARITH_FAST 0x000   /* restructured fp64 arithmetic (FMA, shared terms, one reciprocal   \
+                                  per WENO side); within 1e-12 RMS of LSF_ARITH_STRICT             */
+#define LSF_ARITH_STRICT 0x100 /* every operation as written in subs.f90, no contraction:           \
+                                  bit-identical to the reference for LSF_ORDER_GS                  */
+
+/* ---- library / device ------------------------------------------------------------------- */
+int lsf_version(void);
+const char *lsf_last_error(void);
+/* number of visible HIP devices (0 if none); never fails */
+int lsf_device_count(void);
+/* select the device used by the calling thread's subsequent calls (default 0) */
+int lsf_set_device(int device);
+/* release every cached device buffer of the current device */
+int lsf_release_workspace(void);
+
+/* ---- seam 1: reinit ----------------------------------------------------------------------
+ * Replaces SUBROUTINE reinit(phi,gradPhi,gradPhiMag,nx,ny,nz,iter,dx,h), subs.f90:717-931.
+ * Runs at most iter+1 sweeps (the reference loop is DO n=0,iter, subs.f90:735) of
+ * {one raster sweep of the WENO5/Godunov update (subs.f90:743-852, weno :489-711, phiSign
+ * :152-172); extrapolation boundary condition (:859-897); RMS change over all points (:902-914)}
+ * and stops after the first sweep whose RMS is < tol (the reference uses 1e-5, :915).
+ * gradPhi / gradPhiMag are dead outputs of the reference and are not part
+ * of this interface.
+ *   sweeps_done  (out, may be NULL) number of sweeps executed
+ *   rms_trace    (out, may be NULL) RMS of sweep s (0-based) in rms_trace[s], s < trace_cap; the
+ *                Fortran shim prints the reference's " Iteration: n  RMS Error: e" lines from it
+ * Returns LSF_ERR_NAN if an RMS is NaN (phi then holds the state after that sweep).
+ */
+int lsf_reinit(double *phi, int nx, int ny, int nz, int iter, double dx, double h, double tol,
+               int mode, int *sweeps_done, double *rms_trace, int trace_cap);
+
+/* Same on an HBM-resident field.  d_phi is updated in place.  first_raster (0..7) is the number
+ * of raster directions already consumed (0 = start with scan 1, like the reference); d_phiS may be
+ * NULL (then phiS = phi on entry, subs.f90:731) or a device copy of the sign field to use. */
+int lsf_reinit_device(double *d_phi, const double *d_phiS, int nx, int ny, int nz, int iter, double dx,
+                      double h, double tol, int mode, int first_raster, int *sweeps_done,
+                      double *rms_trace, int trace_cap, void *stream);
+
+/* ---- seam 2: min/max flow ---------------------------------------------------------------
+ * Replaces the loop DO n = 1,iter ... END DO at set3d.f90:394-462 (secondDeriv subs.f90:370-407,
+ * minMax subs.f90:413-483, narrowBand subs.f90:178-207), hoisted into one call.
+ * phiNB / phiSB: in = the masks made at set3d.f90:360; out = the masks the host holds after the
+ * loop (the band is refreshed only on the non-exit path, set3d.f90:448-460).
+ * Stops after the first iteration whose RMS is < tol (reference 1e-7, set3d.f90:448).
+ */
+int lsf_minmax(double *phi, int32_t *phiNB, int32_t *phiSB, int nx, int ny, int nz, int iter,
+               double dx, double h1, double tol, int mode, int *iters_done, double *rms_trace,
+               int trace_cap);
+
+int lsf_minmax_device(double *d_phi, int32_t *d_phiNB, int32_t *d_phiSB, int nx, int ny, int nz,
+                      int iter, double dx, double h1, double tol, int mode, int *iters_done,
+                      double *rms_trace, int trace_cap, void *stream);
+
+/* ---- narrowBand --------------------------------------------------------------------------
+ * Replaces SUBROUTINE narrowBand(nx,ny,nz,dx,phi,phiNB,phiSB), subs.f90:178-207. */
+int lsf_narrowband(const double *phi, int32_t *phiNB, int32_t *phiSB, int nx, int ny, int nz,
+                   double dx);
+int lsf_narrowband_device(const double *d_phi, int32_t *d_phiNB, int32_t *d_phiSB, int nx, int ny,
+                          int nz, double dx, void *stream);
+
+/* ---- block-decomposed building blocks (multi-GPU Jacobi; one process per GPU) -------------
+ * A rank holds a box of the global field: local extents (lx,ly,lz), whose element (0,0,0) is the
+ * global point (gx0,gy0,gz0); global extents are (nx+1,ny+1,nz+1).  The box includes ghost layers
+ * (3 points towards each neighbouring rank) and the physical wall points it owns.  All calls are
+ * asynchronous on `stream` (no synchronisation, no allocation: graph-capturable).
+ */
+typedef struct lsf_box {
+    int lx, ly, lz;    /* local allocation extents (points)                          */
+    int gx0, gy0, gz0; /* global index of local point (0,0,0)                        */
+    int nx, ny, nz;    /* global: field is (0:nx,0:ny,0:nz)                          */
+} lsf_box;
+
+/* One Jacobi update (subs.f90:747-750 per cell, all reads from d_in) of the local cells
+ * [lo[0],hi[0]) x [lo[1],hi[1]) x [lo[2],hi[2]) (local indices; must be interior cells of the
+ * global grid, 1..n-1).  Adds sum((out-in)^2) over those cells to *d_sumsq (a device double;
+ * contributions are combined in a fixed order, so results are reproducible).  */
+int lsf_jacobi_sweep_box(const double *d_in, double *d_out, const double *d_phiS, const lsf_box *box,
+                         const int lo[3], const int hi[3], double dx, double h, int mode,
+                         double *d_sumsq, void *stream);
+
+/* Extrapolation boundary condition (subs.f90:859-897, closed form) on the wall points of the
+ * global grid that lie inside the local index range [lo,hi); reads interior values from d_out,
+ * writes the wall points of d_out, adds sum((out-in)^2) over those wall points to *d_sumsq. */
+int lsf_bc_box(const double *d_in, double *d_out, const lsf_box *box, const int lo[3], const int hi[3],
+               double dx, double *d_sumsq, void *stream);
+
+/* Pack / unpack the local sub-box [lo,hi) to / from a contiguous buffer (i fastest). */
+int lsf_pack_box(const double *d_field, const lsf_box *box, const int lo[3], const int hi[3],
+                 double *d_buf, void *stream);
+int lsf_unpack_box(double *d_field, const lsf_box *box, const int lo[3], const int hi[3],
+                   const double *d_buf, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSF_H */

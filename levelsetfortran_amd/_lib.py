@@ -1,0 +1,96 @@
+"""ctypes binding of liblsf_hip.so (include/lsf.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (``make -C
+levelsetfortran_amd/csrc``).  There is no CPU fallback anywhere in this package: if the library is
+missing, or no gfx950 device is usable, the compute entry points raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_double, c_int, c_int32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblsf_hip.so")
+
+# include/lsf.h
+LSF_OK, LSF_ERR_NAN, LSF_ERR_INVALID, LSF_ERR_HIP, LSF_ERR_NO_DEVICE = 0, 1, 2, 3, 4
+LSF_ORDER_GS, LSF_ORDER_JACOBI = 0, 1
+LSF_ARITH_FAST, LSF_ARITH_STRICT = 0x000, 0x100
+
+
+class LsfBox(ctypes.Structure):
+    """struct lsf_box (include/lsf.h)."""
+
+    _fields_ = [(n, c_int) for n in ("lx", "ly", "lz", "gx0", "gy0", "gz0", "nx", "ny", "nz")]
+
+
+class LsfError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"liblsf_hip error {code}: {message}")
+        self.code = code
+
+
+class LsfNaNError(LsfError):
+    """RMS became NaN: the reference executes STOP here (subs.f90:926 / set3d.f90:458)."""
+
+
+_dp, _ip, _i3 = POINTER(c_double), POINTER(c_int32), POINTER(c_int * 3)
+
+# name -> (restype, argtypes); every symbol include/lsf.h declares
+SIGNATURES = {
+    "lsf_version": (c_int, []),
+    "lsf_last_error": (ctypes.c_char_p, []),
+    "lsf_device_count": (c_int, []),
+    "lsf_set_device": (c_int, [c_int]),
+    "lsf_release_workspace": (c_int, []),
+    "lsf_reinit": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_int,
+                           POINTER(c_int), c_void_p, c_int]),
+    "lsf_reinit_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
+                                  c_int, c_int, POINTER(c_int), c_void_p, c_int, c_void_p]),
+    "lsf_minmax": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double,
+                           c_double, c_int, POINTER(c_int), c_void_p, c_int]),
+    "lsf_minmax_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double,
+                                  c_double, c_int, POINTER(c_int), c_void_p, c_int, c_void_p]),
+    "lsf_narrowband": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double]),
+    "lsf_narrowband_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p]),
+    "lsf_jacobi_sweep_box": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3,
+                                     c_double, c_double, c_int, c_void_p, c_void_p]),
+    "lsf_bc_box": (c_int, [c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_double, c_void_p,
+                           c_void_p]),
+    "lsf_pack_box": (c_int, [c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_void_p, c_void_p]),
+    "lsf_unpack_box": (c_int, [c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load liblsf_hip.so and bind every symbol of include/lsf.h.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  levelsetfortran_amd has no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc == LSF_OK:
+        return
+    msg = (load().lsf_last_error() or b"").decode("utf-8", "replace")
+    if rc == LSF_ERR_NAN:
+        raise LsfNaNError(rc, msg)
+    raise LsfError(rc, msg)
+
+
+def int3(v) -> "ctypes.Array":
+    return (c_int * 3)(int(v[0]), int(v[1]), int(v[2]))

@@ -1,0 +1,610 @@
+// lsf_api.hip -- C ABI (include/lsf.h) over the gfx950 kernels.  Host orchestration only: the
+// arithmetic lives in lsf_cell.hpp / lsf_kernels.hpp.  There is deliberately no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/lsf.h"
+#include "lsf_kernels.hpp"
+
+using namespace lsf;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local int g_device = 0;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(LSF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+constexpr int GS_TA = 16;      // tile length along i of the exact-GS reinit kernel
+constexpr int MM_TA = 32;      // tile length along i of the exact-GS min/max kernel
+constexpr int CHECK_EVERY = 8; // sweeps between host reads of the device stop flag
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct TileList {
+    uint32_t* d = nullptr;
+    std::vector<int> off; // plane offsets, size nplanes+1
+};
+
+enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_NSLOTS };
+
+struct Ctx {
+    Buf slot[S_NSLOTS];
+    std::map<hipStream_t, Buf> part_by_stream;
+    std::map<uint64_t, TileList> tiles;
+    bool checked = false;
+};
+
+std::mutex g_mu;
+std::map<int, Ctx> g_ctx;
+
+int ensure_device()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(LSF_ERR_NO_DEVICE, "no HIP device visible: liblsf_hip has no CPU fallback");
+    }
+    if (g_device >= n) return fail(LSF_ERR_NO_DEVICE, "selected device index out of range");
+    HIPCHK(hipSetDevice(g_device));
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx& c = g_ctx[g_device];
+    if (!c.checked) {
+        hipDeviceProp_t pr;
+        HIPCHK(hipGetDeviceProperties(&pr, g_device));
+        if (std::strncmp(pr.gcnArchName, "gfx950", 6) != 0)
+            return fail(LSF_ERR_NO_DEVICE, std::string("device is ") + pr.gcnArchName +
+                                               ", this library carries gfx950 (MI355X) code only");
+        c.checked = true;
+    }
+    return LSF_OK;
+}
+
+Ctx& ctx()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_ctx[g_device];
+}
+
+int ws(Buf& b, size_t bytes)
+{
+    if (b.bytes >= bytes && b.p) return LSF_OK;
+    if (b.p) HIPCHK(hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    HIPCHK(hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return LSF_OK;
+}
+
+// tiles of an (nA,nB,nC) tile grid sorted by hyperplane A+B+C (sweep frame)
+int get_tiles(int nA, int nB, int nC, TileList** out)
+{
+    if (nA > 1023 || nB > 1023 || nC > 1023) return fail(LSF_ERR_INVALID, "grid too large for tile index packing");
+    const uint64_t key = ((uint64_t)nA << 40) | ((uint64_t)nB << 20) | (uint64_t)nC;
+    Ctx& c = ctx();
+    auto it = c.tiles.find(key);
+    if (it == c.tiles.end()) {
+        TileList tl;
+        std::vector<uint32_t> h;
+        h.reserve((size_t)nA * nB * nC);
+        const int nplanes = nA + nB + nC - 2;
+        tl.off.assign(nplanes + 1, 0);
+        for (int P = 0; P < nplanes; ++P) {
+            tl.off[P] = (int)h.size();
+            // a-fastest inside a plane: neighbouring blocks share halo rows
+            for (int C = 0; C < nC; ++C)
+                for (int B = 0; B < nB; ++B) {
+                    const int A = P - B - C;
+                    if (A < 0 || A >= nA) continue;
+                    h.push_back((uint32_t)A | ((uint32_t)B << 10) | ((uint32_t)C << 20));
+                }
+        }
+        tl.off[nplanes] = (int)h.size();
+        HIPCHK(hipMalloc((void**)&tl.d, h.size() * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(tl.d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        it = c.tiles.emplace(key, std::move(tl)).first;
+    }
+    *out = &it->second;
+    return LSF_OK;
+}
+
+double rms_denominator(int nx, int ny, int nz)
+{
+    // INTEGER*4 product nx*ny*nz, subs.f90:914 / set3d.f90:447 (wraps like the reference)
+    return (double)(int32_t)((uint32_t)nx * (uint32_t)ny * (uint32_t)nz);
+}
+
+const int RASTER_SIGN[8][3] = {{+1, +1, +1}, {+1, +1, -1}, {+1, -1, -1}, {-1, -1, -1},
+                               {-1, +1, -1}, {-1, -1, +1}, {-1, +1, +1}, {+1, -1, +1}};
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+dim3 bc_grid(int e0, int e1, int e2)
+{
+    const int m = std::max(e0, std::max(e1, e2));
+    return dim3(cdiv(m, 64), m, 6);
+}
+
+int check_dims(int nx, int ny, int nz)
+{
+    if (nx < 2 || ny < 2 || nz < 2) return fail(LSF_ERR_INVALID, "nx, ny, nz must be >= 2");
+    if ((double)(nx + 1) * (ny + 1) * (nz + 1) > 9.0e9) return fail(LSF_ERR_INVALID, "field too large");
+    return LSF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx,
+                double h, double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace,
+                int trace_cap, hipStream_t st)
+{
+    int rc = check_dims(nx, ny, nz);
+    if (rc) return rc;
+    if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
+    if (first_raster < 0 || first_raster > 7) return fail(LSF_ERR_INVALID, "first_raster must be 0..7");
+    const int order = mode & LSF_ORDER_MASK;
+    const bool strict = (mode & LSF_ARITH_STRICT) != 0;
+    if (order != LSF_ORDER_GS && order != LSF_ORDER_JACOBI) return fail(LSF_ERR_INVALID, "unknown ordering");
+    if (!d_phi) return fail(LSF_ERR_INVALID, "phi is NULL");
+    Ctx& c = ctx();
+    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    const int max_sweeps = iter + 1; // DO n=0,iter (subs.f90:735)
+
+    if ((rc = ws(c.slot[S_PONG], n * sizeof(double)))) return rc;
+    const double* d_phiS = d_phiS_in;
+    if (!d_phiS) {
+        if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
+        HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st)); // :731
+        d_phiS = (const double*)c.slot[S_PHIS].p;
+    }
+    if ((rc = ws(c.slot[S_CTL], 64))) return rc;
+    if ((rc = ws(c.slot[S_TRACE], (size_t)max_sweeps * sizeof(double)))) return rc;
+    int* ctl = (int*)c.slot[S_CTL].p;
+    double* d_trace = (double*)c.slot[S_TRACE].p;
+    HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
+
+    // sweep geometry
+    TileList* tl = nullptr;
+    int nTi = 0, nTj = 0, nTk = 0;
+    dim3 jgrid;
+    long n_sweep_part = 0;
+    if (order == LSF_ORDER_GS) {
+        nTi = cdiv(nx - 1, GS_TA), nTj = cdiv(ny - 1, 8), nTk = cdiv(nz - 1, 8);
+        if ((rc = get_tiles(nTi, nTj, nTk, &tl))) return rc;
+        n_sweep_part = (long)nTi * nTj * nTk;
+    } else {
+        jgrid = dim3(cdiv(nx - 1, JAC_BX), cdiv(ny - 1, JAC_BY), cdiv(nz - 1, JAC_KC));
+        n_sweep_part = (long)jgrid.x * jgrid.y * jgrid.z;
+    }
+    const dim3 bgrid = bc_grid(nx + 1, ny + 1, nz + 1);
+    const long n_bc_part = (long)bgrid.x * bgrid.y * bgrid.z;
+    const long n_part = n_sweep_part + n_bc_part;
+    if ((rc = ws(c.slot[S_PART], (size_t)n_part * sizeof(double)))) return rc;
+    double* part = (double*)c.slot[S_PART].p;
+    const double den = rms_denominator(nx, ny, nz);
+    const Box bx{nx + 1, ny + 1, nz + 1, 0, 0, 0, nx, ny, nz};
+
+    double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
+    int host_ctl[3] = {0, 0, 0};
+    for (int s = 0; s < max_sweeps; ++s) {
+        const double* A = bufs[s & 1];
+        double* B = bufs[(s + 1) & 1];
+        const int* sg = RASTER_SIGN[(first_raster + s) & 7];
+        if (order == LSF_ORDER_GS) {
+            const int nplanes = (int)tl->off.size() - 1;
+            for (int P = 0; P < nplanes; ++P) {
+                const int cnt = tl->off[P + 1] - tl->off[P];
+                if (cnt <= 0) continue;
+                if (strict)
+                    hipLaunchKernelGGL((k_reinit_gs_plane<GS_TA, true>), dim3(cnt), dim3(64), 0, st, A, B, d_phiS,
+                                       nx, ny, nz, sg[0], sg[1], sg[2], tl->d + tl->off[P], nTi, nTj, nTk, dx, h,
+                                       part, ctl);
+                else
+                    hipLaunchKernelGGL((k_reinit_gs_plane<GS_TA, false>), dim3(cnt), dim3(64), 0, st, A, B, d_phiS,
+                                       nx, ny, nz, sg[0], sg[1], sg[2], tl->d + tl->off[P], nTi, nTj, nTk, dx, h,
+                                       part, ctl);
+            }
+        } else {
+            if (strict)
+                hipLaunchKernelGGL((k_reinit_jacobi<true>), jgrid, dim3(JAC_BX, JAC_BY), 0, st, A, B, d_phiS, bx, 1, 1,
+                                   1, nx, ny, nz, dx, h, part, ctl);
+            else
+                hipLaunchKernelGGL((k_reinit_jacobi<false>), jgrid, dim3(JAC_BX, JAC_BY), 0, st, A, B, d_phiS, bx, 1,
+                                   1, 1, nx, ny, nz, dx, h, part, ctl);
+        }
+        hipLaunchKernelGGL(k_bc, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, dx,
+                           part + n_sweep_part, ctl);
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
+        if ((s + 1) % CHECK_EVERY == 0 && s + 1 < max_sweeps) {
+            HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (host_ctl[0]) break;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int nsw = host_ctl[1];
+    if (bufs[nsw & 1] != d_phi)
+        HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (rms_trace && trace_cap > 0 && nsw > 0)
+        HIPCHK(hipMemcpyAsync(rms_trace, d_trace, sizeof(double) * (size_t)std::min(nsw, trace_cap),
+                              hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (sweeps_done) *sweeps_done = nsw;
+    if (host_ctl[2]) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, subs.f90:926)");
+    return LSF_OK;
+}
+
+int narrowband_core(const double* d_phi, int32_t* d_nb, int32_t* d_sb, size_t n, double dx, hipStream_t st)
+{
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_narrowband, dim3(grid), dim3(256), 0, st, d_phi, d_nb, d_sb, (long)n, dx);
+    HIPCHK(hipGetLastError());
+    return LSF_OK;
+}
+
+int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int nz, int iter, double dx,
+                double h1, double tol, int mode, int* iters_done, double* rms_trace, int trace_cap,
+                hipStream_t st)
+{
+    int rc = check_dims(nx, ny, nz);
+    if (rc) return rc;
+    if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
+    const int order = mode & LSF_ORDER_MASK;
+    if (order != LSF_ORDER_GS && order != LSF_ORDER_JACOBI) return fail(LSF_ERR_INVALID, "unknown ordering");
+    if (!d_phi || !d_nb || !d_sb) return fail(LSF_ERR_INVALID, "NULL field");
+    Ctx& c = ctx();
+    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    if ((rc = ws(c.slot[S_PONG], n * sizeof(double)))) return rc;
+    if ((rc = ws(c.slot[S_CTL], 64))) return rc;
+    if ((rc = ws(c.slot[S_TRACE], (size_t)std::max(iter, 1) * sizeof(double)))) return rc;
+    int* ctl = (int*)c.slot[S_CTL].p;
+    double* d_trace = (double*)c.slot[S_TRACE].p;
+    HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
+
+    TileList* tl = nullptr;
+    int nTi = 0, nTj = 0, nTk = 0, jblocks = 0;
+    long n_part;
+    if (order == LSF_ORDER_GS) {
+        nTi = cdiv(nx + 1, MM_TA), nTj = cdiv(ny + 1, 8), nTk = cdiv(nz + 1, 8);
+        if ((rc = get_tiles(nTi, nTj, nTk, &tl))) return rc;
+        n_part = (long)nTi * nTj * nTk;
+    } else {
+        jblocks = (int)std::min<size_t>((n + 255) / 256, 8192);
+        n_part = jblocks;
+    }
+    if ((rc = ws(c.slot[S_PART], (size_t)n_part * sizeof(double)))) return rc;
+    double* part = (double*)c.slot[S_PART].p;
+    const double den = rms_denominator(nx, ny, nz);
+
+    double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
+    int host_ctl[3] = {0, 0, 0};
+    for (int it = 0; it < iter; ++it) { // DO n = 1,iter (set3d.f90:394)
+        const double* A = bufs[it & 1];
+        double* B = bufs[(it + 1) & 1];
+        const int32_t* mask = it == 0 ? d_nb : nullptr;
+        if (order == LSF_ORDER_GS) {
+            const int nplanes = (int)tl->off.size() - 1;
+            for (int P = 0; P < nplanes; ++P) {
+                const int cnt = tl->off[P + 1] - tl->off[P];
+                if (cnt <= 0) continue;
+                hipLaunchKernelGGL((k_minmax_gs_plane<MM_TA>), dim3(cnt), dim3(64), 0, st, A, B, mask, nx, ny, nz,
+                                   tl->d + tl->off[P], nTi, nTj, nTk, dx, h1, part, ctl);
+            }
+        } else {
+            hipLaunchKernelGGL(k_minmax_jacobi, dim3(jblocks), dim3(256), 0, st, A, B, mask, nx, ny, nz, dx, h1, part,
+                               ctl);
+        }
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, n_part, den, tol, d_trace, std::max(iter, 1),
+                           ctl);
+        if ((it + 1) % CHECK_EVERY == 0 && it + 1 < iter) {
+            HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (host_ctl[0]) break;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int nit = host_ctl[1];
+    const bool stopped_early = host_ctl[0] != 0; // converged or NaN: EXIT/STOP before narrowBand
+    // masks the host would hold now (set3d.f90:448-460)
+    if (nit >= 1) {
+        const double* src = nullptr;
+        if (!stopped_early) src = bufs[nit & 1];                  // band refreshed after the last iteration
+        else if (nit >= 2) src = bufs[(nit - 1) & 1];             // refreshed after iteration nit-1
+        if (src && (rc = narrowband_core(src, d_nb, d_sb, n, dx, st))) return rc;
+    }
+    if (bufs[nit & 1] != d_phi)
+        HIPCHK(hipMemcpyAsync(d_phi, bufs[nit & 1], n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (rms_trace && trace_cap > 0 && nit > 0)
+        HIPCHK(hipMemcpyAsync(rms_trace, d_trace, sizeof(double) * (size_t)std::min(nit, trace_cap),
+                              hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (iters_done) *iters_done = nit;
+    if (host_ctl[2]) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, set3d.f90:458)");
+    return LSF_OK;
+}
+
+int box_ok(const lsf_box* b, const int lo[3], const int hi[3])
+{
+    if (!b || !lo || !hi) return fail(LSF_ERR_INVALID, "NULL box/range");
+    if (b->lx < 1 || b->ly < 1 || b->lz < 1) return fail(LSF_ERR_INVALID, "empty box");
+    const int ext[3] = {b->lx, b->ly, b->lz};
+    for (int a = 0; a < 3; ++a)
+        if (lo[a] < 0 || hi[a] > ext[a]) return fail(LSF_ERR_INVALID, "range outside the local box");
+    return LSF_OK;
+}
+
+int stream_partials(hipStream_t st, size_t count, double** out)
+{
+    Ctx& c = ctx();
+    Buf& b = c.part_by_stream[st];
+    int rc = ws(b, count * sizeof(double));
+    if (rc) return rc;
+    *out = (double*)b.p;
+    return LSF_OK;
+}
+
+} // namespace
+
+// =============================================================================================
+extern "C" {
+
+int lsf_version(void) { return LSF_VERSION; }
+
+const char* lsf_last_error(void) { return g_err.c_str(); }
+
+int lsf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int lsf_set_device(int device)
+{
+    if (device < 0) return fail(LSF_ERR_INVALID, "negative device index");
+    g_device = device;
+    return ensure_device();
+}
+
+int lsf_release_workspace(void)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    Ctx& c = ctx();
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& b : c.slot) {
+        if (b.p) HIPCHK(hipFree(b.p));
+        b = Buf{};
+    }
+    for (auto& kv : c.part_by_stream)
+        if (kv.second.p) HIPCHK(hipFree(kv.second.p));
+    c.part_by_stream.clear();
+    for (auto& kv : c.tiles)
+        if (kv.second.d) HIPCHK(hipFree(kv.second.d));
+    c.tiles.clear();
+    return LSF_OK;
+}
+
+int lsf_reinit_device(double* d_phi, const double* d_phiS, int nx, int ny, int nz, int iter, double dx, double h,
+                      double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace,
+                      int trace_cap, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    return reinit_core(d_phi, d_phiS, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done, rms_trace,
+                       trace_cap, (hipStream_t)stream);
+}
+
+int lsf_reinit(double* phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,
+               int* sweeps_done, double* rms_trace, int trace_cap)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = check_dims(nx, ny, nz))) return rc;
+    if (!phi) return fail(LSF_ERR_INVALID, "phi is NULL");
+    Ctx& c = ctx();
+    const size_t bytes = (size_t)(nx + 1) * (ny + 1) * (nz + 1) * sizeof(double);
+    if ((rc = ws(c.slot[S_HPHI], bytes))) return rc;
+    double* d = (double*)c.slot[S_HPHI].p;
+    HIPCHK(hipMemcpy(d, phi, bytes, hipMemcpyHostToDevice));
+    rc = reinit_core(d, nullptr, nx, ny, nz, iter, dx, h, tol, mode, 0, sweeps_done, rms_trace, trace_cap, nullptr);
+    if (rc == LSF_OK || rc == LSF_ERR_NAN) {
+        const std::string keep = g_err;
+        HIPCHK(hipMemcpy(phi, d, bytes, hipMemcpyDeviceToHost));
+        g_err = keep;
+    }
+    return rc;
+}
+
+int lsf_minmax_device(double* d_phi, int32_t* d_phiNB, int32_t* d_phiSB, int nx, int ny, int nz, int iter,
+                      double dx, double h1, double tol, int mode, int* iters_done, double* rms_trace,
+                      int trace_cap, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    return minmax_core(d_phi, d_phiNB, d_phiSB, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace,
+                       trace_cap, (hipStream_t)stream);
+}
+
+int lsf_minmax(double* phi, int32_t* phiNB, int32_t* phiSB, int nx, int ny, int nz, int iter, double dx,
+               double h1, double tol, int mode, int* iters_done, double* rms_trace, int trace_cap)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = check_dims(nx, ny, nz))) return rc;
+    if (!phi || !phiNB || !phiSB) return fail(LSF_ERR_INVALID, "NULL field");
+    Ctx& c = ctx();
+    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    if ((rc = ws(c.slot[S_HPHI], n * sizeof(double)))) return rc;
+    if ((rc = ws(c.slot[S_HNB], n * sizeof(int32_t)))) return rc;
+    if ((rc = ws(c.slot[S_HSB], n * sizeof(int32_t)))) return rc;
+    double* d = (double*)c.slot[S_HPHI].p;
+    int32_t* dnb = (int32_t*)c.slot[S_HNB].p;
+    int32_t* dsb = (int32_t*)c.slot[S_HSB].p;
+    HIPCHK(hipMemcpy(d, phi, n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dnb, phiNB, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dsb, phiSB, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    rc = minmax_core(d, dnb, dsb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap, nullptr);
+    if (rc == LSF_OK || rc == LSF_ERR_NAN) {
+        const std::string keep = g_err;
+        HIPCHK(hipMemcpy(phi, d, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(phiNB, dnb, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(phiSB, dsb, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        g_err = keep;
+    }
+    return rc;
+}
+
+int lsf_narrowband_device(const double* d_phi, int32_t* d_phiNB, int32_t* d_phiSB, int nx, int ny, int nz,
+                          double dx, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = check_dims(nx, ny, nz))) return rc;
+    if (!d_phi || !d_phiNB || !d_phiSB) return fail(LSF_ERR_INVALID, "NULL field");
+    rc = narrowband_core(d_phi, d_phiNB, d_phiSB, (size_t)(nx + 1) * (ny + 1) * (nz + 1), dx, (hipStream_t)stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return LSF_OK;
+}
+
+int lsf_narrowband(const double* phi, int32_t* phiNB, int32_t* phiSB, int nx, int ny, int nz, double dx)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = check_dims(nx, ny, nz))) return rc;
+    if (!phi || !phiNB || !phiSB) return fail(LSF_ERR_INVALID, "NULL field");
+    Ctx& c = ctx();
+    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    if ((rc = ws(c.slot[S_HPHI], n * sizeof(double)))) return rc;
+    if ((rc = ws(c.slot[S_HNB], n * sizeof(int32_t)))) return rc;
+    if ((rc = ws(c.slot[S_HSB], n * sizeof(int32_t)))) return rc;
+    HIPCHK(hipMemcpy(c.slot[S_HPHI].p, phi, n * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = narrowband_core((const double*)c.slot[S_HPHI].p, (int32_t*)c.slot[S_HNB].p, (int32_t*)c.slot[S_HSB].p, n,
+                              dx, nullptr)))
+        return rc;
+    HIPCHK(hipMemcpy(phiNB, c.slot[S_HNB].p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(phiSB, c.slot[S_HSB].p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return LSF_OK;
+}
+
+int lsf_jacobi_sweep_box(const double* d_in, double* d_out, const double* d_phiS, const lsf_box* box,
+                         const int lo[3], const int hi[3], double dx, double h, int mode, double* d_sumsq,
+                         void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = box_ok(box, lo, hi))) return rc;
+    if (!d_in || !d_out || !d_phiS || !d_sumsq) return fail(LSF_ERR_INVALID, "NULL pointer");
+    if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) return LSF_OK; // empty region
+    // the region must consist of interior cells of the global grid with their stencil inside the box
+    const int g0[3] = {box->gx0, box->gy0, box->gz0}, nn[3] = {box->nx, box->ny, box->nz};
+    const int ext[3] = {box->lx, box->ly, box->lz};
+    for (int a = 0; a < 3; ++a) {
+        if (lo[a] + g0[a] < 1 || hi[a] - 1 + g0[a] > nn[a] - 1)
+            return fail(LSF_ERR_INVALID, "sweep region must lie in the global interior 1..n-1");
+        for (int e = 0; e < 2; ++e) {
+            const int l = e ? hi[a] - 1 : lo[a], g = l + g0[a];
+            // reach: 3 only if the cell can take the WENO branch along this axis; 1 is always needed
+            const int reach = (g > 3 && g < nn[a] - 4) ? 3 : 1;
+            if (l - reach < 0 || l + reach > ext[a] - 1)
+                return fail(LSF_ERR_INVALID, "stencil of the sweep region leaves the local box (ghost layers missing)");
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(cdiv(hi[0] - lo[0], JAC_BX), cdiv(hi[1] - lo[1], JAC_BY), cdiv(hi[2] - lo[2], JAC_KC));
+    const long np = (long)grid.x * grid.y * grid.z;
+    double* part = nullptr;
+    if ((rc = stream_partials(st, (size_t)np, &part))) return rc;
+    const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
+    if (mode & LSF_ARITH_STRICT)
+        hipLaunchKernelGGL((k_reinit_jacobi<true>), grid, dim3(JAC_BX, JAC_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0],
+                           lo[1], lo[2], hi[0], hi[1], hi[2], dx, h, part, (const int*)nullptr);
+    else
+        hipLaunchKernelGGL((k_reinit_jacobi<false>), grid, dim3(JAC_BX, JAC_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0],
+                           lo[1], lo[2], hi[0], hi[1], hi[2], dx, h, part, (const int*)nullptr);
+    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(256), 0, st, part, np, d_sumsq);
+    HIPCHK(hipGetLastError());
+    return LSF_OK;
+}
+
+int lsf_bc_box(const double* d_in, double* d_out, const lsf_box* box, const int lo[3], const int hi[3],
+               double dx, double* d_sumsq, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = box_ok(box, lo, hi))) return rc;
+    if (!d_in || !d_out || !d_sumsq) return fail(LSF_ERR_INVALID, "NULL pointer");
+    if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) return LSF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid = bc_grid(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
+    const long np = (long)grid.x * grid.y * grid.z;
+    double* part = nullptr;
+    if ((rc = stream_partials(st, (size_t)np, &part))) return rc;
+    const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
+    hipLaunchKernelGGL(k_bc, grid, dim3(64), 0, st, d_in, d_out, bx, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], dx,
+                       part, (const int*)nullptr);
+    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(256), 0, st, part, np, d_sumsq);
+    HIPCHK(hipGetLastError());
+    return LSF_OK;
+}
+
+static int pack_impl(const double* d_field, double* d_field_w, const lsf_box* box, const int lo[3], const int hi[3],
+                     double* d_buf, int unpack, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = box_ok(box, lo, hi))) return rc;
+    if (!d_buf || (!d_field && !d_field_w)) return fail(LSF_ERR_INVALID, "NULL pointer");
+    const int e0 = hi[0] - lo[0], e1 = hi[1] - lo[1], e2 = hi[2] - lo[2];
+    if (e0 <= 0 || e1 <= 0 || e2 <= 0) return LSF_OK;
+    const long n = (long)e0 * e1 * e2;
+    const int grid = (int)std::min<long>((n + 255) / 256, 4096);
+    const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
+    hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_field, d_buf, bx, lo[0], lo[1], lo[2],
+                       e0, e1, e2, unpack, d_field_w);
+    HIPCHK(hipGetLastError());
+    return LSF_OK;
+}
+
+int lsf_pack_box(const double* d_field, const lsf_box* box, const int lo[3], const int hi[3], double* d_buf,
+                 void* stream)
+{
+    return pack_impl(d_field, nullptr, box, lo, hi, d_buf, 0, stream);
+}
+
+int lsf_unpack_box(double* d_field, const lsf_box* box, const int lo[3], const int hi[3], const double* d_buf,
+                   void* stream)
+{
+    return pack_impl(nullptr, d_field, box, lo, hi, const_cast<double*>(d_buf), 1, stream);
+}
+
+} // extern "C"

@@ -1,0 +1,275 @@
+// lsf_cell.hpp -- per-cell arithmetic of the hot path, device side (gfx950).
+//
+// Two arithmetic flavours of the same update (include/lsf.h, LSF_ARITH_*):
+//   STRICT: every operation exactly as subs.f90 writes it, left to right, no FMA contraction,
+//           IEEE division and square root -> bit-identical to the reference Fortran.
+//   FAST:   same mathematics, restructured for the fp64 VALU: differences are kept unscaled
+//           (one multiply by 1/dx at the end instead of 17 divisions per axis), the three
+//           non-linear weights of a WENO side share one reciprocal, FMA contraction is on.
+//           Rounding-level differences only (measured <= 1e-13 RMS against STRICT).
+//
+// Reference lines: weno subs.f90:489-711, phiSign subs.f90:152-172, update subs.f90:747-750,
+// secondDeriv subs.f90:384-389, minMax subs.f90:453-481.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lsf {
+
+// Fortran MAX/MIN as compiled by flang (compare + select); STRICT only.
+__device__ __forceinline__ double fmax2(double a, double b) { return (a > b) ? a : b; }
+__device__ __forceinline__ double fmin2(double a, double b) { return (a < b) ? a : b; }
+
+// ---------------------------------------------------------------------------------------------
+// STRICT: one axis of the WENO branch (subs.f90:509-552 / :555-598 / :601-644).
+// q[0..6] = phi at -3..+3 along the axis in ABSOLUTE orientation; yquirk = subs.f90:576.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void weno_axis_strict(const double q[7], double dx, bool yquirk, double& dm,
+                                                 double& dp)
+{
+#pragma clang fp contract(off)
+    const double m3 = q[0], m2 = q[1], m1 = q[2], c0 = q[3], r1 = q[4], r2 = q[5], r3 = q[6];
+    const double ap = (r3 - 2. * r2 + r1) / dx;
+    const double am = (m3 - 2. * m2 + m1) / dx;
+    const double bp = (r2 - 2. * r1 + c0) / dx;
+    const double bm = (m2 - 2. * m1 + c0) / dx;
+    const double cp = (r1 - 2. * c0 + m1) / dx;
+    const double cm = cp, dpp = bm, dmm = bp;
+
+    const double IS0p = 13. * (ap - bp) * (ap - bp) + 3. * (ap - 3. * bp) * (ap - 3. * bp);
+    const double IS0m = 13. * (am - bm) * (am - bm) + 3. * (am - 3. * bm) * (am - 3. * bm);
+    const double IS1p = 13. * (bp - cp) * (bp - cp) + 3. * (bp + cp) * (bp + cp);
+    const double IS1m = 13. * (bm - cm) * (bm - cm) + 3. * (bm + cm) * (bm + cm);
+    const double IS2p = 13. * (cp - dpp) * (cp - dpp) + 3. * (3. * cp - dpp) * (3. * cp - dpp);
+    const double IS2m = 13. * (cm - dmm) * (cm - dmm) + 3. * (3. * cm - dmm) * (3. * cm - dmm);
+
+    const double p0 = (m2 - m3) / dx;
+    const double p1 = (m1 - m2) / dx;
+    const double p2 = (c0 - m1) / dx;
+    const double p3 = (r1 - c0) / dx;
+    const double p4 = (r2 - r1) / dx;
+    const double p5 = yquirk ? (r3 - r3) / dx : (r3 - r2) / dx;
+
+    const double epsp =
+        (1.E-6) * fmax2(p1 * p1, fmax2(p2 * p2, fmax2(p3 * p3, fmax2(p4 * p4, p5 * p5)))) + 1.E-99;
+    const double epsm =
+        (1.E-6) * fmax2(p0 * p0, fmax2(p1 * p1, fmax2(p2 * p2, fmax2(p3 * p3, p4 * p4)))) + 1.E-99;
+
+    const double a0p = 1. / ((epsp + IS0p) * (epsp + IS0p));
+    const double a0m = 1. / ((epsm + IS0m) * (epsm + IS0m));
+    const double a1p = 6. / ((epsp + IS1p) * (epsp + IS1p));
+    const double a1m = 6. / ((epsm + IS1m) * (epsm + IS1m));
+    const double a2p = 3. / ((epsp + IS2p) * (epsp + IS2p));
+    const double a2m = 3. / ((epsm + IS2m) * (epsm + IS2m));
+
+    const double w0p = a0p / (a0p + a1p + a2p);
+    const double w0m = a0m / (a0m + a1m + a2m);
+    const double w2p = a2p / (a0p + a1p + a2p);
+    const double w2m = a2m / (a0m + a1m + a2m);
+
+    const double PWp = 1. / 3. * w0p * (ap - 2. * bp + cp) + 1. / 6. * (w2p - 0.5) * (bp - 2. * cp + dpp);
+    const double PWm = 1. / 3. * w0m * (am - 2. * bm + cm) + 1. / 6. * (w2m - 0.5) * (bm - 2. * cm + dmm);
+
+    dm = 1. / 12. * (-p1 + 7. * p2 + 7. * p3 - p4) - PWm;
+    dp = 1. / 12. * (-p1 + 7. * p2 + 7. * p3 - p4) + PWp;
+}
+
+// STRICT: Godunov switch + magnitude, subs.f90:667-702.
+__device__ __forceinline__ double godunov_strict(double phic, double a, double b, double c, double d,
+                                                 double e, double f)
+{
+#pragma clang fp contract(off)
+    const double pa = fmax2(a, 0.), pb = fmax2(b, 0.), pc = fmax2(c, 0.);
+    const double pd = fmax2(d, 0.), pe = fmax2(e, 0.), pf = fmax2(f, 0.);
+    const double na = fmin2(a, 0.), nb = fmin2(b, 0.), nc = fmin2(c, 0.);
+    const double nd = fmin2(d, 0.), ne = fmin2(e, 0.), nf = fmin2(f, 0.);
+    double gX, gY, gZ;
+    if (phic > 0.) {
+        gX = fmax2(pa * pa, nb * nb);
+        gY = fmax2(pc * pc, nd * nd);
+        gZ = fmax2(pe * pe, nf * nf);
+    } else {
+        gX = fmax2(pb * pb, na * na);
+        gY = fmax2(pd * pd, nc * nc);
+        gZ = fmax2(pf * pf, ne * ne);
+    }
+    return __builtin_sqrt(gX + gY + gZ);
+}
+
+// STRICT cell update: returns phi_new.  qx/qy/qz: -3..+3 stencils (only [2..4] are read when
+// !weno_ok, the first-order branch subs.f90:657-662).
+__device__ __forceinline__ double cell_update_strict(const double qx[7], const double qy[7],
+                                                     const double qz[7], bool weno_ok, double pS,
+                                                     double dx, double h)
+{
+#pragma clang fp contract(off)
+    double a, b, c, d, e, f;
+    const double phic = qx[3];
+    if (weno_ok) {
+        weno_axis_strict(qx, dx, false, a, b);
+        weno_axis_strict(qy, dx, true, c, d);
+        weno_axis_strict(qz, dx, false, e, f);
+    } else {
+        a = (phic - qx[2]) / dx;
+        b = (qx[4] - phic) / dx;
+        c = (phic - qy[2]) / dx;
+        d = (qy[4] - phic) / dx;
+        e = (phic - qz[2]) / dx;
+        f = (qz[4] - phic) / dx;
+    }
+    const double gM = godunov_strict(phic, a, b, c, d, e, f);
+    const double sgn = pS / __builtin_sqrt(pS * pS + dx * dx * gM); // subs.f90:169
+    const double k1 = sgn * (1. - gM);                              // subs.f90:749
+    return phic + h * k1;                                           // subs.f90:750
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST flavour
+// ---------------------------------------------------------------------------------------------
+// full-precision reciprocal from v_rcp_f64 + two Newton steps (no div_scale/div_fixup: the
+// arguments here are sums of squares plus a positive floor, never zero/inf/denormal-critical)
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
+// smoothness indicator 13 (x-y)^2 + 3 t^2 with t supplied by the caller
+__device__ __forceinline__ double is_form(double diff, double t)
+{
+    return __builtin_fma(13.0 * diff, diff, 3.0 * (t * t));
+}
+
+// One axis, unscaled: returns dm*dx and dp*dx (the caller multiplies by 1/dx once).
+// floor2 = 1e-99 * dx^2 (the reference's epsilon floor in unscaled units).
+__device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2, bool yquirk, double& dm,
+                                               double& dp)
+{
+    // first differences d_k = q[k+1]-q[k]  (p_k * dx)
+    const double d0 = q[1] - q[0], d1 = q[2] - q[1], d2 = q[3] - q[2];
+    const double d3 = q[4] - q[3], d4 = q[5] - q[4], d5 = q[6] - q[5];
+    // second differences (ap,bp,cp,bm,am)*dx
+    const double am = d1 - d0, bm = d2 - d1, cp = d3 - d2, bp = d4 - d3, ap = d5 - d4;
+
+    const double IS0p = is_form(ap - bp, __builtin_fma(-3.0, bp, ap));
+    const double IS0m = is_form(am - bm, __builtin_fma(-3.0, bm, am));
+    const double IS1p = is_form(bp - cp, bp + cp);
+    const double IS1m = is_form(bm - cp, bm + cp);
+    const double IS2p = is_form(cp - bm, __builtin_fma(3.0, cp, -bm));
+    const double IS2m = is_form(cp - bp, __builtin_fma(3.0, cp, -bp));
+
+    const double s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3, s4 = d4 * d4;
+    const double mid = __builtin_fmax(__builtin_fmax(s1, s2), __builtin_fmax(s3, s4));
+    const double s5 = yquirk ? 0.0 : d5 * d5;
+    const double epsp = __builtin_fma(1.E-6, __builtin_fmax(mid, s5), floor2);
+    const double epsm = __builtin_fma(1.E-6, __builtin_fmax(mid, d0 * d0), floor2);
+
+    // alpha_k = c_k / q_k^2, w_k = alpha_k / sum  ->  w0 = (q1 q2)^2 / D, w2 = 3 (q0 q1)^2 / D,
+    // D = (q1 q2)^2 + 6 (q0 q2)^2 + 3 (q0 q1)^2 : one reciprocal per side
+    double w0p, w2p, w0m, w2m;
+    {
+        const double q0 = epsp + IS0p, q1 = epsp + IS1p, q2 = epsp + IS2p;
+        const double t12 = q1 * q2, t02 = q0 * q2, t01 = q0 * q1;
+        const double n0 = t12 * t12, n1 = t02 * t02, n2 = 3.0 * (t01 * t01);
+        const double D = __builtin_fma(6.0, n1, n0) + n2;
+        const double r = rcp_nr(__builtin_fmax(D, 1e-300));
+        w0p = n0 * r;
+        w2p = n2 * r;
+    }
+    {
+        const double q0 = epsm + IS0m, q1 = epsm + IS1m, q2 = epsm + IS2m;
+        const double t12 = q1 * q2, t02 = q0 * q2, t01 = q0 * q1;
+        const double n0 = t12 * t12, n1 = t02 * t02, n2 = 3.0 * (t01 * t01);
+        const double D = __builtin_fma(6.0, n1, n0) + n2;
+        const double r = rcp_nr(__builtin_fmax(D, 1e-300));
+        w0m = n0 * r;
+        w2m = n2 * r;
+    }
+    // (ap-2bp+cp), (bp-2cp+bm), (am-2bm+cp)
+    const double Sp = (ap - bp) - (bp - cp);
+    const double S0 = (bp - cp) - (cp - bm);
+    const double Sm = (am - bm) - (bm - cp);
+    const double PWp = __builtin_fma((1.0 / 3.0) * w0p, Sp, (1.0 / 6.0) * (w2p - 0.5) * S0);
+    const double PWm = __builtin_fma((1.0 / 3.0) * w0m, Sm, (1.0 / 6.0) * (w2m - 0.5) * S0);
+    const double cen = (1.0 / 12.0) * (7.0 * (d2 + d3) - (d1 + d4));
+    dm = cen - PWm;
+    dp = cen + PWp;
+}
+
+__device__ __forceinline__ double cell_update_fast(const double qx[7], const double qy[7],
+                                                   const double qz[7], bool weno_ok, double pS, double dx,
+                                                   double inv_dx, double floor2, double h)
+{
+    double a, b, c, d, e, f; // unscaled one-sided differences (true value * dx)
+    const double phic = qx[3];
+    if (weno_ok) {
+        weno_axis_fast(qx, floor2, false, a, b);
+        weno_axis_fast(qy, floor2, true, c, d);
+        weno_axis_fast(qz, floor2, false, e, f);
+    } else {
+        a = phic - qx[2];
+        b = qx[4] - phic;
+        c = phic - qy[2];
+        d = qy[4] - phic;
+        e = phic - qz[2];
+        f = qz[4] - phic;
+    }
+    // Godunov (subs.f90:667-692): phi>0 : max(max(a,0)^2, min(b,0)^2) ; else swap roles
+    const bool pos = phic > 0.;
+    const double ua = pos ? __builtin_fmax(a, 0.) : __builtin_fmin(a, 0.);
+    const double ub = pos ? __builtin_fmin(b, 0.) : __builtin_fmax(b, 0.);
+    const double uc = pos ? __builtin_fmax(c, 0.) : __builtin_fmin(c, 0.);
+    const double ud = pos ? __builtin_fmin(d, 0.) : __builtin_fmax(d, 0.);
+    const double ue = pos ? __builtin_fmax(e, 0.) : __builtin_fmin(e, 0.);
+    const double uf = pos ? __builtin_fmin(f, 0.) : __builtin_fmax(f, 0.);
+    const double gX = __builtin_fmax(ua * ua, ub * ub);
+    const double gY = __builtin_fmax(uc * uc, ud * ud);
+    const double gZ = __builtin_fmax(ue * ue, uf * uf);
+    const double gM = __builtin_sqrt(gX + gY + gZ) * inv_dx;
+    const double sgn = pS / __builtin_sqrt(__builtin_fma(pS, pS, dx * dx * gM));
+    return __builtin_fma(h, sgn * (1. - gM), phic);
+}
+
+template <bool STRICT>
+__device__ __forceinline__ double cell_update(const double qx[7], const double qy[7], const double qz[7],
+                                              bool weno_ok, double pS, double dx, double inv_dx,
+                                              double floor2, double h)
+{
+    if constexpr (STRICT)
+        return cell_update_strict(qx, qy, qz, weno_ok, pS, dx, h);
+    else
+        return cell_update_fast(qx, qy, qz, weno_ok, pS, dx, inv_dx, floor2, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// min/max flow
+// ---------------------------------------------------------------------------------------------
+// secondDeriv order 2 (subs.f90:384-389) summed as minMax does (subs.f90:461): curv.
+// c = centre, (xp,xm,yp,ym,zp,zm) frozen neighbours.  Written so that STRICT and FAST agree
+// bit-for-bit (contraction is switched off here: the kernel is bandwidth-bound).
+__device__ __forceinline__ double minmax_curv(double c, double xp, double xm, double yp, double ym,
+                                              double zp, double zm, double dxx)
+{
+#pragma clang fp contract(off)
+    const double pxx = (-2. * c + xp + xm) * dxx;
+    const double pyy = (-2. * c + yp + ym) * dxx;
+    const double pzz = (-2. * c + zp + zm) * dxx;
+    return pxx + pyy + pzz;
+}
+
+// minMax switch (subs.f90:473-481) on the in-place neighbourhood, then the host update
+// set3d.f90:426.  Order of the pAve sum: centre, i-1, i+1, j+1, j-1, k+1, k-1.
+__device__ __forceinline__ double minmax_update(double c, double im, double ip, double jp, double jm,
+                                                double kp, double km, double curv, double h1)
+{
+#pragma clang fp contract(off)
+    double pAve = c + im + ip + jp + jm + kp + km;
+    pAve = pAve / 7.;
+    const double F = (pAve < 0.) ? fmin2(curv, 0.0) : fmax2(curv, 0.0);
+    return c + h1 * F;
+}
+
+} // namespace lsf

@@ -1,0 +1,522 @@
+// lsf_kernels.hpp -- HIP kernels for gfx950 (MI355X).  No MFMA: the path is a radius-3 star
+// stencil in fp64 (HBM / fp64-VALU bound).  See DESIGN.md for the layout and the rooflines.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lsf_cell.hpp"
+
+namespace lsf {
+
+// A rank-local box of the global field (single GPU: the whole field, offsets 0).
+struct Box {
+    int lx, ly, lz;    // local extents (points)
+    int gx0, gy0, gz0; // global index of local point 0
+    int nx, ny, nz;    // global field is (0:nx,0:ny,0:nz)
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    // fixed butterfly -> deterministic
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// =============================================================================================
+// Reinit, exact Gauss-Seidel ordering: one wavefront per tile, tiles released plane by plane.
+// =============================================================================================
+// Tile = TA x 8 x 8 cells (i x j x k), anchored at cell 1.  The 64 lanes are the 8x8 (j,k) cross
+// section; lane (b,c) marches its i-row with skew a = s - b - c (all in the SWEEP frame, i.e.
+// reflected for negative directions), so every cell sees its -1..-3 neighbours already updated and
+// its +1..+3 neighbours not yet updated: exactly the reference's in-place raster order
+// (SURVEY.md appendix B).  Ping-pong: old values come from A, already-new values of upstream
+// tiles from B, results go to B.
+//
+// LDS image (doubles), ABSOLUTE orientation, star shaped:
+//   core [8][8][TA+6]  : x in [-3,TA+3) for the tile's own (y,z)
+//   yh   [8][6][TA]    : y in {-3,-2,-1, nj, nj+1, nj+2} (stored as 0..5), x in [0,TA)
+//   zh   [6][8][TA]    : z likewise
+template <int TA>
+struct GsTile {
+    static constexpr int RA = TA + 6;
+    static constexpr int CORE = 64 * RA;
+    static constexpr int YH = 8 * 6 * TA;
+    static constexpr int ZH = 6 * 8 * TA;
+    static constexpr int TOTAL = CORE + YH + ZH;
+};
+
+template <int TA, bool STRICT>
+__global__ __launch_bounds__(64) void k_reinit_gs_plane(const double* __restrict__ A, double* __restrict__ B,
+                                                        const double* __restrict__ phiS, int nx, int ny,
+                                                        int nz, int si, int sj, int sk,
+                                                        const uint32_t* __restrict__ tiles, int nTi, int nTj,
+                                                        int nTk, double dx, double h,
+                                                        double* __restrict__ partials,
+                                                        const int* __restrict__ done)
+{
+    using T = GsTile<TA>;
+    __shared__ double lds[T::TOTAL];
+    if (*done) return;
+
+    const int lane = threadIdx.x;
+    const uint32_t packed = tiles[blockIdx.x];
+    const int fA = packed & 0x3ff, fB = (packed >> 10) & 0x3ff, fC = (packed >> 20) & 0x3ff;
+    const int ti = si > 0 ? fA : nTi - 1 - fA;
+    const int tj = sj > 0 ? fB : nTj - 1 - fB;
+    const int tk = sk > 0 ? fC : nTk - 1 - fC;
+    const int i_lo = 1 + ti * TA, j_lo = 1 + tj * 8, k_lo = 1 + tk * 8;
+    const int ni = min(TA, nx - i_lo), nj = min(8, ny - j_lo), nk = min(8, nz - k_lo);
+    const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1);
+
+    double* core = lds;
+    double* yh = lds + T::CORE;
+    double* zh = lds + T::CORE + T::YH;
+
+    // ---- load ---------------------------------------------------------------------------
+    // value for global point (gi,gj,gk): B if it is an interior cell of an upstream tile, else A
+    auto fetch = [&](int gi, int gj, int gk) -> double {
+        if (gi < 0 || gi > nx || gj < 0 || gj > ny || gk < 0 || gk > nz) return 0.0;
+        const bool interior = gi >= 1 && gi <= nx - 1 && gj >= 1 && gj <= ny - 1 && gk >= 1 && gk <= nz - 1;
+        const bool up = (si > 0 ? gi < i_lo : gi >= i_lo + ni) || (sj > 0 ? gj < j_lo : gj >= j_lo + nj) ||
+                        (sk > 0 ? gk < k_lo : gk >= k_lo + nk);
+        const long g = gi + sx * gj + sxy * gk;
+        return (interior && up) ? B[g] : A[g];
+    };
+    for (int idx = lane; idx < T::CORE; idx += 64) {
+        const int x = idx % T::RA - 3, yz = idx / T::RA;
+        core[idx] = fetch(i_lo + x, j_lo + (yz & 7), k_lo + (yz >> 3));
+    }
+    for (int idx = lane; idx < T::YH; idx += 64) {
+        const int x = idx % TA, r = idx / TA, hy = r % 6, z = r / 6;
+        const int y = hy < 3 ? hy - 3 : nj + hy - 3;
+        yh[idx] = fetch(i_lo + x, j_lo + y, k_lo + z);
+    }
+    for (int idx = lane; idx < T::ZH; idx += 64) {
+        const int x = idx % TA, r = idx / TA, y = r & 7, hz = r >> 3;
+        const int z = hz < 3 ? hz - 3 : nk + hz - 3;
+        zh[idx] = fetch(i_lo + x, j_lo + y, k_lo + z);
+    }
+    __syncthreads();
+
+    // ---- march ----------------------------------------------------------------------------
+    const int b = lane & 7, c = lane >> 3;          // frame coordinates of this lane's row
+    const bool row_ok = b < nj && c < nk;
+    const int y = sj > 0 ? b : nj - 1 - b;          // absolute offsets of the row
+    const int z = sk > 0 ? c : nk - 1 - c;
+    const int gj = j_lo + y, gk = k_lo + z;
+    const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
+    const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx;
+    const long rowbase = sx * gj + sxy * gk;
+    double acc = 0.0;
+    const int nsteps = ni + nj + nk - 2;
+
+    auto lds_y = [&](int x, int yy) -> double { // value at (x, yy, z), yy possibly outside [0,nj)
+        if (yy >= 0 && yy < nj) return core[(z * 8 + yy) * T::RA + x + 3];
+        const int hy = yy < 0 ? yy + 3 : yy - nj + 3;
+        return yh[(z * 6 + hy) * TA + x];
+    };
+    auto lds_z = [&](int x, int zz) -> double {
+        if (zz >= 0 && zz < nk) return core[(zz * 8 + y) * T::RA + x + 3];
+        const int hz = zz < 0 ? zz + 3 : zz - nk + 3;
+        return zh[(hz * 8 + y) * TA + x];
+    };
+
+    // phiS of the first cell this lane will visit (prefetched one step ahead afterwards)
+    double pS_next = 0.0;
+    if (row_ok) {
+        const int x0 = si > 0 ? 0 : ni - 1;
+        pS_next = phiS[rowbase + i_lo + x0];
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        const int a = s - b - c;
+        const bool active = row_ok && a >= 0 && a < ni;
+        double newv = 0.0;
+        int x = 0;
+        if (active) {
+            x = si > 0 ? a : ni - 1 - a;
+            const double pS = pS_next;
+            if (a + 1 < ni) pS_next = phiS[rowbase + i_lo + (si > 0 ? x + 1 : x - 1)];
+            const int gi = i_lo + x;
+            const bool weno_ok = yz_weno && gi > 3 && gi < nx - 4;
+            double qx[7], qy[7], qz[7];
+            const double* row = &core[(z * 8 + y) * T::RA + x]; // row[m] = (x+m-3)
+#pragma unroll
+            for (int m = 0; m < 7; ++m) qx[m] = row[m];
+            if (weno_ok) {
+#pragma unroll
+                for (int m = 0; m < 7; ++m) {
+                    qy[m] = (m == 3) ? qx[3] : lds_y(x, y + m - 3);
+                    qz[m] = (m == 3) ? qx[3] : lds_z(x, z + m - 3);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 7; ++m) { qy[m] = 0.0; qz[m] = 0.0; }
+                qy[2] = lds_y(x, y - 1); qy[3] = qx[3]; qy[4] = lds_y(x, y + 1);
+                qz[2] = lds_z(x, z - 1); qz[3] = qx[3]; qz[4] = lds_z(x, z + 1);
+            }
+            newv = cell_update<STRICT>(qx, qy, qz, weno_ok, pS, dx, inv_dx, floor2, h);
+            const double dlt = newv - qx[3];
+            acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
+        }
+        __syncthreads(); // all reads of this step done before any cell of it is overwritten
+        if (active) core[(z * 8 + y) * T::RA + x + 3] = newv;
+        __syncthreads();
+    }
+
+    // ---- write back -------------------------------------------------------------------------
+    for (int idx = lane; idx < 64 * TA; idx += 64) {
+        const int x = idx % TA, yz = idx / TA, yy = yz & 7, zz = yz >> 3;
+        if (x < ni && yy < nj && zz < nk)
+            B[(long)(i_lo + x) + sx * (j_lo + yy) + sxy * (k_lo + zz)] = core[(zz * 8 + yy) * T::RA + x + 3];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) partials[ti + nTi * (tj + (long)nTj * tk)] = acc;
+}
+
+// =============================================================================================
+// Reinit, Jacobi ordering on a box region.  Thread (i,j) marches KC cells in k with a 7-deep
+// register window; x/y neighbours come through the vector L1/L2.
+// =============================================================================================
+constexpr int JAC_BX = 64, JAC_BY = 4, JAC_KC = 16;
+
+template <bool STRICT>
+__global__ __launch_bounds__(JAC_BX* JAC_BY) void k_reinit_jacobi(const double* __restrict__ A,
+                                                                   double* __restrict__ Bout,
+                                                                   const double* __restrict__ phiS, Box bx,
+                                                                   int lo0, int lo1, int lo2, int hi0, int hi1,
+                                                                   int hi2, double dx, double h,
+                                                                   double* __restrict__ partials,
+                                                                   const int* __restrict__ done)
+{
+    __shared__ double red[JAC_BX * JAC_BY / 64];
+    if (done && *done) return;
+    const int li = lo0 + blockIdx.x * JAC_BX + threadIdx.x;
+    const int lj = lo1 + blockIdx.y * JAC_BY + threadIdx.y;
+    const int k0 = lo2 + blockIdx.z * JAC_KC;
+    const int k1 = min(k0 + JAC_KC, hi2);
+    const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
+    double acc = 0.0;
+    if (li < hi0 && lj < hi1) {
+        const int gi = li + bx.gx0, gj = lj + bx.gy0;
+        const bool ij_weno = gi > 3 && gi < bx.nx - 4 && gj > 3 && gj < bx.ny - 4;
+        const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx;
+        const long col = li + sx * lj;
+        double qz[7];
+        // window holds k-3..k+3 of the current cell; clamp reads to the box (values outside the
+        // +-1 / +-3 reach of the branch in use are never consumed)
+        auto ldz = [&](int k) -> double {
+            const int kk = k < 0 ? 0 : (k > bx.lz - 1 ? bx.lz - 1 : k);
+            return A[col + sxy * kk];
+        };
+#pragma unroll
+        for (int m = 0; m < 6; ++m) qz[m + 1] = ldz(k0 - 3 + m);
+        for (int k = k0; k < k1; ++k) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) qz[m] = qz[m + 1];
+            qz[6] = ldz(k + 3);
+            const int gk = k + bx.gz0;
+            const bool weno_ok = ij_weno && gk > 3 && gk < bx.nz - 4;
+            const long cidx = col + sxy * k;
+            double qx[7], qy[7];
+            if (weno_ok) {
+#pragma unroll
+                for (int m = 0; m < 7; ++m) {
+                    qx[m] = (m == 3) ? qz[3] : A[cidx + (m - 3)];
+                    qy[m] = (m == 3) ? qz[3] : A[cidx + sx * (m - 3)];
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 7; ++m) { qx[m] = 0.0; qy[m] = 0.0; }
+                qx[2] = A[cidx - 1]; qx[3] = qz[3]; qx[4] = A[cidx + 1];
+                qy[2] = A[cidx - sx]; qy[3] = qz[3]; qy[4] = A[cidx + sx];
+            }
+            const double newv = cell_update<STRICT>(qx, qy, qz, weno_ok, phiS[cidx], dx, inv_dx, floor2, h);
+            Bout[cidx] = newv;
+            const double dlt = newv - qz[3];
+            acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
+        }
+    }
+    acc = wave_sum(acc);
+    const int tid = threadIdx.x + JAC_BX * threadIdx.y;
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < JAC_BX * JAC_BY / 64; ++w) t += red[w];
+        partials[blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)] = t;
+    }
+}
+
+// =============================================================================================
+// Extrapolation boundary condition, closed form of subs.f90:859-897:
+// wall point <- interior point clamp(i,1,n-1) + dx added m = min(nb, 1+nh) times in sequence.
+// grid = (ceil(maxext/64), maxext, 6 faces); each wall point is owned by exactly one face.
+// =============================================================================================
+__global__ __launch_bounds__(64) void k_bc(const double* __restrict__ A, double* __restrict__ Bout, Box bx,
+                                           int lo0, int lo1, int lo2, int hi0, int hi1, int hi2, double dx,
+                                           double* __restrict__ partials, const int* __restrict__ done)
+{
+    if (done && *done) return;
+    const int face = blockIdx.z; // 0:i=0 1:i=nx 2:j=0 3:j=ny 4:k=0 5:k=nz
+    const int u = blockIdx.x * 64 + threadIdx.x, v = blockIdx.y;
+    const int axis = face >> 1;
+    const int nwall[3] = {bx.nx, bx.ny, bx.nz};
+    const int g0[3] = {bx.gx0, bx.gy0, bx.gz0};
+    const int lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+    const int wall_g = (face & 1) ? nwall[axis] : 0;
+    const int wall_l = wall_g - g0[axis];
+    double contrib = 0.0;
+    const int a1 = axis == 0 ? 1 : 0, a2 = axis == 2 ? 1 : 2; // the two in-face axes (ascending)
+    int l[3];
+    l[axis] = wall_l;
+    l[a1] = lo[a1] + u;
+    l[a2] = lo[a2] + v;
+    if (wall_l >= lo[axis] && wall_l < hi[axis] && l[a1] < hi[a1] && l[a2] < hi[a2]) {
+        const int gi = l[0] + bx.gx0, gj = l[1] + bx.gy0, gk = l[2] + bx.gz0;
+        const bool wi = gi == 0 || gi == bx.nx, wj = gj == 0 || gj == bx.ny, wk = gk == 0 || gk == bx.nz;
+        // ownership: x faces own everything on them; y faces skip points on x walls; z faces skip
+        // points on x or y walls
+        const bool own = axis == 0 || (axis == 1 && !wi) || (axis == 2 && !wi && !wj);
+        if (own) {
+            const int nb = (int)wi + (int)wj + (int)wk;
+            const int nh = (int)(gi == bx.nx) + (int)(gj == bx.ny) + (int)(gk == bx.nz);
+            const int m = min(nb, 1 + nh);
+            const int ci = min(max(gi, 1), bx.nx - 1) - bx.gx0;
+            const int cj = min(max(gj, 1), bx.ny - 1) - bx.gy0;
+            const int ck = min(max(gk, 1), bx.nz - 1) - bx.gz0;
+            const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
+            double val = Bout[ci + sx * cj + sxy * ck];
+            for (int t = 0; t < m; ++t) val = val + dx;
+            const long p = l[0] + sx * l[1] + sxy * l[2];
+            const double dlt = val - A[p];
+            Bout[p] = val;
+            contrib = dlt * dlt;
+        }
+    }
+    contrib = wave_sum(contrib);
+    if (threadIdx.x == 0) partials[blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)] = contrib;
+}
+
+// =============================================================================================
+// Sweep epilogue: fixed-order sum of the partials, RMS, stop test -- all on the device so that the
+// host never has to synchronise per sweep (subs.f90:902-926 / set3d.f90:435-458).
+// ctl[0]=done flag, ctl[1]=sweeps completed, ctl[2]=status (0 ok, 1 NaN)
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_finish(const double* __restrict__ partials, long nPart, double den,
+                                                double tol, double* __restrict__ trace, int trace_cap,
+                                                int* __restrict__ ctl)
+{
+    __shared__ double red[256];
+    if (ctl[0]) return;
+    double t = 0.0;
+    for (long p = threadIdx.x; p < nPart; p += 256) t += partials[p];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double rms = __builtin_sqrt(red[0] / den);
+        const int n = ctl[1];
+        if (n < trace_cap) trace[n] = rms;
+        ctl[1] = n + 1;
+        if (rms < tol) ctl[0] = 1;
+        else if (rms != rms) { ctl[0] = 1; ctl[2] = 1; }
+    }
+}
+
+// adds the fixed-order sum of the partials to *acc (building block for the decomposed path)
+__global__ __launch_bounds__(256) void k_accumulate(const double* __restrict__ partials, long nPart,
+                                                    double* __restrict__ accum)
+{
+    __shared__ double red[256];
+    double t = 0.0;
+    for (long p = threadIdx.x; p < nPart; p += 256) t += partials[p];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *accum += red[0];
+}
+
+// =============================================================================================
+// narrowBand, subs.f90:178-207
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_narrowband(const double* __restrict__ phi, int32_t* __restrict__ nb,
+                                                    int32_t* __restrict__ sb, long n, double dx)
+{
+    const double tn = 4.1 * dx, ts = 8.1 * dx;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < n; p += 256L * gridDim.x) {
+        const double a = __builtin_fabs(phi[p]);
+        nb[p] = a < tn ? 1 : 0;
+        sb[p] = a < ts ? 1 : 0;
+    }
+}
+
+// =============================================================================================
+// Min/max flow.  A = phi at iteration start (frozen: Laplacian, RMS reference), B = result.
+// The band of iteration n is narrowBand(A) (set3d.f90:460 ran on exactly that field) except for the
+// first iteration, which uses the caller's mask (nbmask != nullptr).  Wall points are never
+// updated (a band cell on a wall would read outside the array in the reference).
+// =============================================================================================
+__device__ __forceinline__ bool in_band(const int32_t* nbmask, long g, double a, double dx)
+{
+    return nbmask ? nbmask[g] == 1 : __builtin_fabs(a) < 4.1 * dx;
+}
+
+// Jacobi ordering: pAve from A as well.
+__global__ __launch_bounds__(256) void k_minmax_jacobi(const double* __restrict__ A, double* __restrict__ Bout,
+                                                       const int32_t* __restrict__ nbmask, int nx, int ny,
+                                                       int nz, double dx, double h1,
+                                                       double* __restrict__ partials,
+                                                       const int* __restrict__ done)
+{
+    __shared__ double red[4];
+    if (*done) return;
+    const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1), n = sxy * (nz + 1);
+    const double dxx = 1. / (dx * dx);
+    double acc = 0.0;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < n; p += 256L * gridDim.x) {
+        const int i = p % sx, j = (p / sx) % (ny + 1), k = p / sxy;
+        const double c = A[p];
+        double out = c;
+        const bool interior = i >= 1 && i <= nx - 1 && j >= 1 && j <= ny - 1 && k >= 1 && k <= nz - 1;
+        if (interior && in_band(nbmask, p, c, dx)) {
+            const double xm = A[p - 1], xp = A[p + 1], ym = A[p - sx], yp = A[p + sx], zm = A[p - sxy],
+                         zp = A[p + sxy];
+            const double curv = minmax_curv(c, xp, xm, yp, ym, zp, zm, dxx);
+            out = minmax_update(c, xm, xp, yp, ym, zp, zm, curv, h1);
+            const double d = out - c;
+            acc += d * d;
+        }
+        Bout[p] = out;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// Exact Gauss-Seidel ordering of set3d.f90:417-431 (always the (+,+,+) raster): tile = TA x 8 x 8
+// POINTS anchored at point 0, same lane/skew mapping as the reinit kernel, halo 1.
+// LDS: box [10][10][TA+2] of in-place values + [8][8][TA] frozen curvature.
+template <int TA>
+__global__ __launch_bounds__(64) void k_minmax_gs_plane(const double* __restrict__ A, double* __restrict__ B,
+                                                        const int32_t* __restrict__ nbmask, int nx, int ny,
+                                                        int nz, const uint32_t* __restrict__ tiles, int nTi,
+                                                        int nTj, int nTk, double dx, double h1,
+                                                        double* __restrict__ partials,
+                                                        const int* __restrict__ done)
+{
+    constexpr int RA = TA + 2;
+    __shared__ double box[10 * 10 * RA];
+    __shared__ double curvs[64 * TA];
+    __shared__ int anyband;
+    if (*done) return;
+    const int lane = threadIdx.x;
+    const uint32_t packed = tiles[blockIdx.x];
+    const int ti = packed & 0x3ff, tj = (packed >> 10) & 0x3ff, tk = (packed >> 20) & 0x3ff;
+    const int i_lo = ti * TA, j_lo = tj * 8, k_lo = tk * 8;
+    const int ni = min(TA, nx + 1 - i_lo), nj = min(8, ny + 1 - j_lo), nk = min(8, nz + 1 - k_lo);
+    const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1);
+    const double dxx = 1. / (dx * dx);
+    if (lane == 0) anyband = 0;
+
+    // frozen values of the whole box from A (corners are never read)
+    for (int idx = lane; idx < 100 * RA; idx += 64) {
+        const int x = idx % RA - 1, r = idx / RA, y = r % 10 - 1, z = r / 10 - 1;
+        const int gi = i_lo + x, gj = j_lo + y, gk = k_lo + z;
+        const bool ok = gi >= 0 && gi <= nx && gj >= 0 && gj <= ny && gk >= 0 && gk <= nz;
+        box[idx] = ok ? A[gi + sx * gj + sxy * gk] : 0.0;
+    }
+    __syncthreads();
+    // frozen curvature of the band cells of the tile (pass A, set3d.f90:399-414); NaN marks "not band"
+    bool mine = false;
+    for (int idx = lane; idx < 64 * TA; idx += 64) {
+        const int x = idx % TA, yz = idx / TA, y = yz & 7, z = yz >> 3;
+        const int gi = i_lo + x, gj = j_lo + y, gk = k_lo + z;
+        double cv = __builtin_nan("");
+        if (x < ni && y < nj && z < nk && gi >= 1 && gi <= nx - 1 && gj >= 1 && gj <= ny - 1 && gk >= 1 &&
+            gk <= nz - 1) {
+            const int o = (x + 1) + RA * ((y + 1) + 10 * (z + 1));
+            const double cc = box[o];
+            if (in_band(nbmask, gi + sx * gj + sxy * gk, cc, dx)) {
+                cv = minmax_curv(cc, box[o + 1], box[o - 1], box[o + RA], box[o - RA], box[o + 10 * RA],
+                                 box[o - 10 * RA], dxx);
+                mine = true;
+            }
+        }
+        curvs[idx] = cv;
+    }
+    if (mine) anyband = 1;
+    __syncthreads();
+    double acc = 0.0;
+    if (anyband) {
+        // replace the upstream (low-side) halo faces by the already-updated values from B
+        auto refresh = [&](int x, int y, int z) {
+            const int gi = i_lo + x, gj = j_lo + y, gk = k_lo + z;
+            if (gi >= 0 && gi <= nx && gj >= 0 && gj <= ny && gk >= 0 && gk <= nz)
+                box[(x + 1) + RA * ((y + 1) + 10 * (z + 1))] = B[gi + sx * gj + sxy * gk];
+        };
+        refresh(-1, lane & 7, lane >> 3);
+        for (int idx = lane; idx < 8 * TA; idx += 64) {
+            refresh(idx % TA, -1, idx / TA);
+            refresh(idx % TA, idx / TA, -1);
+        }
+        __syncthreads();
+        const int b = lane & 7, c = lane >> 3;
+        const int nsteps = ni + nj + nk - 2;
+        for (int s = 0; s < nsteps; ++s) {
+            const int a = s - b - c;
+            const bool active = b < nj && c < nk && a >= 0 && a < ni;
+            double newv = 0.0;
+            bool upd = false;
+            int o = 0;
+            if (active) {
+                const double cv = curvs[a + TA * (b + 8 * c)];
+                if (cv == cv) {
+                    o = (a + 1) + RA * ((b + 1) + 10 * (c + 1));
+                    const double cc = box[o];
+                    newv = minmax_update(cc, box[o - 1], box[o + 1], box[o + RA], box[o - RA], box[o + 10 * RA],
+                                         box[o - 10 * RA], cv, h1);
+                    const double d = newv - cc;
+                    acc += d * d;
+                    upd = true;
+                }
+            }
+            __syncthreads();
+            if (upd) box[o] = newv;
+            __syncthreads();
+        }
+    }
+    for (int idx = lane; idx < 64 * TA; idx += 64) {
+        const int x = idx % TA, yz = idx / TA, y = yz & 7, z = yz >> 3;
+        if (x < ni && y < nj && z < nk)
+            B[(long)(i_lo + x) + sx * (j_lo + y) + sxy * (k_lo + z)] = box[(x + 1) + RA * ((y + 1) + 10 * (z + 1))];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) partials[ti + nTi * (tj + (long)nTj * tk)] = acc;
+}
+
+// =============================================================================================
+// pack / unpack of a sub-box (halo slabs)
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_pack(const double* __restrict__ f, double* __restrict__ buf, Box bx,
+                                              int lo0, int lo1, int lo2, int e0, int e1, int e2, int unpack,
+                                              double* __restrict__ fw)
+{
+    const long n = (long)e0 * e1 * e2;
+    const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < n; p += 256L * gridDim.x) {
+        const int x = p % e0, y = (p / e0) % e1, z = p / ((long)e0 * e1);
+        const long g = (lo0 + x) + sx * (lo1 + y) + sxy * (lo2 + z);
+        if (unpack) fw[g] = buf[p];
+        else buf[p] = f[g];
+    }
+}
+
+} // namespace lsf

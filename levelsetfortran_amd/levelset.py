@@ -1,0 +1,198 @@
+"""Host-side mirror of the reference's interface for the hot path.
+
+Same names, argument meaning and error behaviour as the Fortran module procedures and the loop
+they replace (citations are into /root/reference):
+
+  reinit(phi, gradPhi, gradPhiMag, nx, ny, nz, iter, dx, h)     subs.f90:717-931
+  narrowBand(nx, ny, nz, dx, phi, phiNB, phiSB)                 subs.f90:178-207
+  minmaxFlow(phi, phiNB, phiSB, nx, ny, nz, iter, dx, h1)       set3d.f90:394-462 (hoisted)
+
+Fields are updated IN PLACE like the INTENT(INOUT) dummies of the reference.  A field is either
+  * a numpy float64 array, Fortran-ordered with shape (nx+1, ny+1, nz+1) (or 1-D of that size):
+    the host seam -- the library copies it to HBM and back (lsf_reinit / lsf_minmax), or
+  * a torch CUDA float64 tensor, C-contiguous with shape (nz+1, ny+1, nx+1) (or 1-D): the same
+    bytes already resident in HBM (lsf_*_device); nothing crosses PCIe.
+
+All arithmetic happens in liblsf_hip.so (hand-written HIP for gfx950).  This module contains no
+numerical code and no fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import sys
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import LSF_ARITH_FAST, LSF_ARITH_STRICT, LSF_ORDER_GS, LSF_ORDER_JACOBI, LsfError, LsfNaNError
+
+__all__ = ["reinit", "narrowBand", "minmaxFlow", "SweepReport", "mode_word", "LsfError", "LsfNaNError"]
+
+REINIT_TOL = 1.0e-5  # subs.f90:915
+MINMAX_TOL = 1.0e-7  # set3d.f90:448
+
+
+def mode_word(order: str = "gs", arith: str = "fast") -> int:
+    """Build the `mode` argument of include/lsf.h from readable names."""
+    o = {"gs": LSF_ORDER_GS, "jacobi": LSF_ORDER_JACOBI}[order]
+    a = {"fast": LSF_ARITH_FAST, "strict": LSF_ARITH_STRICT}[arith]
+    return o | a
+
+
+@dataclass
+class SweepReport:
+    """What the reference prints while iterating (subs.f90:916,923 / set3d.f90:449,456)."""
+
+    count: int  # sweeps / iterations executed
+    rms: List[float] = field(default_factory=list)  # RMS change after each of them
+    converged: bool = False  # last RMS < tol -> the "steady state" line
+
+    def lines(self, first_index: int, steady_msg: str) -> List[str]:
+        """The stdout lines of the reference for this run (list-directed formatting aside)."""
+        out = []
+        n_print = self.count - 1 if self.converged else self.count
+        for s in range(n_print):
+            out.append(f"  Iteration:  {s + first_index}   RMS Error:  {self.rms[s]!r}")
+        if self.converged:
+            out.append(steady_msg)
+        return out
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _npoints(nx: int, ny: int, nz: int) -> int:
+    return (nx + 1) * (ny + 1) * (nz + 1)
+
+
+def _host_ptr(a: np.ndarray, dtype, nx, ny, nz, name: str) -> int:
+    if not isinstance(a, np.ndarray) or a.dtype != dtype:
+        raise TypeError(f"{name} must be a numpy array of {np.dtype(dtype).name}")
+    if a.ndim == 3:
+        if a.shape != (nx + 1, ny + 1, nz + 1) or not a.flags.f_contiguous:
+            raise ValueError(f"{name} must be Fortran-ordered with shape (nx+1, ny+1, nz+1) = {(nx+1, ny+1, nz+1)}")
+    elif a.ndim != 1 or a.size != _npoints(nx, ny, nz) or not a.flags.c_contiguous:
+        raise ValueError(f"{name} must have (nx+1)(ny+1)(nz+1) contiguous elements")
+    if not a.flags.writeable:
+        raise ValueError(f"{name} must be writeable (it is INTENT(INOUT) in the reference)")
+    return a.ctypes.data
+
+
+def _dev_ptr(t, torch_dtype, nx, ny, nz, name: str) -> int:
+    import torch
+
+    if not t.is_cuda or t.dtype != torch_dtype:
+        raise TypeError(f"{name} must be a CUDA tensor of {torch_dtype}")
+    if t.dim() == 3:
+        if tuple(t.shape) != (nz + 1, ny + 1, nx + 1):
+            raise ValueError(f"{name} must have shape (nz+1, ny+1, nx+1) (i is the unit-stride axis)")
+    elif t.dim() != 1 or t.numel() != _npoints(nx, ny, nz):
+        raise ValueError(f"{name} must have (nx+1)(ny+1)(nz+1) elements")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def _stream_and_device(t):
+    import torch
+
+    lib = _lib.load()
+    _lib.check(lib.lsf_set_device(t.device.index or 0))
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def reinit(phi, gradPhi=None, gradPhiMag=None, nx: int = 0, ny: int = 0, nz: int = 0, iter: int = 0,
+           dx: float = 0.0, h: float = 0.0, *, tol: float = REINIT_TOL, order: str = "gs", arith: str = "fast",
+           first_raster: int = 0, phiS=None, echo: bool = False) -> SweepReport:
+    """SUBROUTINE reinit (subs.f90:717-931) on the GPU; `phi` is updated in place.
+
+    gradPhi / gradPhiMag are accepted for signature parity and left untouched: the reference never
+    reads what reinit stores there (set3d.f90:372-375 zeroes them).
+    Runs at most iter+1 sweeps (subs.f90:735).  Raises LsfNaNError where the reference STOPs.
+    echo=True prints the reference's per-sweep lines.
+    """
+    lib = _lib.load()
+    cap = int(iter) + 1
+    trace = np.zeros(max(cap, 1), dtype=np.float64)
+    done = ctypes.c_int(0)
+    mode = mode_word(order, arith)
+    if _is_torch(phi):
+        import torch
+
+        p = _dev_ptr(phi, torch.float64, nx, ny, nz, "phi")
+        ps = _dev_ptr(phiS, torch.float64, nx, ny, nz, "phiS") if phiS is not None else None
+        st = _stream_and_device(phi)
+        rc = lib.lsf_reinit_device(p, ps, nx, ny, nz, int(iter), float(dx), float(h), float(tol), mode,
+                                   int(first_raster), ctypes.byref(done), trace.ctypes.data, cap, st)
+    else:
+        if first_raster != 0 or phiS is not None:
+            raise ValueError("first_raster / phiS are only available on the device seam")
+        p = _host_ptr(phi, np.float64, nx, ny, nz, "phi")
+        rc = lib.lsf_reinit(p, nx, ny, nz, int(iter), float(dx), float(h), float(tol), mode, ctypes.byref(done),
+                            trace.ctypes.data, cap)
+    n = done.value
+    rep = SweepReport(n, [float(v) for v in trace[:n]], bool(n and trace[n - 1] < tol))
+    if echo:
+        for ln in rep.lines(0, "  Distance function time integration has reached steady state "):
+            print(ln)
+        print()
+        sys.stdout.flush()
+    _lib.check(rc)
+    return rep
+
+
+def narrowBand(nx: int, ny: int, nz: int, dx: float, phi, phiNB, phiSB) -> None:
+    """SUBROUTINE narrowBand (subs.f90:178-207): phiNB = |phi| < 4.1 dx, phiSB = |phi| < 8.1 dx."""
+    lib = _lib.load()
+    if _is_torch(phi):
+        import torch
+
+        st = _stream_and_device(phi)
+        rc = lib.lsf_narrowband_device(_dev_ptr(phi, torch.float64, nx, ny, nz, "phi"),
+                                       _dev_ptr(phiNB, torch.int32, nx, ny, nz, "phiNB"),
+                                       _dev_ptr(phiSB, torch.int32, nx, ny, nz, "phiSB"), nx, ny, nz, float(dx), st)
+    else:
+        rc = lib.lsf_narrowband(_host_ptr(phi, np.float64, nx, ny, nz, "phi"),
+                                _host_ptr(phiNB, np.int32, nx, ny, nz, "phiNB"),
+                                _host_ptr(phiSB, np.int32, nx, ny, nz, "phiSB"), nx, ny, nz, float(dx))
+    _lib.check(rc)
+
+
+def minmaxFlow(phi, phiNB, phiSB, nx: int, ny: int, nz: int, iter: int, dx: float, h1: float, *,
+               tol: float = MINMAX_TOL, order: str = "gs", echo: bool = False) -> SweepReport:
+    """The min/max-flow loop of the main program (set3d.f90:394-462) as one call.
+
+    phi, phiNB, phiSB are updated in place; the masks come back as the host would hold them after
+    the loop (refreshed only on the non-exit path, set3d.f90:448-460).
+    """
+    lib = _lib.load()
+    cap = max(int(iter), 1)
+    trace = np.zeros(cap, dtype=np.float64)
+    done = ctypes.c_int(0)
+    mode = mode_word(order, "strict")  # min/max has a single (exact) arithmetic
+    if _is_torch(phi):
+        import torch
+
+        st = _stream_and_device(phi)
+        rc = lib.lsf_minmax_device(_dev_ptr(phi, torch.float64, nx, ny, nz, "phi"),
+                                   _dev_ptr(phiNB, torch.int32, nx, ny, nz, "phiNB"),
+                                   _dev_ptr(phiSB, torch.int32, nx, ny, nz, "phiSB"), nx, ny, nz, int(iter),
+                                   float(dx), float(h1), float(tol), mode, ctypes.byref(done), trace.ctypes.data,
+                                   cap, st)
+    else:
+        rc = lib.lsf_minmax(_host_ptr(phi, np.float64, nx, ny, nz, "phi"),
+                            _host_ptr(phiNB, np.int32, nx, ny, nz, "phiNB"),
+                            _host_ptr(phiSB, np.int32, nx, ny, nz, "phiSB"), nx, ny, nz, int(iter), float(dx),
+                            float(h1), float(tol), mode, ctypes.byref(done), trace.ctypes.data, cap)
+    n = done.value
+    rep = SweepReport(n, [float(v) for v in trace[:n]], bool(n and trace[n - 1] < tol))
+    if echo:
+        for ln in rep.lines(1, "  Min/max time integration has reached steady state "):
+            print(ln)
+        print()
+        sys.stdout.flush()
+    _lib.check(rc)
+    return rep

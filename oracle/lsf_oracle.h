@@ -1,0 +1,73 @@
+/*
+ * lsf_oracle.h -- TEST INFRASTRUCTURE: CPU restatement of the reference hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker.  The product (levelsetfortran_amd/) never does.
+ *
+ * All arrays are Fortran-ordered exactly like the reference's
+ * `REAL phi(0:nx,0:ny,0:nz)` (subs.f90:721): extents (nx+1,ny+1,nz+1), `i` unit stride,
+ * element (i,j,k) at  i + (nx+1)*(j + (ny+1)*k).
+ */
+#ifndef LSF_ORACLE_H
+#define LSF_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sweep orderings for lsf_oracle_reinit / lsf_oracle_minmax */
+enum {
+    LSF_ORACLE_GS_LEX = 0,   /* the reference's own loop nests, subs.f90:743-852 / set3d.f90:417-431 */
+    LSF_ORACLE_GS_HYPER = 1, /* same update, hyperplane visiting order          */
+    LSF_ORACLE_JACOBI = 2    /* double-buffered variant; NOT what the reference computes               */
+};
+
+/* boundary-condition evaluators for lsf_oracle_reinit */
+enum {
+    LSF_ORACLE_BC_CLOSED = 0, /* closed form of subs.f90:859-897  */
+    LSF_ORACLE_BC_LITERAL = 1 /* the 26 assignments inside the full (i,j,k) loop, as written    */
+};
+
+/* subs.f90:489-711: returns gM for cell (i,j,k); the dead side outputs are not produced. */
+double lsf_oracle_weno(int i, int j, int k, int nx, int ny, int nz, double dx, const double *phi);
+
+/* subs.f90:152-172 */
+double lsf_oracle_phisign(double pS, double dxx, double gM);
+
+/* subs.f90:859-897 on its own (both evaluators), for tests */
+void lsf_oracle_bc(double *phi, int nx, int ny, int nz, double dx, int bc_kind);
+
+/* subs.f90:717-931.  Runs at most iter+1 sweeps (subs.f90:735), stops when RMS < tol
+ * (reference: 1e-5, subs.f90:915).  first_raster = 0 reproduces the reference (raster starts
+ * at 1); other values 0..7 start the 8-cycle elsewhere (used to split a run in tests).
+ * rms_trace (may be NULL) receives one RMS per executed sweep, up to trace_cap entries.
+ * Returns 0, or 1 if the RMS became NaN (the reference STOPs there, subs.f90:926). */
+int lsf_oracle_reinit(double *phi, int nx, int ny, int nz, int iter, double dx, double h, double tol,
+                      int order, int bc_kind, int first_raster, int *sweeps_done, double *rms_trace,
+                      int trace_cap);
+
+/* subs.f90:178-207 */
+void lsf_oracle_narrowband(int nx, int ny, int nz, double dx, const double *phi, int32_t *phiNB,
+                           int32_t *phiSB);
+
+/* set3d.f90:394-462 hoisted into one call (secondDeriv subs.f90:370-407, minMax subs.f90:413-483).
+ * phiNB/phiSB are in/out exactly as in the host: the masks made at set3d.f90:360 on entry, the
+ * masks the host would hold after the loop on return (EXIT-before-narrowBand asymmetry).
+ * Runs iterations n = 1..iter, stops when RMS < tol (reference: 1e-7, set3d.f90:448).
+ * Returns 0, or 1 on NaN RMS (set3d.f90:458). */
+int lsf_oracle_minmax(double *phi, int32_t *phiNB, int32_t *phiSB, int nx, int ny, int nz, int iter,
+                      double dx, double h1, double tol, int order, int *iters_done, double *rms_trace,
+                      int trace_cap);
+
+/* set3d.f90:196-268: inside/outside initialisation from an indexed triangle soup (the step before
+ * the hot path).  surfX is (nSurfNode,3) Fortran-ordered, surfElem is
+ * (nSurfElem,3) Fortran-ordered 1-based.  phi must be pre-filled with 1.0 (set3d.f90:161). */
+void lsf_oracle_phi0(double *phi, int nx, int ny, int nz, double dx, const double xLo[3],
+                     const double minX[3], const double maxX[3], const double *surfX, int nSurfNode,
+                     const int32_t *surfElem, int nSurfElem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
