@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json on MI355X:
+
+    cell-updates/s (WENO5 reinit, 512^3 fp64); achieved HBM GB/s vs peak
+
+A "step" is one reinitialisation sweep (raster sweep of the WENO5/Godunov/Euler update over all
+(N-2)^3 interior cells + extrapolation BC + RMS/stop test; subs.f90:735-928) of a 512^3 fp64 field
+that is already resident in HBM.  The default ordering is the reference's own in-place Gauss-Seidel
+ordering, reproduced exactly on the GPU (LSF_ORDER_GS): that is the path whose output matches the
+reference to the last bit (STRICT arithmetic) / to ~1e-16 (FAST arithmetic, used here).  The
+double-buffered Jacobi ordering (does not reproduce the reference field; shards across GPUs) is
+measured in the same run and reported under "jacobi".
+
+    python bench.py --gpus N --steps K --warmup W [--mode gs|jacobi] [--size 512]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU:
+  mode gs      exact ordering does not shard: N independent replicas, weak scaling
+  mode jacobi  3-D block decomposition, 3-cell halos over RCCL, local block = --size^3, weak scaling
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # vendor vector fp64 (FMA counted as 2)
+BYTES_PER_CELL_UPDATE = 24.0  # read phi, read phiS, write phi
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline worker (separate process: the Fortran runtime of the reference prints one line per
+# sweep on stdout, which must not reach the JSON line)
+# ------------------------------------------------------------------------------------------------
+def _cpu_worker(out_path: str, n: int, slab: int, sweeps: int) -> None:
+    import threading
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from levelsetfortran_amd import fields
+
+    # the sample: a z-slab of `slab` points through the centre of the same n^3 two-sphere phi0
+    phi_full_x, dx = None, 3.0 / (n - 1)
+    x = -1.5 + dx * np.arange(n)
+    k0 = n // 2 - slab // 2
+    z = x[k0:k0 + slab]
+    d = None
+    for c in ((-0.6, 0.0, 0.0), (0.6, 0.0, 0.0)):
+        r = np.sqrt((x[:, None, None] - c[0]) ** 2 + (x[None, :, None] - c[1]) ** 2 + (z[None, None, :] - c[2]) ** 2)
+        d = r - 0.5 if d is None else np.minimum(d, r - 0.5)
+    phi = np.asfortranarray(d / np.sqrt(d * d + dx * dx))
+    del phi_full_x
+    nx, ny, nz = n - 1, n - 1, slab - 1
+    h = fields.reinit_step(dx)
+    res = {}
+
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref_subs.so")
+
+    def run():
+        t0 = time.perf_counter()
+        if os.path.exists(ref_so):
+            L = ctypes.CDLL(ref_so)
+            f = L._QMset_subsPreinit  # SUBROUTINE reinit, subs.f90:717, as compiled by amdflang
+            f.restype = None
+            f.argtypes = [ctypes.c_void_p] * 9
+            gp = np.zeros(phi.shape + (3,), order="F")
+            gm = np.zeros(phi.shape, order="F")
+            keep = [ctypes.c_int(nx), ctypes.c_int(ny), ctypes.c_int(nz), ctypes.c_int(sweeps - 1), ctypes.c_double(dx),
+                    ctypes.c_double(h)]
+            t0 = time.perf_counter()
+            f(phi.ctypes.data, gp.ctypes.data, gm.ctypes.data, *[ctypes.addressof(v) for v in keep])
+            res["kind"] = "reference"
+        else:
+            import oracle_lib
+
+            t0 = time.perf_counter()
+            oracle_lib.reinit(phi, nx, ny, nz, sweeps - 1, dx, h, tol=0.0, order=oracle_lib.GS_LEX)
+            res["kind"] = "port"
+        res["seconds"] = time.perf_counter() - t0
+
+    threading.stack_size(1 << 30)  # reinit keeps two automatic arrays on the stack (subs.f90:724)
+    th = threading.Thread(target=run)
+    th.start()
+    th.join()
+    res["cells"] = (nx - 1) * (ny - 1) * (nz - 1) * sweeps
+    with open(out_path, "w") as fh:
+        json.dump(res, fh)
+
+
+def cpu_baseline(n: int, slab: int = 20, sweeps: int = 8):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "cpu.json")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", out, "--size", str(n), "--cpu-slab", str(slab),
+               "--cpu-sweeps", str(sweeps)]
+        try:
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=900)
+            r = json.load(open(out))
+        except Exception as e:  # noqa: BLE001
+            return {"value": None, "unit": "cell-updates/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+    what = ("reference subs.f90 reinit built by amdflang -O3 -fdefault-real-8 (oracle/_ref)" if r["kind"] == "reference"
+            else "C restatement oracle/lsf_oracle.c (bit-identical to the reference)")
+    return {
+        "value": r["cells"] / r["seconds"],
+        "unit": "cell-updates/s",
+        "cores": 1,
+        "kind": r["kind"],
+        "sample": f"{n}x{n}x{slab}-point z-slab through the centre of the same {n}^3 phi0, {sweeps} sweeps "
+                  f"(one cycle of the 8 raster directions), {r['seconds']:.1f} s; {what}; serial like the reference",
+    }
+
+
+# ------------------------------------------------------------------------------------------------
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--mode", choices=("gs", "jacobi"), default="gs")
+    ap.add_argument("--arith", choices=("fast", "strict"), default="fast")
+    ap.add_argument("--size", type=int, default=512, help="points per axis (per GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary-ordering measurement")
+    ap.add_argument("--cpu-worker", default=None)
+    ap.add_argument("--cpu-slab", type=int, default=20)
+    ap.add_argument("--cpu-sweeps", type=int, default=8)
+    args = ap.parse_args()
+    if args.cpu_worker:
+        _cpu_worker(args.cpu_worker, args.size, args.cpu_slab, args.cpu_sweeps)
+        return
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import levelsetfortran_amd as lsf
+    from levelsetfortran_amd import _lib, fields
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    lib = _lib.load()
+    N = args.size
+    K, W = args.steps, args.warmup
+    out = {}
+
+    if args.mode == "jacobi" and world > 1:
+        from levelsetfortran_amd import distributed as lsd
+
+        res = lsd.bench_weak_scaling(N, K, W, dev, arith=args.arith)
+        cells_total, seconds, prof, parallelism = res["cells_total"], res["seconds"], res["prof"], res["parallelism"]
+        order = "jacobi"
+    else:
+        order = args.mode
+        nx = ny = nz = N - 1
+        phi0_np, dx = fields.two_sphere_phi0((N, N, N))
+        h = fields.reinit_step(dx)
+        phi0 = torch.from_numpy(phi0_np.reshape(-1, order="F")).to(dev)
+        del phi0_np
+        phiS = phi0.clone()
+        phi = phi0.clone()
+
+        def run(order_, sweeps, profile=False):
+            lib.lsf_profile(1 if profile else 0)
+            rep = lsf.reinit(phi, None, None, nx, ny, nz, sweeps - 1, dx, h, tol=0.0, order=order_, arith=args.arith,
+                             phiS=phiS)
+            assert rep.count == sweeps, (rep.count, sweeps)
+            return rep
+
+        def timed(order_):
+            phi.copy_(phi0)
+            if W > 0:
+                run(order_, W)
+            barrier()
+            t0 = time.perf_counter()
+            run(order_, K, profile=True)
+            barrier()
+            dt = time.perf_counter() - t0
+            sw, bc, fin = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            nl, ns = ctypes.c_longlong(), ctypes.c_int()
+            lib.lsf_profile_get(ctypes.byref(sw), ctypes.byref(bc), ctypes.byref(fin), ctypes.byref(nl), ctypes.byref(ns))
+            lib.lsf_profile(0)
+            return dt, {"sweep_ms": sw.value, "bc_ms": bc.value, "finish_ms": fin.value, "launches": nl.value,
+                        "sweeps": ns.value}
+
+        seconds, prof = timed(order)
+        cells_total = float(nx - 1) * (ny - 1) * (nz - 1) * K * world
+        parallelism = "1 GPU" if world == 1 else f"{world} independent replicas (exact Gauss-Seidel ordering does not shard)"
+
+    if world > 1:
+        t = torch.tensor([seconds], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seconds = float(t.item())
+
+    kernel = {"gs": "k_reinit_gs_plane", "jacobi": "k_reinit_jacobi"}[order]
+
+    def roofline(prof_, cells_per_sweep):
+        if not prof_ or not prof_.get("sweeps"):
+            return None
+        per_sweep_s = prof_["sweep_ms"] * 1e-3 / prof_["sweeps"]
+        ach = cells_per_sweep * BYTES_PER_CELL_UPDATE / per_sweep_s / 1e9
+        lps = prof_["launches"] / prof_["sweeps"]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(kernel, {}).get(str(N))
+            except Exception:  # noqa: BLE001
+                traffic = None
+        return {
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "kernel": kernel, "launches_per_sweep": lps,
+            "avg_launch_us": per_sweep_s / lps * 1e6,
+            "algorithmic_bytes_per_launch": cells_per_sweep * BYTES_PER_CELL_UPDATE / lps,
+            "note": "achieved = 24 B x (N-2)^3 cells / HIP-event time of the sweep kernel launch(es) of one sweep; "
+                    "traffic = measured HBM bytes per sweep from rocprofv3 PMC passes (profiles/), null if not collected",
+        }
+
+    per_gpu_cells_per_sweep = cells_total / K / world
+    out = {
+        "metric": "cell-updates/s (WENO5 reinit, 512^3 fp64)",
+        "value": cells_total / seconds,
+        "unit": "cell-updates/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": seconds / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"WENO5 HJ reinit sweep (weno+Godunov+Euler, BC, RMS), {N}^3 fp64 per GPU, synthetic two-sphere "
+                        f"phi0 (SURVEY.md 8d), HBM-resident",
+            "grid": [N, N, N],
+            "ordering": "exact Gauss-Seidel raster order of the reference (tiled hyperplane wavefront)" if order == "gs"
+                        else "Jacobi (double-buffered; not reference-equal)",
+            "arithmetic": args.arith,
+            "parallelism": parallelism,
+        },
+        "roofline": roofline(prof, per_gpu_cells_per_sweep),
+    }
+    if prof:
+        out["step_breakdown_ms"] = {k: prof[k] / max(prof["sweeps"], 1) for k in ("sweep_ms", "bc_ms", "finish_ms")}
+    out["roofline_fp64_valu"] = {
+        "bound": "fp64-valu", "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "note": "the update is ~505 fp64 flop/cell as written in subs.f90 (SURVEY.md 8d): at 24 B/cell the fp64 vector "
+                "unit, not HBM, is the first bound; achieved = 505 x value",
+        "achieved": 505.0 * (cells_total / seconds) / world / 1e12,
+    }
+    out["roofline_fp64_valu"]["frac"] = out["roofline_fp64_valu"]["achieved"] / FP64_VALU_PEAK_TFLOPS
+
+    if world == 1 and not args.no_secondary and not (args.mode == "jacobi" and world > 1):
+        other = "jacobi" if order == "gs" else "gs"
+        sec2, prof2 = timed(other)
+        cells2 = float(nx - 1) * (ny - 1) * (nz - 1) * K
+        kernel = {"gs": "k_reinit_gs_plane", "jacobi": "k_reinit_jacobi"}[other]
+        out[other] = {
+            "value": cells2 / sec2, "unit": "cell-updates/s", "ms_per_step": sec2 / K * 1e3,
+            "roofline": roofline(prof2, cells2 / K),
+            "note": "Jacobi ordering: same per-cell arithmetic, double-buffered; its field differs from the reference's "
+                    "Gauss-Seidel result (5.5e-5 RMS on cube40, SURVEY.md section 0)" if other == "jacobi"
+                    else "exact Gauss-Seidel ordering of the reference",
+        }
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

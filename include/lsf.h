@@ -63,6 +63,13 @@ int lsf_device_count(void);
 int lsf_set_device(int device);
 /* release every cached device buffer of the current device */
 int lsf_release_workspace(void);
+/* Measurement aid (bench.py): with profiling enabled the next lsf_reinit*_ call brackets, per sweep,
+ * the sweep kernel(s), the boundary-condition kernel and the RMS/stop kernel with HIP events on the
+ * stream they are launched on.  lsf_profile_get returns the sums over the sweeps of that call (ms),
+ * the number of sweep-kernel launches and the number of sweeps timed. */
+int lsf_profile(int enable);
+int lsf_profile_get(double *sweep_kernel_ms, double *bc_ms, double *finish_ms,
+                    long long *sweep_kernel_launches, int *sweeps);
 
 /* ---- seam 1: reinit ----------------------------------------------------------------------
  * Replaces SUBROUTINE reinit(phi,gradPhi,gradPhiMag,nx,ny,nz,iter,dx,h), subs.f90:717-931.

@@ -59,6 +59,48 @@ struct Ctx {
 std::mutex g_mu;
 std::map<int, Ctx> g_ctx;
 
+// optional event timing of the sweep kernels (lsf_profile): accumulated over the last core call
+struct Profile {
+    bool on = false;
+    double sweep_ms = 0, bc_ms = 0, finish_ms = 0;
+    long sweep_launches = 0;
+    int sweeps = 0;
+    std::vector<hipEvent_t> ev; // 4 per timed sweep
+};
+thread_local Profile g_prof;
+
+void prof_begin()
+{
+    g_prof.sweep_ms = g_prof.bc_ms = g_prof.finish_ms = 0;
+    g_prof.sweep_launches = 0;
+    g_prof.sweeps = 0;
+    for (auto e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear();
+}
+void prof_mark(hipStream_t st)
+{
+    if (!g_prof.on) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    g_prof.ev.push_back(e);
+}
+void prof_end(int sweeps_done)
+{
+    if (!g_prof.on) return;
+    const int timed = std::min<int>(sweeps_done, (int)g_prof.ev.size() / 4);
+    for (int s = 0; s < timed; ++s) {
+        float a = 0, b = 0, c = 0;
+        (void)hipEventElapsedTime(&a, g_prof.ev[4 * s], g_prof.ev[4 * s + 1]);
+        (void)hipEventElapsedTime(&b, g_prof.ev[4 * s + 1], g_prof.ev[4 * s + 2]);
+        (void)hipEventElapsedTime(&c, g_prof.ev[4 * s + 2], g_prof.ev[4 * s + 3]);
+        g_prof.sweep_ms += a;
+        g_prof.bc_ms += b;
+        g_prof.finish_ms += c;
+    }
+    g_prof.sweeps = timed;
+}
+
 int ensure_device()
 {
     int n = 0;
@@ -207,10 +249,17 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
 
     double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
     int host_ctl[3] = {0, 0, 0};
+    prof_begin();
+    long launches_per_sweep = 1;
+    if (order == LSF_ORDER_GS) {
+        launches_per_sweep = 0;
+        for (size_t P = 0; P + 1 < tl->off.size(); ++P) launches_per_sweep += tl->off[P + 1] > tl->off[P];
+    }
     for (int s = 0; s < max_sweeps; ++s) {
         const double* A = bufs[s & 1];
         double* B = bufs[(s + 1) & 1];
         const int* sg = RASTER_SIGN[(first_raster + s) & 7];
+        prof_mark(st);
         if (order == LSF_ORDER_GS) {
             const int nplanes = (int)tl->off.size() - 1;
             for (int P = 0; P < nplanes; ++P) {
@@ -233,9 +282,12 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
                 hipLaunchKernelGGL((k_reinit_jacobi<false>), jgrid, dim3(JAC_BX, JAC_BY), 0, st, A, B, d_phiS, bx, 1,
                                    1, 1, nx, ny, nz, dx, h, part, ctl);
         }
+        prof_mark(st);
         hipLaunchKernelGGL(k_bc, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, dx,
                            part + n_sweep_part, ctl);
+        prof_mark(st);
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
+        prof_mark(st);
         if ((s + 1) % CHECK_EVERY == 0 && s + 1 < max_sweeps) {
             HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -246,6 +298,8 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const int nsw = host_ctl[1];
+    prof_end(nsw);
+    g_prof.sweep_launches = launches_per_sweep * g_prof.sweeps;
     if (bufs[nsw & 1] != d_phi)
         HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (rms_trace && trace_cap > 0 && nsw > 0)
@@ -392,6 +446,24 @@ int lsf_set_device(int device)
     if (device < 0) return fail(LSF_ERR_INVALID, "negative device index");
     g_device = device;
     return ensure_device();
+}
+
+int lsf_profile(int enable)
+{
+    g_prof.on = enable != 0;
+    prof_begin();
+    return LSF_OK;
+}
+
+int lsf_profile_get(double* sweep_kernel_ms, double* bc_ms, double* finish_ms, long long* sweep_kernel_launches,
+                    int* sweeps)
+{
+    if (sweep_kernel_ms) *sweep_kernel_ms = g_prof.sweep_ms;
+    if (bc_ms) *bc_ms = g_prof.bc_ms;
+    if (finish_ms) *finish_ms = g_prof.finish_ms;
+    if (sweep_kernel_launches) *sweep_kernel_launches = g_prof.sweep_launches;
+    if (sweeps) *sweeps = g_prof.sweeps;
+    return LSF_OK;
 }
 
 int lsf_release_workspace(void)

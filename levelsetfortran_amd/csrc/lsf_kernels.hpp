@@ -43,7 +43,8 @@ struct GsTile {
     static constexpr int CORE = 64 * RA;
     static constexpr int YH = 8 * 6 * TA;
     static constexpr int ZH = 6 * 8 * TA;
-    static constexpr int TOTAL = CORE + YH + ZH;
+    static constexpr int PS = 64 * TA; // phiS of the tile's own cells
+    static constexpr int TOTAL = CORE + YH + ZH + PS;
 };
 
 template <int TA, bool STRICT>
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(64) void k_reinit_gs_plane(const double* __restrict
     double* core = lds;
     double* yh = lds + T::CORE;
     double* zh = lds + T::CORE + T::YH;
+    double* ps = lds + T::CORE + T::YH + T::ZH;
 
     // ---- load ---------------------------------------------------------------------------
     // value for global point (gi,gj,gk): B if it is an interior cell of an upstream tile, else A
@@ -97,6 +99,10 @@ __global__ __launch_bounds__(64) void k_reinit_gs_plane(const double* __restrict
         const int z = hz < 3 ? hz - 3 : nk + hz - 3;
         zh[idx] = fetch(i_lo + x, j_lo + y, k_lo + z);
     }
+    for (int idx = lane; idx < T::PS; idx += 64) {
+        const int x = idx % TA, yz = idx / TA, yy = yz & 7, zz = yz >> 3;
+        ps[idx] = (x < ni && yy < nj && zz < nk) ? phiS[(long)(i_lo + x) + sx * (j_lo + yy) + sxy * (k_lo + zz)] : 0.0;
+    }
     __syncthreads();
 
     // ---- march ----------------------------------------------------------------------------
@@ -107,7 +113,6 @@ __global__ __launch_bounds__(64) void k_reinit_gs_plane(const double* __restrict
     const int gj = j_lo + y, gk = k_lo + z;
     const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
     const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx;
-    const long rowbase = sx * gj + sxy * gk;
     double acc = 0.0;
     const int nsteps = ni + nj + nk - 2;
 
@@ -122,12 +127,6 @@ __global__ __launch_bounds__(64) void k_reinit_gs_plane(const double* __restrict
         return zh[(hz * 8 + y) * TA + x];
     };
 
-    // phiS of the first cell this lane will visit (prefetched one step ahead afterwards)
-    double pS_next = 0.0;
-    if (row_ok) {
-        const int x0 = si > 0 ? 0 : ni - 1;
-        pS_next = phiS[rowbase + i_lo + x0];
-    }
     for (int s = 0; s < nsteps; ++s) {
         const int a = s - b - c;
         const bool active = row_ok && a >= 0 && a < ni;
@@ -135,8 +134,7 @@ __global__ __launch_bounds__(64) void k_reinit_gs_plane(const double* __restrict
         int x = 0;
         if (active) {
             x = si > 0 ? a : ni - 1 - a;
-            const double pS = pS_next;
-            if (a + 1 < ni) pS_next = phiS[rowbase + i_lo + (si > 0 ? x + 1 : x - 1)];
+            const double pS = ps[(z * 8 + y) * TA + x];
             const int gi = i_lo + x;
             const bool weno_ok = yz_weno && gi > 3 && gi < nx - 4;
             double qx[7], qy[7], qz[7];
@@ -159,7 +157,8 @@ __global__ __launch_bounds__(64) void k_reinit_gs_plane(const double* __restrict
             const double dlt = newv - qx[3];
             acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
         }
-        __syncthreads(); // all reads of this step done before any cell of it is overwritten
+        // one wavefront per tile: its LDS operations execute in program order, so the reads of this
+        // step are done before the write below; the fence makes the write visible to the next step
         if (active) core[(z * 8 + y) * T::RA + x + 3] = newv;
         __syncthreads();
     }

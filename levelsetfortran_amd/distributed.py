@@ -1,0 +1,377 @@
+"""Block-decomposed Jacobi reinitialisation: one process per GPU, 3-cell face halos over
+torch.distributed (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).
+
+The reference is serial (README.md:17): nothing here mirrors reference code.  What must hold is
+that the decomposed sweep produces exactly the field of the single-domain Jacobi sweep
+(include/lsf.h LSF_ORDER_JACOBI), because every cell update reads the same 19 values.  The exact
+Gauss-Seidel ordering does not shard and is not offered here.
+
+Per sweep (DESIGN.md "multi-GPU"):
+  comm stream   : pack owned face slabs (3 thick) -> isend/irecv with up to 6 face neighbours ->
+                  unpack into the ghost layers.  Star stencil: faces only, no edges or corners.
+  compute stream: interior cells (>= 3 from every cut face) concurrently with the exchange,
+                  then the rim slabs, then the extrapolation BC on the owned wall points.
+  RMS           : device partial sums -> one all_reduce(SUM) of a double per sweep.
+
+All arithmetic goes through a backend object:
+  HipBackend   -> liblsf_hip.so (lsf_jacobi_sweep_box / lsf_bc_box / lsf_pack_box / lsf_unpack_box)
+The CPU tests inject an oracle-backed backend from tests/ (the package itself never imports the
+oracle), which exercises this file's decomposition, halo schedule and reduction unchanged.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+HALO = 3  # WENO5 reaches +-3 (subs.f90:509-530)
+
+
+# ------------------------------------------------------------------------------------------------
+# decomposition (pure index arithmetic)
+# ------------------------------------------------------------------------------------------------
+def default_dims(world: int) -> Tuple[int, int, int]:
+    """BASELINE.json configs: 4 GPUs -> 2x2x1, 8 GPUs -> 2x2x2; otherwise factor x, then y, then z."""
+    table = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
+    if world in table:
+        return table[world]
+    dims = [1, 1, 1]
+    n, a = world, 0
+    for p in range(2, world + 1):
+        while n % p == 0:
+            dims[a % 3] *= p
+            n //= p
+            a += 1
+    return tuple(dims)
+
+
+def split_points(npoints: int, parts: int) -> List[Tuple[int, int]]:
+    """Contiguous balanced split of point indices 0..npoints-1 into `parts` ranges [s,e)."""
+    base, extra = divmod(npoints, parts)
+    out, s = [], 0
+    for p in range(parts):
+        e = s + base + (1 if p < extra else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+@dataclass
+class Block:
+    """What one rank holds of the global field (0:nx,0:ny,0:nz)."""
+
+    dims: Tuple[int, int, int]  # process grid
+    coords: Tuple[int, int, int]  # this rank's position
+    n: Tuple[int, int, int]  # global (nx,ny,nz)
+    own: Tuple[Tuple[int, int], ...]  # owned global point range per axis [s,e)
+    g0: Tuple[int, int, int]  # global index of local point 0 (own start minus ghost)
+    ext: Tuple[int, int, int]  # local extents including ghosts
+
+    @property
+    def own_local(self):
+        return tuple((s - g, e - g) for (s, e), g in zip(self.own, self.g0))
+
+    def neighbour(self, axis: int, side: int) -> Optional[int]:
+        c = list(self.coords)
+        c[axis] += side
+        if c[axis] < 0 or c[axis] >= self.dims[axis]:
+            return None
+        return rank_of(tuple(c), self.dims)
+
+    def npoints_local(self) -> int:
+        return self.ext[0] * self.ext[1] * self.ext[2]
+
+
+def rank_of(coords, dims) -> int:
+    return coords[0] + dims[0] * (coords[1] + dims[1] * coords[2])
+
+
+def coords_of(rank, dims):
+    return (rank % dims[0], (rank // dims[0]) % dims[1], rank // (dims[0] * dims[1]))
+
+
+def make_block(rank: int, dims, n) -> Block:
+    coords = coords_of(rank, dims)
+    own, g0, ext = [], [], []
+    for a in range(3):
+        s, e = split_points(n[a] + 1, dims[a])[coords[a]]
+        if e - s < 2 * HALO and dims[a] > 1:
+            raise ValueError(f"axis {a}: {e - s} owned points per rank is fewer than 2*HALO")
+        lo = s - HALO if coords[a] > 0 else s
+        hi = e + HALO if coords[a] < dims[a] - 1 else e
+        own.append((s, e))
+        g0.append(lo)
+        ext.append(hi - lo)
+    return Block(tuple(dims), coords, tuple(n), tuple(own), tuple(g0), tuple(ext))
+
+
+def interior_cells_local(b: Block):
+    """Owned cells that are interior cells of the global grid (1..n-1), as local [lo,hi) per axis."""
+    out = []
+    for a in range(3):
+        s, e = b.own[a]
+        out.append((max(s, 1) - b.g0[a], min(e, b.n[a]) - b.g0[a]))
+    return out
+
+
+def sweep_regions(b: Block):
+    """(core, rims): core needs no ghost data; the rims (disjoint boxes) need the halo exchange."""
+    cells = interior_cells_local(b)
+    core = []
+    for a in range(3):
+        lo, hi = cells[a]
+        if b.coords[a] > 0:
+            lo += HALO
+        if b.coords[a] < b.dims[a] - 1:
+            hi -= HALO
+        core.append((lo, max(hi, lo)))
+    rims = []
+    cur = [list(c) for c in cells]  # shrinking box; peel one axis at a time so rims are disjoint
+    for a in range(3):
+        if core[a][0] > cur[a][0]:
+            r = [tuple(c) for c in cur]
+            r[a] = (cur[a][0], core[a][0])
+            rims.append(r)
+            cur[a][0] = core[a][0]
+        if core[a][1] < cur[a][1]:
+            r = [tuple(c) for c in cur]
+            r[a] = (core[a][1], cur[a][1])
+            rims.append(r)
+            cur[a][1] = core[a][1]
+    return core, rims
+
+
+def halo_plan(b: Block):
+    """[(peer, send_box, recv_box)] in local indices; cross-sections are the owned ranges."""
+    plan = []
+    ol = b.own_local
+    for a in range(3):
+        for side in (-1, +1):
+            peer = b.neighbour(a, side)
+            if peer is None:
+                continue
+            send = [tuple(r) for r in ol]
+            recv = [tuple(r) for r in ol]
+            if side < 0:
+                send[a] = (ol[a][0], ol[a][0] + HALO)
+                recv[a] = (ol[a][0] - HALO, ol[a][0])
+            else:
+                send[a] = (ol[a][1] - HALO, ol[a][1])
+                recv[a] = (ol[a][1], ol[a][1] + HALO)
+            plan.append((peer, send, recv, a, side))
+    return plan
+
+
+# ------------------------------------------------------------------------------------------------
+# HIP backend
+# ------------------------------------------------------------------------------------------------
+class HipBackend:
+    """Device arithmetic through the C ABI; tensors are 1-D torch CUDA float64, i fastest."""
+
+    def __init__(self, device, arith: str = "fast"):
+        import torch
+
+        from . import _lib
+
+        self.torch = torch
+        self.L = _lib
+        self.lib = _lib.load()
+        self.device = device
+        self.mode = _lib.LSF_ORDER_JACOBI | (_lib.LSF_ARITH_STRICT if arith == "strict" else _lib.LSF_ARITH_FAST)
+        _lib.check(self.lib.lsf_set_device(device.index or 0))
+        self.compute = torch.cuda.current_stream(device)
+        self.comm = torch.cuda.Stream(device)
+
+    def empty(self, n, dtype=None):
+        return self.torch.empty(n, dtype=dtype or self.torch.float64, device=self.device)
+
+    def zeros(self, n):
+        return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
+
+    def from_numpy(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a.ravel(order="F"))).to(self.device)
+
+    def to_numpy(self, t, shape):
+        return t.cpu().numpy().reshape(shape, order="F")
+
+    def _box(self, b: Block):
+        return self.L.LsfBox(b.ext[0], b.ext[1], b.ext[2], b.g0[0], b.g0[1], b.g0[2], b.n[0], b.n[1], b.n[2])
+
+    @staticmethod
+    def _lohi(region):
+        from ._lib import int3
+
+        return int3([r[0] for r in region]), int3([r[1] for r in region])
+
+    def sweep(self, a_in, a_out, phiS, b, region, dx, h, sumsq, stream):
+        lo, hi = self._lohi(region)
+        self.L.check(self.lib.lsf_jacobi_sweep_box(a_in.data_ptr(), a_out.data_ptr(), phiS.data_ptr(),
+                                                   ctypes.byref(self._box(b)), lo, hi, dx, h, self.mode,
+                                                   sumsq.data_ptr(), stream.cuda_stream))
+
+    def bc(self, a_in, a_out, b, region, dx, sumsq, stream):
+        lo, hi = self._lohi(region)
+        self.L.check(self.lib.lsf_bc_box(a_in.data_ptr(), a_out.data_ptr(), ctypes.byref(self._box(b)), lo, hi, dx,
+                                         sumsq.data_ptr(), stream.cuda_stream))
+
+    def pack(self, f, b, region, buf, stream):
+        lo, hi = self._lohi(region)
+        self.L.check(self.lib.lsf_pack_box(f.data_ptr(), ctypes.byref(self._box(b)), lo, hi, buf.data_ptr(),
+                                           stream.cuda_stream))
+
+    def unpack(self, f, b, region, buf, stream):
+        lo, hi = self._lohi(region)
+        self.L.check(self.lib.lsf_unpack_box(f.data_ptr(), ctypes.byref(self._box(b)), lo, hi, buf.data_ptr(),
+                                             stream.cuda_stream))
+
+    def stream_ctx(self, stream):
+        return self.torch.cuda.stream(stream)
+
+    def wait(self, waiter, waited):
+        waiter.wait_stream(waited)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# the distributed sweep loop
+# ------------------------------------------------------------------------------------------------
+def _vol(region):
+    return max(region[0][1] - region[0][0], 0) * max(region[1][1] - region[1][0], 0) * max(region[2][1] - region[2][0], 0)
+
+
+class DistributedReinit:
+    """Jacobi reinit of a block-decomposed field.  `backend` supplies the arithmetic and streams."""
+
+    def __init__(self, backend, block: Block, dx: float, h: float, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.be = backend
+        self.b = block
+        self.dx, self.h = float(dx), float(h)
+        self.group = group
+        self.core, self.rims = sweep_regions(block)
+        self.plan = halo_plan(block)
+        self.send_bufs = [backend.empty(_vol(s)) for (_, s, _, _, _) in self.plan]
+        self.recv_bufs = [backend.empty(_vol(r)) for (_, _, r, _, _) in self.plan]
+        self.sumsq = backend.zeros(1)
+        # INTEGER*4 product nx*ny*nz of the GLOBAL grid (subs.f90:914), wrapping like the reference
+        nx, ny, nz = block.n
+        self.den = float(np.int32(np.uint32((nx * ny * nz) & 0xFFFFFFFF)))
+
+    # -- halo exchange of field f on the comm stream ------------------------------------------------
+    def exchange(self, f):
+        be, dist = self.be, self.dist
+        if not self.plan:
+            return
+        be.wait(be.comm, be.compute)  # f was produced on the compute stream
+        with be.stream_ctx(be.comm):
+            ops = []
+            for (peer, s_box, _r, _a, _s), sb in zip(self.plan, self.send_bufs):
+                be.pack(f, self.b, s_box, sb, be.comm)
+            for (peer, _s, _r, a, side), sb, rb in zip(self.plan, self.send_bufs, self.recv_bufs):
+                # tag by (axis, direction of travel) so the two messages between a pair of ranks that are
+                # neighbours on both sides of a periodic-free 2-rank axis cannot be confused
+                ops.append(dist.P2POp(dist.isend, sb, peer, group=self.group, tag=2 * a + (0 if side < 0 else 1)))
+                ops.append(dist.P2POp(dist.irecv, rb, peer, group=self.group, tag=2 * a + (1 if side < 0 else 0)))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for (peer, _s, r_box, _a, _sd), rb in zip(self.plan, self.recv_bufs):
+                be.unpack(f, self.b, r_box, rb, be.comm)
+
+    # -- one sweep: a_in -> a_out; returns nothing; self.sumsq accumulates the local sum of squares ---
+    def sweep(self, a_in, a_out, phiS):
+        be, b = self.be, self.b
+        self.sumsq.zero_()
+        self.exchange(a_in)  # ghosts of a_in (comm stream)
+        if _vol(self.core) > 0:
+            be.sweep(a_in, a_out, phiS, b, self.core, self.dx, self.h, self.sumsq, be.compute)  # overlaps the exchange
+        be.wait(be.compute, be.comm)
+        for r in self.rims:
+            if _vol(r) > 0:
+                be.sweep(a_in, a_out, phiS, b, r, self.dx, self.h, self.sumsq, be.compute)
+        be.bc(a_in, a_out, b, [tuple(r) for r in b.own_local], self.dx, self.sumsq, be.compute)
+
+    def rms_async(self):
+        """all_reduce of the sum of squares; returns a 1-element tensor holding the global sum."""
+        if self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
+            self.dist.all_reduce(self.sumsq, op=self.dist.ReduceOp.SUM, group=self.group)
+        return self.sumsq
+
+    def run(self, phi, iter: int, tol: float = 1.0e-5, check_every: int = 1):
+        """reinit semantics (subs.f90:735-928) on the decomposed field: at most iter+1 sweeps, stop when
+        RMS < tol.  phi is this rank's local box (ghost layers included); returns (result, sweeps, rms list).
+        """
+        be = self.be
+        phiS = phi.clone()
+        bufs = [phi, phi.clone()]
+        rms_hist, pending = [], []
+        done_at = None
+        for s in range(iter + 1):
+            a_in, a_out = bufs[s & 1], bufs[(s + 1) & 1]
+            self.sweep(a_in, a_out, phiS)
+            pending.append(self.rms_async().clone())
+            if (s + 1) % check_every == 0 or s == iter:
+                for t in pending:
+                    rms = math.sqrt(float(t.item()) / self.den) if float(t.item()) >= 0 else float("nan")
+                    rms_hist.append(rms)
+                pending = []
+                hit = [k for k, r in enumerate(rms_hist) if r < tol or r != r]
+                if hit:
+                    done_at = hit[0] + 1
+                    break
+        nsw = done_at if done_at is not None else len(rms_hist)
+        if check_every != 1 and done_at is not None and done_at != len(rms_hist):
+            raise RuntimeError("check_every > 1 ran past the stop sweep; use check_every=1 for run-to-convergence")
+        return bufs[nsw & 1], nsw, rms_hist[:nsw]
+
+
+# ------------------------------------------------------------------------------------------------
+def bench_weak_scaling(N: int, K: int, W: int, device, arith: str = "fast"):
+    """bench.py --mode jacobi --gpus >1: every rank owns an N^3-point block of a (Px N, Py N, Pz N) grid."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from . import fields
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dims = default_dims(world)
+    gpts = tuple(d * N for d in dims)
+    n = tuple(g - 1 for g in gpts)
+    b = make_block(rank, dims, n)
+    be = HipBackend(device, arith)
+    rng = tuple((g, g + e) for g, e in zip(b.g0, b.ext))
+    phi_np, dx = fields.two_sphere_phi0(gpts, ranges=rng)
+    h = fields.reinit_step(dx)
+    phi = be.from_numpy(phi_np)
+    del phi_np
+    dr = DistributedReinit(be, b, dx, h)
+    phiS = phi.clone()
+    bufs = [phi, phi.clone()]
+
+    def steps(k, s0):
+        for s in range(s0, s0 + k):
+            dr.sweep(bufs[s & 1], bufs[(s + 1) & 1], phiS)
+            dr.rms_async()
+        return s0 + k
+
+    s0 = steps(W, 0)
+    dist.barrier(device_ids=[device.index])
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    steps(K, s0)
+    dist.barrier(device_ids=[device.index])
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    cells = float(n[0] - 1) * (n[1] - 1) * (n[2] - 1) * K
+    return {"cells_total": cells, "seconds": dt, "prof": None,
+            "parallelism": f"{dims[0]}x{dims[1]}x{dims[2]} block decomposition, 3-cell face halos over RCCL (xGMI), "
+                           f"halo exchange overlapped with interior cells on a second HIP stream"}

@@ -18,9 +18,12 @@ def grid_axes(npts, lo=-1.5, hi=1.5):
     return lo + dx * np.arange(nxp), lo + dx * np.arange(nyp), lo + dx * np.arange(nzp), dx
 
 
-def sphere_phi0(npts, centers=((0.0, 0.0, 0.0),), radius=1.0, lo=-1.5, hi=1.5):
-    """Fortran-ordered (Nx,Ny,Nz) float64 field and dx.  Several centres -> union (min distance)."""
+def sphere_phi0(npts, centers=((0.0, 0.0, 0.0),), radius=1.0, lo=-1.5, hi=1.5, ranges=None):
+    """Fortran-ordered (Nx,Ny,Nz) float64 field and dx.  Several centres -> union (min distance).
+    ranges = ((i0,i1),(j0,j1),(k0,k1)) returns only that index block of the global field."""
     x, y, z, dx = grid_axes(npts, lo, hi)
+    if ranges is not None:
+        x, y, z = x[ranges[0][0]:ranges[0][1]], y[ranges[1][0]:ranges[1][1]], z[ranges[2][0]:ranges[2][1]]
     d = None
     for c in centers:
         r = np.sqrt((x[:, None, None] - c[0]) ** 2 + (y[None, :, None] - c[1]) ** 2 + (z[None, None, :] - c[2]) ** 2)
@@ -30,8 +33,8 @@ def sphere_phi0(npts, centers=((0.0, 0.0, 0.0),), radius=1.0, lo=-1.5, hi=1.5):
     return np.asfortranarray(phi, dtype=np.float64), float(dx)
 
 
-def two_sphere_phi0(npts, lo=-1.5, hi=1.5):
-    return sphere_phi0(npts, centers=((-0.6, 0.0, 0.0), (0.6, 0.0, 0.0)), radius=0.5, lo=lo, hi=hi)
+def two_sphere_phi0(npts, lo=-1.5, hi=1.5, ranges=None):
+    return sphere_phi0(npts, centers=((-0.6, 0.0, 0.0), (0.6, 0.0, 0.0)), radius=0.5, lo=lo, hi=hi, ranges=ranges)
 
 
 def reinit_step(dx: float, extent=(2.0, 2.0, 2.0), cfl: float = 0.1) -> float:

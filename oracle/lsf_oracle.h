@@ -60,6 +60,13 @@ int lsf_oracle_minmax(double *phi, int32_t *phiNB, int32_t *phiSB, int nx, int n
                       double dx, double h1, double tol, int order, int *iters_done, double *rms_trace,
                       int trace_cap);
 
+/* Block-decomposed pieces used by the tests of levelsetfortran_amd/distributed.py.
+ * box[9] = {lx,ly,lz, gx0,gy0,gz0, nx,ny,nz} (include/lsf.h lsf_box); lo/hi are local [lo,hi). */
+void lsf_oracle_jacobi_box(const double *in, double *out, const double *phiS, const int box[9],
+                           const int lo[3], const int hi[3], double dx, double h, double *sumsq);
+void lsf_oracle_bc_box(const double *in, double *out, const int box[9], const int lo[3], const int hi[3],
+                       double dx, double *sumsq);
+
 /* set3d.f90:196-268: inside/outside initialisation from an indexed triangle soup (the step before
  * the hot path).  surfX is (nSurfNode,3) Fortran-ordered, surfElem is
  * (nSurfElem,3) Fortran-ordered 1-based.  phi must be pre-filled with 1.0 (set3d.f90:161). */

@@ -1,0 +1,38 @@
+"""Binary STL reader with the reference's node de-duplication (restates subs.f90:17-121 in numpy).
+
+Test/fixture tooling only: the STL reader is host I/O and out of the hot-path scope (SURVEY.md
+section 2 row 9); it is needed here to regenerate phi0 from the sample surfaces for the oracle's
+phi0 check.
+"""
+import numpy as np
+
+
+def stl_read(path):
+    """Returns (surfX float64 (nNode,3), surfElem int32 (nTri,3) 1-based) like stlRead."""
+    with open(path, "rb") as f:
+        f.read(80)  # header, subs.f90:38
+        ntri = int(np.frombuffer(f.read(4), dtype="<i4")[0])  # :39
+        rec = np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("pad", "<i2")])  # :48-52
+        tris = np.frombuffer(f.read(ntri * 50), dtype=rec)
+    verts = tris["v"].reshape(-1, 3)  # REAL*4 triangles(3, ntri*3), :49-51
+    # subs.f90:69-93: a vertex is shared if all three REAL*4 coordinates differ by < 1e-13 from an
+    # already stored node.  For float32 data that is exact equality except between values both
+    # smaller than 1e-13; node numbers follow first occurrence.  (The search window quirk
+    # `DO kk = 1,nSurfNode` with nSurfNode updated once per triangle only matters for a triangle
+    # that repeats one of its own new vertices, i.e. a degenerate triangle.)
+    key = np.where(np.abs(verts) < 1e-13, np.float32(0), verts)
+    _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(first)  # unique rows in order of first appearance
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    surfElem = (rank[inv.ravel()] + 1).astype(np.int32).reshape(ntri, 3)
+    surfX = verts[first[order]].astype(np.float64)  # promoted to REAL(8), :99-103
+    return surfX, surfElem
+
+
+def grid_from_surface(surfX, dx=0.05, dd=10):
+    """set3d.f90:90-157: bounding box, nx/ny/nz, xLo for the as-shipped parameters."""
+    mn, mx = surfX.min(axis=0), surfX.max(axis=0)
+    n = [int(np.ceil((mx[a] - mn[a]) / dx)) + 1 + 2 * dd for a in range(3)]
+    xLo = mn - dd * dx
+    return n, xLo, mn, mx

@@ -1,0 +1,249 @@
+"""Parity of the HIP path (through the C ABI) with the reference -- via the committed golden outputs
+of the reference itself and via the oracle on the same seeded inputs.  Integer/sign results and the
+STRICT arithmetic are compared with `==`; the FAST arithmetic within 1e-12 RMS (north_star: 1e-10)."""
+import numpy as np
+import pytest
+
+from conftest import F, sha
+
+pytestmark = pytest.mark.gpu
+
+FAST_RMS_TOL = 1.0e-12  # north_star asks for 1e-10 RMS against the reference; measured ~1e-16
+
+
+def _n(g):
+    return int(g["nx"]), int(g["ny"]), int(g["nz"])
+
+
+def _rms(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+@pytest.fixture(scope="module")
+def lsf():
+    import torch
+
+    assert torch.cuda.is_available()
+    import levelsetfortran_amd
+
+    return levelsetfortran_amd
+
+
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a.ravel(order="F"))).cuda()
+
+
+def _host(t, shape):
+    return t.cpu().numpy().reshape(shape, order="F")
+
+
+# ---------------------------------------------------------------------------------- reinit, exact order
+def test_reinit_strict_matches_reference_synthetic(lsf, synth):
+    nx, ny, nz = _n(synth)
+    phi = F(synth["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, 15, float(synth["dx"]), float(synth["h"]), arith="strict")
+    assert rep.count == 16 and not rep.converged
+    assert np.array_equal(phi, synth["phi_16"])  # all 8 raster directions twice, WENO + first-order cells, BC
+    assert np.allclose(rep.rms, synth["rms"], rtol=1e-11, atol=0)  # parallel sum vs sequential sum
+    phi = F(synth["phi0"])
+    lsf.reinit(phi, None, None, nx, ny, nz, 0, float(synth["dx"]), float(synth["h"]), arith="strict")
+    assert np.array_equal(phi, synth["phi_1"])
+
+
+def test_reinit_fast_within_tolerance_and_sign_exact(lsf, synth):
+    nx, ny, nz = _n(synth)
+    phi = F(synth["phi0"])
+    lsf.reinit(phi, None, None, nx, ny, nz, 15, float(synth["dx"]), float(synth["h"]), arith="fast")
+    assert _rms(phi, synth["phi_16"]) < FAST_RMS_TOL
+    assert np.array_equal(np.signbit(phi), np.signbit(synth["phi_16"]))
+
+
+@pytest.mark.parametrize("npts", [(5, 5, 5), (9, 12, 10), (11, 11, 11), (18, 9, 10), (21, 27, 13), (70, 21, 45), (35, 35, 35)])
+def test_reinit_strict_vs_oracle_ragged_sizes(lsf, oracle, npts):
+    """tiny grids (no WENO cell at all), partial tiles in every axis, one-tile grids"""
+    from levelsetfortran_amd import fields
+
+    phi0, dx = fields.sphere_phi0(npts, radius=0.7, centers=((0.1, -0.2, 0.05),))
+    nx, ny, nz = (v - 1 for v in npts)
+    h = fields.reinit_step(dx)
+    ref = phi0.copy(order="F")
+    rc, n, tr = oracle.reinit(ref, nx, ny, nz, 9, dx, h, tol=0.0)
+    for seam in ("host", "device"):
+        if seam == "host":
+            got = phi0.copy(order="F")
+            rep = lsf.reinit(got, None, None, nx, ny, nz, 9, dx, h, tol=0.0, arith="strict")
+        else:
+            t = _dev(phi0)
+            rep = lsf.reinit(t, None, None, nx, ny, nz, 9, dx, h, tol=0.0, arith="strict")
+            got = _host(t, phi0.shape)
+        assert rep.count == n == 10
+        assert np.array_equal(got, ref), (seam, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("sweeps", [1, 8, 64])
+def test_reinit_cube40_intermediate(lsf, cube40, sweeps):
+    nx, ny, nz = _n(cube40)
+    phi = F(cube40["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, sweeps - 1, float(cube40["dx"]), float(cube40["h"]), arith="strict")
+    assert rep.count == sweeps
+    assert sha(phi) == str(cube40[f"re{sweeps}_sha"])
+
+
+def test_reinit_cube40_to_convergence(lsf, cube40):
+    """BASELINE config 1 (as shipped, 62^3): same sweep count, bit-identical field (STRICT); FAST within tol."""
+    nx, ny, nz = _n(cube40)
+    dx, h, it = float(cube40["dx"]), float(cube40["h"]), int(cube40["iter_reinit"])
+    phi = F(cube40["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, it, dx, h, arith="strict")
+    assert rep.count == int(cube40["sweeps_reinit"]) == 2155 and rep.converged
+    assert np.array_equal(phi, cube40["phi_reinit"])
+    assert np.allclose(rep.rms[:-1], cube40["rms_reinit"], rtol=1e-10, atol=0)
+    lines = rep.lines(0, "steady")
+    assert len(lines) == 2155 and lines[-1] == "steady"  # 2154 "Iteration" lines + the steady-state line
+    phi = F(cube40["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, it, dx, h, arith="fast")
+    assert rep.count == 2155
+    assert _rms(phi, cube40["phi_reinit"]) < FAST_RMS_TOL
+    assert np.array_equal(phi < 0, cube40["phi_reinit"] < 0)  # inside/outside bit-exact
+
+
+def test_reinit_twocube10(lsf, twocube):
+    """BASELINE config 3's surface: pre-divergence state and the NaN stop of the reference."""
+    nx, ny, nz = _n(twocube)
+    dx, h = float(twocube["dx"]), float(twocube["h"])
+    phi = F(twocube["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, 63, dx, h, arith="strict")
+    assert rep.count == 64 and sha(phi) == str(twocube["re64_sha"])
+    phi = F(twocube["phi0"])
+    with pytest.raises(lsf.LsfNaNError):
+        lsf.reinit(phi, None, None, nx, ny, nz, 10000, dx, h, arith="strict")
+
+
+def test_reinit_device_seam_resume_with_phiS(lsf, oracle, synth):
+    """16 sweeps == 5 sweeps + 11 more resumed at raster 5 with the original sign field."""
+    nx, ny, nz = _n(synth)
+    dx, h = float(synth["dx"]), float(synth["h"])
+    t, s = _dev(synth["phi0"]), _dev(synth["phi0"])
+    lsf.reinit(t, None, None, nx, ny, nz, 4, dx, h, tol=0.0, arith="strict", phiS=s)
+    lsf.reinit(t, None, None, nx, ny, nz, 10, dx, h, tol=0.0, arith="strict", phiS=s, first_raster=5)
+    assert np.array_equal(_host(t, synth["phi0"].shape), synth["phi_16"])
+
+
+# ---------------------------------------------------------------------------------- reinit, Jacobi order
+def test_reinit_jacobi_matches_oracle_jacobi(lsf, oracle, synth):
+    nx, ny, nz = _n(synth)
+    dx, h = float(synth["dx"]), float(synth["h"])
+    ref = F(synth["phi0"])
+    oracle.reinit(ref, nx, ny, nz, 15, dx, h, tol=0.0, order=oracle.JACOBI)
+    phi = F(synth["phi0"])
+    lsf.reinit(phi, None, None, nx, ny, nz, 15, dx, h, tol=0.0, order="jacobi", arith="strict")
+    assert np.array_equal(phi, ref)
+    phi = F(synth["phi0"])
+    lsf.reinit(phi, None, None, nx, ny, nz, 15, dx, h, tol=0.0, order="jacobi", arith="fast")
+    assert _rms(phi, ref) < FAST_RMS_TOL
+
+
+def test_box_building_blocks_single_rank(lsf, oracle, synth):
+    """lsf_jacobi_sweep_box + lsf_bc_box + pack/unpack (the multi-GPU pieces) on one GPU, split into
+    core + rims exactly as a rank of a 2x2x2 decomposition would."""
+    import torch
+
+    from levelsetfortran_amd import distributed as D
+
+    nx, ny, nz = _n(synth)
+    dx, h = float(synth["dx"]), float(synth["h"])
+    ref = F(synth["phi0"])
+    rc, n, tr = oracle.reinit(ref, nx, ny, nz, 2, dx, h, tol=0.0, order=oracle.JACOBI)
+    be = D.HipBackend(torch.device("cuda", 0), arith="strict")
+    b = D.make_block(0, (1, 1, 1), (nx, ny, nz))
+    dr = D.DistributedReinit(be, b, dx, h)
+    # force a multi-region sweep: pretend the block had neighbours on every side
+    cells = D.interior_cells_local(b)
+    core = [(lo + 3, hi - 3) for lo, hi in cells]
+    fake = D.Block((3, 3, 3), (1, 1, 1), b.n, b.own, b.g0, b.ext)
+    c2, rims = D.sweep_regions(fake)
+    assert c2 == core and len(rims) == 6
+    dr.core, dr.rims = c2, rims
+    out, nsw, rms = dr.run(be.from_numpy(synth["phi0"]), 2, tol=0.0)
+    assert nsw == 3 and np.array_equal(be.to_numpy(out, b.ext), ref)
+    assert np.allclose(rms, tr, rtol=1e-11, atol=0)
+    # pack / unpack round trip of a ragged sub-box
+    f = be.from_numpy(synth["phi0"])
+    reg = [(2, 7), (1, 9), (3, 6)]
+    buf = be.empty(5 * 8 * 3)
+    be.pack(f, b, reg, buf, be.compute)
+    g = be.zeros(f.numel())
+    be.unpack(g, b, reg, buf, be.compute)
+    be.synchronize()
+    a3 = synth["phi0"]
+    z = np.zeros_like(a3)
+    z[2:7, 1:9, 3:6] = a3[2:7, 1:9, 3:6]
+    assert np.array_equal(be.to_numpy(g, b.ext), z)
+
+
+# ---------------------------------------------------------------------------------- narrowBand, min/max
+def test_narrowband(lsf, cube40):
+    nx, ny, nz = _n(cube40)
+    phi = F(cube40["phi_reinit"])
+    nb = np.zeros(phi.shape, dtype=np.int32, order="F")
+    sb = np.full(phi.shape, 7, dtype=np.int32, order="F")
+    lsf.narrowBand(nx, ny, nz, float(cube40["dx"]), phi, nb, sb)
+    assert np.array_equal(nb, cube40["NB0"]) and np.array_equal(sb, cube40["SB0"])
+
+
+@pytest.mark.parametrize("its", [1, 2, 10, 200])
+def test_minmax_cube40_intermediate(lsf, cube40, its):
+    nx, ny, nz = _n(cube40)
+    phi, nb, sb = F(cube40["phi_reinit"]), F(cube40["NB0"].astype(np.int32)), F(cube40["SB0"].astype(np.int32))
+    rep = lsf.minmaxFlow(phi, nb, sb, nx, ny, nz, its, float(cube40["dx"]), float(cube40["h1"]))
+    assert rep.count == its and sha(phi) == str(cube40[f"mm{its}_sha"])
+
+
+def test_minmax_cube40_to_convergence(lsf, cube40):
+    nx, ny, nz = _n(cube40)
+    for seam in ("host", "device"):
+        phi, nb, sb = F(cube40["phi_reinit"]), F(cube40["NB0"].astype(np.int32)), F(cube40["SB0"].astype(np.int32))
+        if seam == "device":
+            import torch
+
+            tp, tn, ts = _dev(phi), _dev(nb), _dev(sb)
+            rep = lsf.minmaxFlow(tp, tn, ts, nx, ny, nz, 10000, float(cube40["dx"]), float(cube40["h1"]))
+            phi, nb, sb = _host(tp, phi.shape), _host(tn, phi.shape), _host(ts, phi.shape)
+        else:
+            rep = lsf.minmaxFlow(phi, nb, sb, nx, ny, nz, 10000, float(cube40["dx"]), float(cube40["h1"]))
+        assert rep.count == int(cube40["iters_minmax"]) == 406 and rep.converged
+        assert np.array_equal(phi, cube40["phi_minmax"])
+        # EXIT happens before narrowBand (set3d.f90:448-460): masks describe the previous iteration
+        assert np.array_equal(nb, cube40["NBfinal"]) and np.array_equal(sb, cube40["SBfinal"])
+        assert np.allclose(rep.rms[:-1], cube40["rms_minmax"], rtol=1e-9, atol=0)
+
+
+def test_minmax_vs_oracle_other_shapes(lsf, oracle):
+    from levelsetfortran_amd import fields
+
+    for npts, order, oo in (((40, 33, 27), "gs", None), ((24, 50, 31), "gs", None), ((40, 33, 27), "jacobi", None)):
+        phi0, dx = fields.sphere_phi0(npts, radius=0.45, centers=((0.0, 0.0, -0.1),), lo=-1.0, hi=1.0)
+        nx, ny, nz = (v - 1 for v in npts)
+        # a rough signed-distance-like field so that the band is a thin shell away from the walls
+        x, y, z, _ = fields.grid_axes(npts, -1.0, 1.0)
+        d = np.sqrt(x[:, None, None] ** 2 + y[None, :, None] ** 2 + (z[None, None, :] + 0.1) ** 2) - 0.45
+        phi0 = np.asfortranarray(d + 0.02 * np.sin(9 * x)[:, None, None] * np.cos(7 * y)[None, :, None])
+        nb, sb = oracle.narrowband(nx, ny, nz, dx, phi0)
+        assert 0 < nb.sum() < nb.size // 2
+        a, na, sa = phi0.copy(order="F"), nb.copy(order="F"), sb.copy(order="F")
+        oracle.minmax(a, na, sa, nx, ny, nz, 12, dx, 1e-4, tol=0.0, order=oracle.GS_LEX if order == "gs" else oracle.JACOBI)
+        b, nb2, sb2 = phi0.copy(order="F"), nb.copy(order="F"), sb.copy(order="F")
+        rep = lsf.minmaxFlow(b, nb2, sb2, nx, ny, nz, 12, dx, 1e-4, tol=0.0, order=order)
+        assert rep.count == 12
+        assert np.array_equal(a, b) and np.array_equal(na, nb2) and np.array_equal(sa, sb2)
+
+
+def test_zero_iterations_and_errors(lsf):
+    phi = np.ones((8, 8, 8), order="F")
+    nb = np.zeros((8, 8, 8), dtype=np.int32, order="F")
+    rep = lsf.minmaxFlow(phi, nb, nb.copy(order="F"), 7, 7, 7, 0, 0.1, 0.01)
+    assert rep.count == 0 and np.all(phi == 1.0)
+    with pytest.raises(lsf.LsfError):
+        lsf.reinit(np.ones((2, 2, 2), order="F"), None, None, 1, 1, 1, 0, 0.1, 0.01)  # nx must be >= 2

@@ -1,0 +1,137 @@
+"""The oracle (oracle/lsf_oracle.c) against the reference's own outputs (tests/golden/*.npz, made by
+tests/golden/make_golden.py from the amdflang-built reference).  CPU only.  Everything is `==`."""
+import numpy as np
+import pytest
+
+from conftest import F, sha
+
+
+def _n(g):
+    return int(g["nx"]), int(g["ny"]), int(g["nz"])
+
+
+def test_reinit_synthetic_matches_reference(oracle, synth):
+    nx, ny, nz = _n(synth)
+    dx, h = float(synth["dx"]), float(synth["h"])
+    for order in (oracle.GS_LEX, oracle.GS_HYPER):
+        phi = F(synth["phi0"])
+        rc, n, tr = oracle.reinit(phi, nx, ny, nz, 15, dx, h, order=order)
+        assert rc == 0 and n == 16
+        assert np.array_equal(phi, synth["phi_16"])
+        assert np.array_equal(tr, synth["rms"])  # the values the reference printed
+    phi = F(synth["phi0"])
+    oracle.reinit(phi, nx, ny, nz, 0, dx, h)
+    assert np.array_equal(phi, synth["phi_1"])
+
+
+def test_first_raster_split_equals_one_run(oracle, synth):
+    """16 sweeps == 5 sweeps + 11 sweeps resumed at raster 5 with the same sign field (device-seam feature)."""
+    nx, ny, nz = _n(synth)
+    dx, h = float(synth["dx"]), float(synth["h"])
+    # the oracle resets phiS = phi on entry, so a split run differs unless the field is resumed
+    # through the library's phiS argument; here we only check the raster bookkeeping on sweep 1
+    phi = F(synth["phi0"])
+    oracle.reinit(phi, nx, ny, nz, 0, dx, h, first_raster=0)
+    assert np.array_equal(phi, synth["phi_1"])
+    phi2 = F(synth["phi0"])
+    oracle.reinit(phi2, nx, ny, nz, 0, dx, h, first_raster=3)
+    assert not np.array_equal(phi2, synth["phi_1"])
+
+
+@pytest.mark.parametrize("sweeps", [1, 8, 64])
+def test_reinit_cube40_intermediate(oracle, cube40, sweeps):
+    nx, ny, nz = _n(cube40)
+    phi = F(cube40["phi0"])
+    rc, n, tr = oracle.reinit(phi, nx, ny, nz, sweeps - 1, float(cube40["dx"]), float(cube40["h"]))
+    assert n == sweeps
+    assert sha(phi) == str(cube40[f"re{sweeps}_sha"])
+    assert np.array_equal(phi[::3, ::3, ::3], cube40[f"re{sweeps}_sample"])
+    assert np.array_equal(tr, cube40["rms_reinit"][:sweeps])
+
+
+def test_reinit_cube40_to_convergence(oracle, cube40):
+    """The shipped case: 2155 sweeps, bit-identical field, every printed RMS identical."""
+    nx, ny, nz = _n(cube40)
+    phi = F(cube40["phi0"])
+    rc, n, tr = oracle.reinit(phi, nx, ny, nz, int(cube40["iter_reinit"]), float(cube40["dx"]), float(cube40["h"]))
+    assert rc == 0 and n == int(cube40["sweeps_reinit"]) == 2155
+    assert np.array_equal(phi, cube40["phi_reinit"])
+    assert np.array_equal(tr[:-1], cube40["rms_reinit"])  # the converged sweep prints no RMS line
+    assert tr[-1] < 1e-5
+    # SURVEY.md section 4 known answers
+    assert phi[31, 31, 31] == -0.915413945378742 and phi[0, 0, 0] == 0.8395727865558302
+    assert int((phi < 0).sum()) == 59319
+
+
+def test_narrowband_cube40(oracle, cube40):
+    nx, ny, nz = _n(cube40)
+    nb, sb = oracle.narrowband(nx, ny, nz, float(cube40["dx"]), F(cube40["phi_reinit"]))
+    assert np.array_equal(nb, cube40["NB0"].astype(np.int32)) and np.array_equal(sb, cube40["SB0"].astype(np.int32))
+    assert int(nb.sum()) == 84530 and int(sb.sum()) == 161222
+
+
+def test_minmax_cube40(oracle, cube40):
+    nx, ny, nz = _n(cube40)
+    dx, h1 = float(cube40["dx"]), float(cube40["h1"])
+    for order in (oracle.GS_LEX, oracle.GS_HYPER):
+        for its in (1, 2, 10, 200):
+            phi, nb, sb = F(cube40["phi_reinit"]), F(cube40["NB0"].astype(np.int32)), F(cube40["SB0"].astype(np.int32))
+            rc, n, tr = oracle.minmax(phi, nb, sb, nx, ny, nz, its, dx, h1, order=order)
+            assert n == its and sha(phi) == str(cube40[f"mm{its}_sha"])
+            assert np.array_equal(tr, cube40["rms_minmax"][:its])
+            if order == oracle.GS_HYPER:
+                break
+    phi, nb, sb = F(cube40["phi_reinit"]), F(cube40["NB0"].astype(np.int32)), F(cube40["SB0"].astype(np.int32))
+    rc, n, tr = oracle.minmax(phi, nb, sb, nx, ny, nz, 10000, dx, h1)
+    assert rc == 0 and n == int(cube40["iters_minmax"]) == 406
+    assert np.array_equal(phi, cube40["phi_minmax"])
+    assert np.array_equal(nb, cube40["NBfinal"].astype(np.int32)) and np.array_equal(sb, cube40["SBfinal"].astype(np.int32))
+    assert int((phi < 0).sum()) == 59311
+
+
+def test_twocube10_divergence(oracle, twocube):
+    """twoCube10.stl as shipped diverges: the reference prints NaN at sweep index 272 and STOPs."""
+    nx, ny, nz = _n(twocube)
+    dx, h = float(twocube["dx"]), float(twocube["h"])
+    phi = F(twocube["phi0"])
+    rc, n, tr = oracle.reinit(phi, nx, ny, nz, 63, dx, h)
+    assert n == 64 and sha(phi) == str(twocube["re64_sha"])
+    assert np.array_equal(phi[::3, ::3, ::3], twocube["re64_sample"])
+    phi = F(twocube["phi0"])
+    rc, n, tr = oracle.reinit(phi, nx, ny, nz, 10000, dx, h)
+    k = int(twocube["nan_sweep_index"])
+    assert rc == 1 and n == k + 1 == 273
+    assert np.array_equal(tr[:k], twocube["rms"][:k]) and np.isnan(tr[k])
+
+
+def test_bc_closed_form_equals_literal_loop(oracle):
+    rng = np.random.default_rng(7)
+    for shape in ((9, 7, 6), (5, 5, 5), (12, 4, 8)):
+        a = np.asfortranarray(rng.standard_normal(shape))
+        b = a.copy(order="F")
+        nx, ny, nz = (s - 1 for s in shape)
+        oracle.bc(a, nx, ny, nz, 0.0371, oracle.BC_LITERAL)
+        oracle.bc(b, nx, ny, nz, 0.0371, oracle.BC_CLOSED)
+        assert np.array_equal(a, b)
+
+
+def test_phi0_from_surfaces(oracle, cube40, twocube):
+    """set3d.f90:130-268 restated: grid from the bounding box, nearest-centroid sign."""
+    import stl_io
+
+    s = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "surfaces.npz"))
+    for tag, gold in (("cube40", cube40), ("twocube10", twocube)):
+        X, E = s[tag + "_surfX"].astype(np.float64), s[tag + "_surfElem"]
+        n, xLo, mn, mx = stl_io.grid_from_surface(X)
+        assert tuple(n) == _n(gold)
+        p = oracle.phi0(n[0], n[1], n[2], 0.05, xLo, mn, mx, X, E)
+        assert np.array_equal(p, gold["phi0"])
+
+
+def test_jacobi_differs_from_reference_ordering(oracle, synth):
+    """Why two orderings exist: the double-buffered sweep is NOT what the reference computes."""
+    nx, ny, nz = _n(synth)
+    phi = F(synth["phi0"])
+    oracle.reinit(phi, nx, ny, nz, 15, float(synth["dx"]), float(synth["h"]), order=oracle.JACOBI)
+    d = np.abs(phi - synth["phi_16"]).max()
+    assert 1e-9 < d < 1e-2
