@@ -1,0 +1,226 @@
+!*************************************************************************************!
+! lsf_hip.f90 -- iso_c_binding shim between the reference's Fortran host (set3d.f90) and
+! liblsf_hip.so (include/lsf.h).
+!
+! It gives the host back the procedures of the hot path UNDER THEIR ORIGINAL NAMES AND
+! ARGUMENT LISTS, so that the main program calls them exactly as before:
+!
+!   reinit(phi,gradPhi,gradPhiMag,nx,ny,nz,iter,dx,h)   replaces subs.f90:717-931
+!   narrowBand(nx,ny,nz,dx,phi,phiNB,phiSB)             replaces subs.f90:178-207
+!   minmaxFlow(phi,phiNB,phiSB,nx,ny,nz,iter,dx,h1)     replaces the loop set3d.f90:394-462
+!
+! and reproduces what the reference prints around them (subs.f90:916,923,929 and
+! set3d.f90:449,456,463) and its STOP on a NaN residual (subs.f90:926, set3d.f90:458).
+!
+! Build with the reference's own flags (-fdefault-real-8, Makefile:4): REAL below is
+! then REAL(8) = C double, INTEGER is C int.  INTEGRATION.md shows the two edits to the
+! host that bring this module in; levelsetfortran_amd/fortran/Makefile applies them to
+! /root/reference/set3d.f90 at build time without copying it into this repository.
+!
+! Runtime switches (environment):  LSF_ORDER = gs (default) | jacobi
+!                                  LSF_ARITH = fast (default) | strict
+!*************************************************************************************!
+MODULE lsf_hip
+
+USE, INTRINSIC :: iso_c_binding
+IMPLICIT NONE
+PRIVATE
+PUBLIC :: reinit, narrowBand, minmaxFlow, lsf_env_real, lsf_env_int
+
+INTEGER(c_int), PARAMETER :: LSF_OK = 0, LSF_ERR_NAN = 1
+INTEGER(c_int), PARAMETER :: LSF_ORDER_JACOBI = 1, LSF_ARITH_STRICT = 256
+
+INTERFACE
+   ! int lsf_reinit(double*,int,int,int,int,double,double,double,int,int*,double*,int)
+   FUNCTION lsf_reinit(phi,nx,ny,nz,iter,dx,h,tol,mode,sweeps_done,rms_trace,trace_cap) &
+            BIND(C,NAME='lsf_reinit') RESULT(rc)
+      IMPORT :: c_int, c_double
+      REAL(c_double), INTENT(INOUT) :: phi(*)
+      INTEGER(c_int), VALUE :: nx,ny,nz,iter,mode,trace_cap
+      REAL(c_double), VALUE :: dx,h,tol
+      INTEGER(c_int), INTENT(OUT) :: sweeps_done
+      REAL(c_double), INTENT(OUT) :: rms_trace(*)
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_reinit
+   FUNCTION lsf_minmax(phi,phiNB,phiSB,nx,ny,nz,iter,dx,h1,tol,mode,iters_done,rms_trace,trace_cap) &
+            BIND(C,NAME='lsf_minmax') RESULT(rc)
+      IMPORT :: c_int, c_double
+      REAL(c_double), INTENT(INOUT) :: phi(*)
+      INTEGER(c_int), INTENT(INOUT) :: phiNB(*),phiSB(*)
+      INTEGER(c_int), VALUE :: nx,ny,nz,iter,mode,trace_cap
+      REAL(c_double), VALUE :: dx,h1,tol
+      INTEGER(c_int), INTENT(OUT) :: iters_done
+      REAL(c_double), INTENT(OUT) :: rms_trace(*)
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_minmax
+   FUNCTION lsf_narrowband(phi,phiNB,phiSB,nx,ny,nz,dx) BIND(C,NAME='lsf_narrowband') RESULT(rc)
+      IMPORT :: c_int, c_double
+      REAL(c_double), INTENT(IN) :: phi(*)
+      INTEGER(c_int), INTENT(INOUT) :: phiNB(*),phiSB(*)
+      INTEGER(c_int), VALUE :: nx,ny,nz
+      REAL(c_double), VALUE :: dx
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_narrowband
+   FUNCTION lsf_last_error() BIND(C,NAME='lsf_last_error') RESULT(p)
+      IMPORT :: c_ptr
+      TYPE(c_ptr) :: p
+   END FUNCTION lsf_last_error
+   FUNCTION c_strlen(s) BIND(C,NAME='strlen') RESULT(n)
+      IMPORT :: c_ptr, c_size_t
+      TYPE(c_ptr), VALUE :: s
+      INTEGER(c_size_t) :: n
+   END FUNCTION c_strlen
+END INTERFACE
+
+CONTAINS
+
+!*************************************************************************************!
+! mode word of include/lsf.h from the environment
+!*************************************************************************************!
+FUNCTION lsf_mode() RESULT(mode)
+INTEGER(c_int) :: mode
+CHARACTER(LEN=32) :: v
+INTEGER :: st
+mode = 0
+CALL get_environment_variable('LSF_ORDER',v,STATUS=st)
+IF (st == 0 .AND. TRIM(v) == 'jacobi') mode = mode + LSF_ORDER_JACOBI
+CALL get_environment_variable('LSF_ARITH',v,STATUS=st)
+IF (st == 0 .AND. TRIM(v) == 'strict') mode = mode + LSF_ARITH_STRICT
+END FUNCTION lsf_mode
+
+SUBROUTINE lsf_fail(where,rc)
+CHARACTER(LEN=*), INTENT(IN) :: where
+INTEGER(c_int), INTENT(IN) :: rc
+TYPE(c_ptr) :: p
+CHARACTER(KIND=c_char), POINTER :: s(:)
+INTEGER :: n,i
+CHARACTER(LEN=512) :: msg
+msg = ''
+p = lsf_last_error()
+IF (c_associated(p)) THEN
+   n = MIN(INT(c_strlen(p)),512)
+   CALL c_f_pointer(p,s,(/n/))
+   DO i = 1,n
+      msg(i:i) = s(i)
+   END DO
+END IF
+PRINT*, " liblsf_hip: ",where," failed with code ",rc,": ",TRIM(msg)
+STOP 1
+END SUBROUTINE lsf_fail
+
+!*************************************************************************************!
+! Reinitialize the signed distance function  (same dummy arguments as subs.f90:717-725)
+!*************************************************************************************!
+SUBROUTINE reinit(phi,gradPhi,gradPhiMag,nx,ny,nz,iter,dx,h)
+
+INTEGER,INTENT(IN) :: nx,ny,nz,iter
+REAL,INTENT(IN) :: dx,h
+REAL,DIMENSION(0:nx,0:ny,0:nz),INTENT(INOUT) :: phi,gradPhiMag
+REAL,DIMENSION(0:nx,0:ny,0:nz,3),INTENT(INOUT) :: gradPhi
+REAL,ALLOCATABLE :: trace(:)
+INTEGER(c_int) :: rc,done
+INTEGER :: n
+
+! gradPhi and gradPhiMag are dead outputs of the reference's reinit: the host zeroes them
+! right after the first call (set3d.f90:372-375) and never reads them after the second.
+! They are left untouched.
+
+ALLOCATE(trace(iter+1))
+rc = lsf_reinit(phi,nx,ny,nz,iter,dx,h,1.E-5,lsf_mode(),done,trace,iter+1)
+IF (rc /= LSF_OK .AND. rc /= LSF_ERR_NAN) CALL lsf_fail('lsf_reinit',rc)
+
+! what the reference prints, sweep by sweep (subs.f90:915-926)
+DO n = 0,done-1
+   IF (trace(n+1) < 1.E-5) THEN
+      PRINT*, " Distance function time integration has reached steady state "
+      EXIT
+   END IF
+   PRINT*, " Iteration: ",n," ", " RMS Error: ",trace(n+1)
+   IF (isnan(trace(n+1))) STOP
+END DO
+PRINT*
+DEALLOCATE(trace)
+
+END SUBROUTINE reinit
+
+!*************************************************************************************!
+! Determine Narrow Band  (same dummy arguments as subs.f90:178-184)
+!*************************************************************************************!
+SUBROUTINE narrowBand(nx,ny,nz,dx,phi,phiNB,phiSB)
+
+INTEGER,INTENT(IN) :: nx,ny,nz
+REAL,INTENT(IN) :: dx
+REAL,DIMENSION(0:nx,0:ny,0:nz),INTENT(IN) :: phi
+INTEGER,DIMENSION(0:nx,0:ny,0:nz),INTENT(INOUT) :: phiNB,phiSB
+INTEGER(c_int) :: rc
+
+rc = lsf_narrowband(phi,phiNB,phiSB,nx,ny,nz,dx)
+IF (rc /= LSF_OK) CALL lsf_fail('lsf_narrowband',rc)
+
+END SUBROUTINE narrowBand
+
+!*************************************************************************************!
+! Min/Max Flow: the loop of set3d.f90:394-462 as one call
+!*************************************************************************************!
+SUBROUTINE minmaxFlow(phi,phiNB,phiSB,nx,ny,nz,iter,dx,h1)
+
+INTEGER,INTENT(IN) :: nx,ny,nz,iter
+REAL,INTENT(IN) :: dx,h1
+REAL,DIMENSION(0:nx,0:ny,0:nz),INTENT(INOUT) :: phi
+INTEGER,DIMENSION(0:nx,0:ny,0:nz),INTENT(INOUT) :: phiNB,phiSB
+REAL,ALLOCATABLE :: trace(:)
+INTEGER(c_int) :: rc,done
+INTEGER :: n
+
+ALLOCATE(trace(MAX(iter,1)))
+rc = lsf_minmax(phi,phiNB,phiSB,nx,ny,nz,iter,dx,h1,1.E-7,lsf_mode(),done,trace,MAX(iter,1))
+IF (rc /= LSF_OK .AND. rc /= LSF_ERR_NAN) CALL lsf_fail('lsf_minmax',rc)
+
+! what the reference prints (set3d.f90:448-458)
+DO n = 1,done
+   IF (trace(n) < 1.E-7) THEN
+      PRINT*, " Min/max time integration has reached steady state "
+      EXIT
+   END IF
+   PRINT*, " Iteration: ",n," ", " RMS Error: ",trace(n)
+   IF (isnan(trace(n))) STOP
+END DO
+PRINT*
+DEALLOCATE(trace)
+
+END SUBROUTINE minmaxFlow
+
+!*************************************************************************************!
+! Run-time overrides of the host's hard-coded parameters (set3d.f90:140,148,298,390,576)
+! needed by every BASELINE configuration except the as-shipped one.
+!*************************************************************************************!
+SUBROUTINE lsf_env_real(name,val)
+CHARACTER(LEN=*), INTENT(IN) :: name
+REAL, INTENT(INOUT) :: val
+CHARACTER(LEN=64) :: v
+INTEGER :: st,ios
+REAL :: t
+CALL get_environment_variable(name,v,STATUS=st)
+IF (st /= 0) RETURN
+READ(v,*,IOSTAT=ios) t
+IF (ios == 0) THEN
+   val = t
+   PRINT*, " ",name," = ",val," (environment override)"
+END IF
+END SUBROUTINE lsf_env_real
+
+SUBROUTINE lsf_env_int(name,val)
+CHARACTER(LEN=*), INTENT(IN) :: name
+INTEGER, INTENT(INOUT) :: val
+CHARACTER(LEN=64) :: v
+INTEGER :: st,ios,t
+CALL get_environment_variable(name,v,STATUS=st)
+IF (st /= 0) RETURN
+READ(v,*,IOSTAT=ios) t
+IF (ios == 0) THEN
+   val = t
+   PRINT*, " ",name," = ",val," (environment override)"
+END IF
+END SUBROUTINE lsf_env_int
+
+END MODULE lsf_hip

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 CSVs of profiles/collect.sh into the small committed summaries:
+  profiles/<tag>_kernel_stats.csv      per-kernel calls / total / average / min / max (from --stats)
+  profiles/<tag>_pmc_hbm.json          HBM bytes per sweep from FETCH_SIZE / WRITE_SIZE, raw and with the
+                                       gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 128-B
+                                       requests as 64 B for wide coalesced reads -> x2 upper bound)
+  profiles/traffic.json                {kernel: {N: bytes per sweep}} read by bench.py ("traffic")
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+out_dir, tag = sys.argv[1], sys.argv[2]
+here = os.path.dirname(os.path.abspath(__file__))
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(out_dir, pattern), recursive=True)
+    return g[0] if g else None
+
+
+stats = one("trace/**/*kernel_stats.csv")
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join(here, f"{tag}_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"])
+        for r in rows:
+            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]])
+
+res = {"unit": "bytes per sweep", "N": 512, "note": "sum over the sweep-kernel dispatches of one sweep; counters are in KiB "
+       "(rocprofv3 FETCH_SIZE/WRITE_SIZE); fetch_corrected = 2 x fetch_raw (gfx950 wide-read correction, upper bound)"}
+traffic = {}
+for mode, kern in (("gs", "k_reinit_gs_plane"), ("jacobi", "k_reinit_jacobi")):
+    entry = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = one(f"pmc_{ctr}_{mode}/**/*counter_collection.csv")
+        if not f:
+            continue
+        tot, ndisp = 0.0, 0
+        for r in csv.DictReader(open(f)):
+            if kern in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                tot += float(r["Counter_Value"])
+                ndisp += 1
+        entry[ctr] = {"sum_KiB": tot, "dispatches": ndisp}
+    if "FETCH_SIZE" in entry and "WRITE_SIZE" in entry:
+        sweeps = 2.0
+        fr = entry["FETCH_SIZE"]["sum_KiB"] * 1024 / sweeps
+        wr = entry["WRITE_SIZE"]["sum_KiB"] * 1024 / sweeps
+        entry["per_sweep"] = {"fetch_raw": fr, "fetch_corrected": 2 * fr, "write": wr, "hbm_raw": fr + wr,
+                              "hbm_corrected": 2 * fr + wr, "algorithmic": 24.0 * 510 ** 3}
+        traffic[kern] = {"512": 2 * fr + wr}
+    res[kern] = entry
+json.dump(res, open(os.path.join(here, f"{tag}_pmc_hbm.json"), "w"), indent=1)
+if traffic:
+    json.dump(traffic, open(os.path.join(here, "traffic.json"), "w"), indent=1)
+b = os.path.join(out_dir, "bench_under_rocprof.json")
+if os.path.exists(b):
+    lines = [l for l in open(b) if l.startswith("{")]
+    if lines:
+        open(os.path.join(here, f"{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
+print(json.dumps(res)[:1500])

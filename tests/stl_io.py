@@ -36,3 +36,23 @@ def grid_from_surface(surfX, dx=0.05, dd=10):
     n = [int(np.ceil((mx[a] - mn[a]) / dx)) + 1 + 2 * dd for a in range(3)]
     xLo = mn - dd * dx
     return n, xLo, mn, mx
+
+
+def stl_write(path, surfX, surfElem):
+    """Binary STL from nodes + 1-based connectivity (normals zero: the reference reader ignores them)."""
+    tri = np.asarray(surfX, dtype=np.float32)[np.asarray(surfElem) - 1]  # (ntri,3,3)
+    rec = np.zeros(tri.shape[0], dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("pad", "<i2")]))
+    rec["v"] = tri
+    with open(path, "wb") as f:
+        f.write(b"levelsetfortran_amd test surface".ljust(80, b" "))
+        f.write(np.int32(tri.shape[0]).tobytes())
+        f.write(rec.tobytes())
+
+
+def vti_read_phi(path, shape):
+    """Payload of the reference's .vti writer (set3d.f90:336-351): '_' + int32 + raw Float64, i fastest."""
+    raw = open(path, "rb").read()
+    k = raw.index(b'<AppendedData encoding="raw">') + len(b'<AppendedData encoding="raw">') + 1  # + lf
+    assert raw[k:k + 1] == b"_"
+    n = int(np.prod(shape))
+    return np.frombuffer(raw, dtype="<f8", count=n, offset=k + 1 + 4).reshape(shape, order="F")

@@ -1,0 +1,39 @@
+"""BASELINE config 1 through the drop-in executable: the reference's own host (set3d.f90, built where
+it lies by levelsetfortran_amd/fortran/Makefile) calling liblsf_hip.so through the iso_c_binding shim.
+Skipped when the executable was not built (it needs /root/reference at build time)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "build", "dropin", "set3d_hip.exec")
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="drop-in executable not built")
+def test_cube40_as_shipped_through_the_fortran_host(tmp_path, cube40):
+    import stl_io
+
+    s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    stl_io.stl_write(tmp_path / "cube40.stl", s["cube40_surfX"], s["cube40_surfElem"])
+    env = dict(os.environ, LSF_ARITH="strict", LSF_REINIT2_ITER="0")
+    p = subprocess.run(f"ulimit -s unlimited; cd {tmp_path}; {EXE} cube40.stl", shell=True, env=env, text=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout
+    assert p.returncode == 0, out[-2000:]
+    assert "Grid Size: nx = 61 , ny = 61 ,nz = 61" in out
+    assert "Distance function time integration has reached steady state" in out
+    assert "Min/max time integration has reached steady state" in out
+    its = [int(x) for x in re.findall(r"Iteration:\s+(\d+)", out)]
+    # reinit #1 prints 0..2153, min/max prints 1..405, reinit #2 (capped to 1 sweep here) prints 0
+    assert its[:2154] == list(range(2154)) and its[2154:2154 + 405] == list(range(1, 406))
+    asym = float(re.search(r"Asymptotic Error:\s+(\S+)", out).group(1))
+    assert abs(asym - 1.0085048924202963E-02) < 1e-15
+    shape = (62, 62, 62)
+    assert np.array_equal(stl_io.vti_read_phi(tmp_path / "signedDistanceFunction.vti", shape), cube40["phi_reinit"])
+    assert np.array_equal(stl_io.vti_read_phi(tmp_path / "smoothedDistanceFunction.vti", shape), cube40["phi_minmax"])
+    assert os.path.exists(tmp_path / "cube40.s3d")
