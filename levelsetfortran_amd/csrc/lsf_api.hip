@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -33,7 +34,16 @@ int fail(int code, const std::string& msg)
             return fail(LSF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
     } while (0)
 
-constexpr int GS_TA = 16;      // tile length along i of the exact-GS reinit kernel
+// tile length along i of the exact-GS reinit (quad) kernel; cross-section 4x4.  LSF_GS_TA=8|16|32 overrides.
+int gs_ta()
+{
+    static int v = [] {
+        const char* e = getenv("LSF_GS_TA");
+        const int t = e ? atoi(e) : 16;
+        return (t == 8 || t == 16 || t == 32) ? t : 16;
+    }();
+    return v;
+}
 constexpr int MM_TA = 32;      // tile length along i of the exact-GS min/max kernel
 constexpr int CHECK_EVERY = 8; // sweeps between host reads of the device stop flag
 
@@ -232,9 +242,9 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     dim3 jgrid;
     long n_sweep_part = 0;
     if (order == LSF_ORDER_GS) {
-        nTi = cdiv(nx - 1, GS_TA), nTj = cdiv(ny - 1, 8), nTk = cdiv(nz - 1, 8);
+        nTi = cdiv(nx - 1, gs_ta()), nTj = cdiv(ny - 1, 4), nTk = cdiv(nz - 1, 4);
         if ((rc = get_tiles(nTi, nTj, nTk, &tl))) return rc;
-        n_sweep_part = (long)nTi * nTj * nTk;
+        n_sweep_part = (long)nTj * nTk; // one RMS slot per (tj,tk) tile column
     } else {
         jgrid = dim3(cdiv(nx - 1, JAC_BX), cdiv(ny - 1, JAC_BY), cdiv(nz - 1, JAC_KC));
         n_sweep_part = (long)jgrid.x * jgrid.y * jgrid.z;
@@ -261,18 +271,25 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
         const int* sg = RASTER_SIGN[(first_raster + s) & 7];
         prof_mark(st);
         if (order == LSF_ORDER_GS) {
+            hipLaunchKernelGGL(k_copy_walls, bgrid, dim3(64), 0, st, A, B, nx, ny, nz, ctl);
             const int nplanes = (int)tl->off.size() - 1;
             for (int P = 0; P < nplanes; ++P) {
                 const int cnt = tl->off[P + 1] - tl->off[P];
                 if (cnt <= 0) continue;
-                if (strict)
-                    hipLaunchKernelGGL((k_reinit_gs_plane<GS_TA, true>), dim3(cnt), dim3(64), 0, st, A, B, d_phiS,
-                                       nx, ny, nz, sg[0], sg[1], sg[2], tl->d + tl->off[P], nTi, nTj, nTk, dx, h,
-                                       part, ctl);
-                else
-                    hipLaunchKernelGGL((k_reinit_gs_plane<GS_TA, false>), dim3(cnt), dim3(64), 0, st, A, B, d_phiS,
-                                       nx, ny, nz, sg[0], sg[1], sg[2], tl->d + tl->off[P], nTi, nTj, nTk, dx, h,
-                                       part, ctl);
+#define LSF_LAUNCH_QUAD(TA_, ST_)                                                                                  \
+    hipLaunchKernelGGL((k_reinit_gs_quad<TA_, ST_>), dim3(cnt), dim3(64), 0, st, A, B, d_phiS, nx, ny, nz, sg[0],   \
+                       sg[1], sg[2], tl->d + tl->off[P], nTi, nTj, nTk, dx, h, part, ctl)
+                const int ta = gs_ta();
+                if (strict) {
+                    if (ta == 8) LSF_LAUNCH_QUAD(8, true);
+                    else if (ta == 16) LSF_LAUNCH_QUAD(16, true);
+                    else LSF_LAUNCH_QUAD(32, true);
+                } else {
+                    if (ta == 8) LSF_LAUNCH_QUAD(8, false);
+                    else if (ta == 16) LSF_LAUNCH_QUAD(16, false);
+                    else LSF_LAUNCH_QUAD(32, false);
+                }
+#undef LSF_LAUNCH_QUAD
             }
         } else {
             if (strict)

@@ -245,6 +245,84 @@ __device__ __forceinline__ double cell_update(const double qx[7], const double q
 }
 
 // ---------------------------------------------------------------------------------------------
+// Per-axis pieces (used by the lane-per-axis exact-GS kernel, where the x, y and z derivatives of
+// one cell are computed by three lanes of a quad).  Same expressions as cell_update_* above.
+// ---------------------------------------------------------------------------------------------
+// one-sided derivatives along one axis: STRICT -> true values (a,b); FAST -> values * dx
+template <bool STRICT>
+__device__ __forceinline__ void axis_pair(const double q[7], bool weno_ok, bool yquirk, double dx, double floor2,
+                                          double& dm, double& dp)
+{
+    if constexpr (STRICT) {
+#pragma clang fp contract(off)
+        if (weno_ok) {
+            weno_axis_strict(q, dx, yquirk, dm, dp);
+        } else {
+            dm = (q[3] - q[2]) / dx; // subs.f90:657-662
+            dp = (q[4] - q[3]) / dx;
+        }
+    } else {
+        if (weno_ok) {
+            weno_axis_fast(q, floor2, yquirk, dm, dp);
+        } else {
+            dm = q[3] - q[2];
+            dp = q[4] - q[3];
+        }
+    }
+}
+
+// the Godunov term of one axis (gradX / gradY / gradZ of subs.f90:684-692)
+template <bool STRICT>
+__device__ __forceinline__ double axis_godunov(double phic, double dm, double dp)
+{
+    if constexpr (STRICT) {
+#pragma clang fp contract(off)
+        const double pa = fmax2(dm, 0.), pb = fmax2(dp, 0.), na = fmin2(dm, 0.), nb = fmin2(dp, 0.);
+        if (phic > 0.) return fmax2(pa * pa, nb * nb);
+        return fmax2(pb * pb, na * na);
+    } else {
+        const bool pos = phic > 0.;
+        const double ua = pos ? __builtin_fmax(dm, 0.) : __builtin_fmin(dm, 0.);
+        const double ub = pos ? __builtin_fmin(dp, 0.) : __builtin_fmax(dp, 0.);
+        return __builtin_fmax(ua * ua, ub * ub);
+    }
+}
+
+// 1/sqrt(t) from v_rsq_f64 + two Newton steps (FAST only)
+__device__ __forceinline__ double rsqrt_nr(double t)
+{
+    double y = __builtin_amdgcn_rsq(t);
+    const double hlf = 0.5 * t;
+    double e = __builtin_fma(-hlf * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-hlf * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+
+// gM, smeared sign and Euler step from the three axis terms (subs.f90:702, :169, :749-750)
+template <bool STRICT>
+__device__ __forceinline__ double finish_update(double phic, double gX, double gY, double gZ, double pS, double dx,
+                                                double inv_dx, double h)
+{
+    if constexpr (STRICT) {
+#pragma clang fp contract(off)
+        const double gM = __builtin_sqrt(gX + gY + gZ);
+        const double sgn = pS / __builtin_sqrt(pS * pS + dx * dx * gM);
+        const double k1 = sgn * (1. - gM);
+        return phic + h * k1;
+    } else {
+        const double S = gX + gY + gZ; // unscaled: true value * dx^2
+        const double y = rsqrt_nr(S);
+        double g = S * y;
+        g = __builtin_fma(__builtin_fma(-g, g, S), 0.5 * y, g);
+        const double gM = (S > 0. ? g : 0.) * inv_dx;
+        const double sgn = pS * rsqrt_nr(__builtin_fma(pS, pS, dx * dx * gM));
+        return __builtin_fma(h, sgn * (1. - gM), phic);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // min/max flow
 // ---------------------------------------------------------------------------------------------
 // secondDeriv order 2 (subs.f90:384-389) summed as minMax does (subs.f90:461): curv.
