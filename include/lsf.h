@@ -116,6 +116,20 @@ int lsf_narrowband(const double *phi, int32_t *phiNB, int32_t *phiSB, int nx, in
 int lsf_narrowband_device(const double *d_phi, int32_t *d_phiNB, int32_t *d_phiSB, int nx, int ny,
                           int nz, double dx, void *stream);
 
+/* ---- phi0: inside/outside initialisation (the step before the hot path) -------------------
+ * Replaces the centroid table + search loop of the main program, set3d.f90:196-268 (SURVEY.md section 8f
+ * rank 1): for every grid point within 3 cells of the surface bounding box, the nearest triangle centroid
+ * (first minimum), the sign of the triple product of its vertex vectors, smeared by phiSign(pS,dx,1);
+ * 1.0 elsewhere (set3d.f90:161).  surfX is the host's REAL surfX(nSurfNode,3), surfElem its
+ * INTEGER*4 surfElem(nSurfElem,3) (1-based), both Fortran-ordered HOST arrays; xLo/minX/maxX as computed at
+ * set3d.f90:94-157.  Bit-identical to the reference. */
+int lsf_phi0(double *phi, int nx, int ny, int nz, double dx, const double xLo[3], const double minX[3],
+             const double maxX[3], const double *surfX, int nSurfNode, const int32_t *surfElem,
+             int nSurfElem);
+int lsf_phi0_device(double *d_phi, int nx, int ny, int nz, double dx, const double xLo[3],
+                    const double minX[3], const double maxX[3], const double *surfX, int nSurfNode,
+                    const int32_t *surfElem, int nSurfElem, void *stream);
+
 /* ---- block-decomposed building blocks (multi-GPU Jacobi; one process per GPU) -------------
  * A rank holds a box of the global field: local extents (lx,ly,lz), whose element (0,0,0) is the
  * global point (gx0,gy0,gz0); global extents are (nx+1,ny+1,nz+1).  The box includes ghost layers

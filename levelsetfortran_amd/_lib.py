@@ -57,6 +57,10 @@ SIGNATURES = {
                                   c_double, c_int, POINTER(c_int), c_void_p, c_int, c_void_p]),
     "lsf_narrowband": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double]),
     "lsf_narrowband_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p]),
+    "lsf_phi0": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                         c_void_p, c_int]),
+    "lsf_phi0_device": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                c_void_p, c_int, c_void_p]),
     "lsf_jacobi_sweep_box": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3,
                                      c_double, c_double, c_int, c_void_p, c_void_p]),
     "lsf_bc_box": (c_int, [c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_double, c_void_p,

@@ -57,7 +57,7 @@ struct TileList {
     std::vector<int> off; // plane offsets, size nplanes+1
 };
 
-enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_NSLOTS };
+enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_NSLOTS };
 
 struct Ctx {
     Buf slot[S_NSLOTS];
@@ -602,6 +602,75 @@ int lsf_narrowband(const double* phi, int32_t* phiNB, int32_t* phiSB, int nx, in
         return rc;
     HIPCHK(hipMemcpy(phiNB, c.slot[S_HNB].p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(phiSB, c.slot[S_HSB].p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return LSF_OK;
+}
+
+int lsf_phi0_device(double* d_phi, int nx, int ny, int nz, double dx, const double xLo[3], const double minX[3],
+                    const double maxX[3], const double* surfX, int nSurfNode, const int32_t* surfElem, int nSurfElem,
+                    void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = check_dims(nx, ny, nz))) return rc;
+    if (!d_phi || !xLo || !minX || !maxX || !surfX || !surfElem) return fail(LSF_ERR_INVALID, "NULL pointer");
+    if (nSurfNode < 1 || nSurfElem < 1) return fail(LSF_ERR_INVALID, "empty surface");
+    hipStream_t st = (hipStream_t)stream;
+    // search box, set3d.f90:180-186 (same expressions, host side)
+    const int im = (int)std::floor((minX[0] - xLo[0]) / dx) - 3, ip = (int)std::floor((maxX[0] - xLo[0]) / dx) + 3;
+    const int jm = (int)std::floor((minX[1] - xLo[1]) / dx) - 3, jp = (int)std::floor((maxX[1] - xLo[1]) / dx) + 3;
+    const int km = (int)std::floor((minX[2] - xLo[2]) / dx) - 3, kp = (int)std::floor((maxX[2] - xLo[2]) / dx) + 3;
+    if (im < 0 || jm < 0 || km < 0 || ip > nx || jp > ny || kp > nz)
+        return fail(LSF_ERR_INVALID, "search box leaves the grid (the reference would write outside phi)");
+    // centroids (set3d.f90:199-215) and per-triangle vertex coordinates; surfX is (nSurfNode,3) and surfElem
+    // (nSurfElem,3), both Fortran-ordered, connectivity 1-based
+    std::vector<double> cen((size_t)nSurfElem * 3), vtx((size_t)nSurfElem * 9);
+    for (int n = 0; n < nSurfElem; ++n) {
+        int id[3];
+        for (int v = 0; v < 3; ++v) {
+            id[v] = surfElem[(size_t)n + (size_t)nSurfElem * v];
+            if (id[v] < 1 || id[v] > nSurfNode) return fail(LSF_ERR_INVALID, "surfElem index out of range");
+        }
+        for (int c = 0; c < 3; ++c) {
+            const double p1 = surfX[(size_t)(id[0] - 1) + (size_t)nSurfNode * c];
+            const double p2 = surfX[(size_t)(id[1] - 1) + (size_t)nSurfNode * c];
+            const double p3 = surfX[(size_t)(id[2] - 1) + (size_t)nSurfNode * c];
+            cen[(size_t)n * 3 + c] = (p1 + p2 + p3) / 3.;
+            vtx[(size_t)n * 9 + c] = p1;
+            vtx[(size_t)n * 9 + 3 + c] = p2;
+            vtx[(size_t)n * 9 + 6 + c] = p3;
+        }
+    }
+    Ctx& c = ctx();
+    if ((rc = ws(c.slot[S_CEN], cen.size() * sizeof(double)))) return rc;
+    if ((rc = ws(c.slot[S_VTX], vtx.size() * sizeof(double)))) return rc;
+    HIPCHK(hipMemcpyAsync(c.slot[S_CEN].p, cen.data(), cen.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c.slot[S_VTX].p, vtx.data(), vtx.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    const long n = (long)(nx + 1) * (ny + 1) * (nz + 1);
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, st, d_phi, n,
+                       1.0); // phi = 1., set3d.f90:161
+    const long npts = (long)(ip - im + 1) * (jp - jm + 1) * (kp - km + 1);
+    hipLaunchKernelGGL(k_phi0, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, d_phi, nx, ny, im, ip, jm, jp,
+                       km, kp, dx, xLo[0], xLo[1], xLo[2], (const double*)c.slot[S_CEN].p,
+                       (const double*)c.slot[S_VTX].p, nSurfElem);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st)); // cen/vtx are host temporaries
+    return LSF_OK;
+}
+
+int lsf_phi0(double* phi, int nx, int ny, int nz, double dx, const double xLo[3], const double minX[3],
+             const double maxX[3], const double* surfX, int nSurfNode, const int32_t* surfElem, int nSurfElem)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = check_dims(nx, ny, nz))) return rc;
+    if (!phi) return fail(LSF_ERR_INVALID, "phi is NULL");
+    Ctx& c = ctx();
+    const size_t bytes = (size_t)(nx + 1) * (ny + 1) * (nz + 1) * sizeof(double);
+    if ((rc = ws(c.slot[S_HPHI], bytes))) return rc;
+    rc = lsf_phi0_device((double*)c.slot[S_HPHI].p, nx, ny, nz, dx, xLo, minX, maxX, surfX, nSurfNode, surfElem,
+                         nSurfElem, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(phi, c.slot[S_HPHI].p, bytes, hipMemcpyDeviceToHost));
     return LSF_OK;
 }
 

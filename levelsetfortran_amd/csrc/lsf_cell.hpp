@@ -137,14 +137,15 @@ __device__ __forceinline__ double rcp_nr(double x)
     return r;
 }
 
-// smoothness indicator 13 (x-y)^2 + 3 t^2 with t supplied by the caller
+// smoothness indicator (13 (x-y)^2 + 3 t^2) / 13 with t supplied by the caller.  Only ratios of
+// (eps + IS) enter the weights, so the common factor 1/13 is folded into the epsilon constants.
 __device__ __forceinline__ double is_form(double diff, double t)
 {
-    return __builtin_fma(13.0 * diff, diff, 3.0 * (t * t));
+    return __builtin_fma(diff, diff, (3.0 / 13.0) * (t * t));
 }
 
 // One axis, unscaled: returns dm*dx and dp*dx (the caller multiplies by 1/dx once).
-// floor2 = 1e-99 * dx^2 (the reference's epsilon floor in unscaled units).
+// floor2 = 1e-99 * dx^2 / 13 (the reference's epsilon floor in unscaled units, /13 like the IS).
 __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2, bool yquirk, double& dm,
                                                double& dp)
 {
@@ -161,11 +162,14 @@ __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2,
     const double IS2p = is_form(cp - bm, __builtin_fma(3.0, cp, -bm));
     const double IS2m = is_form(cp - bp, __builtin_fma(3.0, cp, -bp));
 
-    const double s1 = d1 * d1, s2 = d2 * d2, s3 = d3 * d3, s4 = d4 * d4;
-    const double mid = __builtin_fmax(__builtin_fmax(s1, s2), __builtin_fmax(s3, s4));
-    const double s5 = yquirk ? 0.0 : d5 * d5;
-    const double epsp = __builtin_fma(1.E-6, __builtin_fmax(mid, s5), floor2);
-    const double epsm = __builtin_fma(1.E-6, __builtin_fmax(mid, d0 * d0), floor2);
+    // eps = 1e-6 max(p^2) + 1e-99 (subs.f90:533-534), in unscaled units and divided by 13 like the IS;
+    // max of squares = square of the max magnitude (|x| is a free source modifier)
+    const double mid = __builtin_fmax(__builtin_fmax(__builtin_fabs(d1), __builtin_fabs(d2)),
+                                      __builtin_fmax(__builtin_fabs(d3), __builtin_fabs(d4)));
+    const double mp = yquirk ? mid : __builtin_fmax(mid, __builtin_fabs(d5));
+    const double mm = __builtin_fmax(mid, __builtin_fabs(d0));
+    const double epsp = __builtin_fma((1.E-6 / 13.0) * mp, mp, floor2);
+    const double epsm = __builtin_fma((1.E-6 / 13.0) * mm, mm, floor2);
 
     // alpha_k = c_k / q_k^2, w_k = alpha_k / sum  ->  w0 = (q1 q2)^2 / D, w2 = 3 (q0 q1)^2 / D,
     // D = (q1 q2)^2 + 6 (q0 q2)^2 + 3 (q0 q1)^2 : one reciprocal per side
@@ -199,38 +203,26 @@ __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2,
     dp = cen + PWp;
 }
 
+template <bool STRICT>
+__device__ __forceinline__ void axis_pair(const double q[7], bool weno_ok, bool yquirk, double dx, double floor2,
+                                          double& dm, double& dp);
+template <bool STRICT>
+__device__ __forceinline__ double axis_godunov(double phic, double dm, double dp);
+template <bool STRICT>
+__device__ __forceinline__ double finish_update(double phic, double gX, double gY, double gZ, double pS, double dx,
+                                                double inv_dx, double h);
+
 __device__ __forceinline__ double cell_update_fast(const double qx[7], const double qy[7],
                                                    const double qz[7], bool weno_ok, double pS, double dx,
                                                    double inv_dx, double floor2, double h)
 {
     double a, b, c, d, e, f; // unscaled one-sided differences (true value * dx)
+    axis_pair<false>(qx, weno_ok, false, dx, floor2, a, b);
+    axis_pair<false>(qy, weno_ok, true, dx, floor2, c, d);
+    axis_pair<false>(qz, weno_ok, false, dx, floor2, e, f);
     const double phic = qx[3];
-    if (weno_ok) {
-        weno_axis_fast(qx, floor2, false, a, b);
-        weno_axis_fast(qy, floor2, true, c, d);
-        weno_axis_fast(qz, floor2, false, e, f);
-    } else {
-        a = phic - qx[2];
-        b = qx[4] - phic;
-        c = phic - qy[2];
-        d = qy[4] - phic;
-        e = phic - qz[2];
-        f = qz[4] - phic;
-    }
-    // Godunov (subs.f90:667-692): phi>0 : max(max(a,0)^2, min(b,0)^2) ; else swap roles
-    const bool pos = phic > 0.;
-    const double ua = pos ? __builtin_fmax(a, 0.) : __builtin_fmin(a, 0.);
-    const double ub = pos ? __builtin_fmin(b, 0.) : __builtin_fmax(b, 0.);
-    const double uc = pos ? __builtin_fmax(c, 0.) : __builtin_fmin(c, 0.);
-    const double ud = pos ? __builtin_fmin(d, 0.) : __builtin_fmax(d, 0.);
-    const double ue = pos ? __builtin_fmax(e, 0.) : __builtin_fmin(e, 0.);
-    const double uf = pos ? __builtin_fmin(f, 0.) : __builtin_fmax(f, 0.);
-    const double gX = __builtin_fmax(ua * ua, ub * ub);
-    const double gY = __builtin_fmax(uc * uc, ud * ud);
-    const double gZ = __builtin_fmax(ue * ue, uf * uf);
-    const double gM = __builtin_sqrt(gX + gY + gZ) * inv_dx;
-    const double sgn = pS / __builtin_sqrt(__builtin_fma(pS, pS, dx * dx * gM));
-    return __builtin_fma(h, sgn * (1. - gM), phic);
+    return finish_update<false>(phic, axis_godunov<false>(phic, a, b), axis_godunov<false>(phic, c, d),
+                                axis_godunov<false>(phic, e, f), pS, dx, inv_dx, h);
 }
 
 template <bool STRICT>

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) void k_reinit_gs_plane(const double* __restrict
     const int z = sk > 0 ? c : nk - 1 - c;
     const int gj = j_lo + y, gk = k_lo + z;
     const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
-    const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx;
+    const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
     double acc = 0.0;
     const int nsteps = ni + nj + nk - 2;
 
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64) void k_reinit_gs_quad(const double* __restrict_
         off[m] = !in_y ? o_yh : (!in_z ? o_zh : o_core);
     }
     const int ps_row = T::CORE + T::YH + T::ZH + (zc * 4 + yc) * TA;
-    const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx;
+    const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
     double acc = 0.0;
     const int nsteps = ni + nj + nk - 2;
 
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY) void k_reinit_jacobi(const double* 
     if (li < hi0 && lj < hi1) {
         const int gi = li + bx.gx0, gj = lj + bx.gy0;
         const bool ij_weno = gi > 3 && gi < bx.nx - 4 && gj > 3 && gj < bx.ny - 4;
-        const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx;
+        const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
         const long col = li + sx * lj;
         double qz[7];
         // window holds k-3..k+3 of the current cell; clamp reads to the box (values outside the
@@ -720,6 +720,65 @@ __global__ __launch_bounds__(64) void k_minmax_gs_plane(const double* __restrict
     }
     acc = wave_sum(acc);
     if (lane == 0) partials[ti + nTi * (tj + (long)nTj * tk)] = acc;
+}
+
+// =============================================================================================
+// phi0: inside/outside initialisation, set3d.f90:196-268 (the step just before the hot path;
+// SURVEY.md section 8f rank 1).  One thread per grid point of the search box [im,ip]x[jm,jp]x[km,kp]:
+// brute-force nearest triangle CENTROID (first minimum wins, `dis < minD`, set3d.f90:232), sign of the
+// triple product of the three vertex vectors (set3d.f90:242-258), smeared with phiSign(pS,dx,gM=1)
+// (set3d.f90:260-264).  Centroids are staged through LDS in chunks; every operation is written as in
+// the reference and contraction is off, so the result is bit-identical.
+// cen: [nElem][3] centroids computed on the host exactly as set3d.f90:212-214 does.
+// =============================================================================================
+constexpr int PHI0_CHUNK = 1024;
+
+__global__ __launch_bounds__(256) void k_phi0(double* __restrict__ phi, int nx, int ny, int im, int ip, int jm,
+                                              int jp, int km, int kp, double dx, double xlo0, double xlo1,
+                                              double xlo2, const double* __restrict__ cen,
+                                              const double* __restrict__ vtx, int nElem)
+{
+#pragma clang fp contract(off)
+    __shared__ double sc[PHI0_CHUNK * 3];
+    const int ei = ip - im + 1, ej = jp - jm + 1, ek = kp - km + 1;
+    const long npts = (long)ei * ej * ek;
+    const long t = blockIdx.x * 256L + threadIdx.x;
+    const bool live = t < npts;
+    const long tt = live ? t : 0;
+    const int i = im + (int)(tt % ei), j = jm + (int)((tt / ei) % ej), k = km + (int)(tt / ((long)ei * ej));
+    const double gX = xlo0 + i * dx, gY = xlo1 + j * dx, gZ = xlo2 + k * dx; // gridX, set3d.f90:168-170
+    double minD = 100000.;
+    int fN = 0;
+    for (int base = 0; base < nElem; base += PHI0_CHUNK) {
+        const int cnt = min(PHI0_CHUNK, nElem - base);
+        __syncthreads();
+        for (int q = threadIdx.x; q < cnt * 3; q += 256) sc[q] = cen[(long)base * 3 + q];
+        __syncthreads();
+        for (int n = 0; n < cnt; ++n) {
+            const double pX = sc[3 * n], pY = sc[3 * n + 1], pZ = sc[3 * n + 2];
+            const double dis = __builtin_sqrt((pX - gX) * (pX - gX) + (pY - gY) * (pY - gY) + (pZ - gZ) * (pZ - gZ));
+            if (dis < minD) {
+                minD = dis;
+                fN = base + n;
+            }
+        }
+    }
+    if (!live) return;
+    const double* v = vtx + (long)fN * 9; // the three vertices of triangle fN: surfX(n1,:), surfX(n2,:), surfX(n3,:)
+    const double A1 = v[0] - gX, A2 = v[1] - gY, A3 = v[2] - gZ;
+    const double B1 = v[3] - gX, B2 = v[4] - gY, B3 = v[5] - gZ;
+    const double C1 = v[6] - gX, C2 = v[7] - gY, C3 = v[8] - gZ;
+    const double pSx = A2 * B3 - A3 * B2;
+    const double pSy = -(A1 * B3 - B1 * A3);
+    const double pSz = A1 * B2 - B1 * A2;
+    const double pS = -(pSx * C1 + pSy * C2 + pSz * C3);
+    const double gM = 1.;
+    phi[i + (long)(nx + 1) * (j + (long)(ny + 1) * k)] = pS / __builtin_sqrt(pS * pS + dx * dx * gM); // subs.f90:169
+}
+
+__global__ __launch_bounds__(256) void k_fill(double* __restrict__ p, long n, double v)
+{
+    for (long q = blockIdx.x * 256L + threadIdx.x; q < n; q += 256L * gridDim.x) p[q] = v;
 }
 
 // =============================================================================================

@@ -8,6 +8,8 @@
 !   reinit(phi,gradPhi,gradPhiMag,nx,ny,nz,iter,dx,h)   replaces subs.f90:717-931
 !   narrowBand(nx,ny,nz,dx,phi,phiNB,phiSB)             replaces subs.f90:178-207
 !   minmaxFlow(phi,phiNB,phiSB,nx,ny,nz,iter,dx,h1)     replaces the loop set3d.f90:394-462
+!   phi0Init(phi,nx,ny,nz,dx,xLo,xMin,xMax,surfX,nSurfNode,surfElem,nSurfElem)
+!                                                        replaces the loop set3d.f90:218-268
 !
 ! and reproduces what the reference prints around them (subs.f90:916,923,929 and
 ! set3d.f90:449,456,463) and its STOP on a NaN residual (subs.f90:926, set3d.f90:458).
@@ -25,7 +27,7 @@ MODULE lsf_hip
 USE, INTRINSIC :: iso_c_binding
 IMPLICIT NONE
 PRIVATE
-PUBLIC :: reinit, narrowBand, minmaxFlow, lsf_env_real, lsf_env_int
+PUBLIC :: reinit, narrowBand, minmaxFlow, phi0Init, lsf_env_real, lsf_env_int
 
 INTEGER(c_int), PARAMETER :: LSF_OK = 0, LSF_ERR_NAN = 1
 INTEGER(c_int), PARAMETER :: LSF_ORDER_JACOBI = 1, LSF_ARITH_STRICT = 256
@@ -61,6 +63,16 @@ INTERFACE
       REAL(c_double), VALUE :: dx
       INTEGER(c_int) :: rc
    END FUNCTION lsf_narrowband
+   FUNCTION lsf_phi0(phi,nx,ny,nz,dx,xLo,xMin,xMax,surfX,nSurfNode,surfElem,nSurfElem) &
+            BIND(C,NAME='lsf_phi0') RESULT(rc)
+      IMPORT :: c_int, c_double
+      REAL(c_double), INTENT(INOUT) :: phi(*)
+      INTEGER(c_int), VALUE :: nx,ny,nz,nSurfNode,nSurfElem
+      REAL(c_double), VALUE :: dx
+      REAL(c_double), INTENT(IN) :: xLo(3),xMin(3),xMax(3),surfX(*)
+      INTEGER(c_int), INTENT(IN) :: surfElem(*)
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_phi0
    FUNCTION lsf_last_error() BIND(C,NAME='lsf_last_error') RESULT(p)
       IMPORT :: c_ptr
       TYPE(c_ptr) :: p
@@ -189,6 +201,25 @@ PRINT*
 DEALLOCATE(trace)
 
 END SUBROUTINE minmaxFlow
+
+!*************************************************************************************!
+! Inside/outside initialisation: the search loop of set3d.f90:218-268 as one call
+! (SURVEY.md section 8f rank 1).  phi must hold 1. on entry like at set3d.f90:161.
+!*************************************************************************************!
+SUBROUTINE phi0Init(phi,nx,ny,nz,dx,xLo,xMin,xMax,surfX,nSurfNode,surfElem,nSurfElem)
+
+INTEGER,INTENT(IN) :: nx,ny,nz
+INTEGER*4,INTENT(IN) :: nSurfNode,nSurfElem
+REAL,INTENT(IN) :: dx,xLo(3),xMin(3),xMax(3)
+REAL,DIMENSION(0:nx,0:ny,0:nz),INTENT(INOUT) :: phi
+REAL,INTENT(IN) :: surfX(nSurfNode,3)
+INTEGER*4,INTENT(IN) :: surfElem(nSurfElem,3)
+INTEGER(c_int) :: rc
+
+rc = lsf_phi0(phi,nx,ny,nz,dx,xLo,xMin,xMax,surfX,nSurfNode,surfElem,nSurfElem)
+IF (rc /= LSF_OK) CALL lsf_fail('lsf_phi0',rc)
+
+END SUBROUTINE phi0Init
 
 !*************************************************************************************!
 ! Run-time overrides of the host's hard-coded parameters (set3d.f90:140,148,298,390,576)

@@ -28,7 +28,7 @@ import numpy as np
 from . import _lib
 from ._lib import LSF_ARITH_FAST, LSF_ARITH_STRICT, LSF_ORDER_GS, LSF_ORDER_JACOBI, LsfError, LsfNaNError
 
-__all__ = ["reinit", "narrowBand", "minmaxFlow", "SweepReport", "mode_word", "LsfError", "LsfNaNError"]
+__all__ = ["reinit", "narrowBand", "minmaxFlow", "phi0Init", "SweepReport", "mode_word", "LsfError", "LsfNaNError"]
 
 REINIT_TOL = 1.0e-5  # subs.f90:915
 MINMAX_TOL = 1.0e-7  # set3d.f90:448
@@ -196,3 +196,27 @@ def minmaxFlow(phi, phiNB, phiSB, nx: int, ny: int, nz: int, iter: int, dx: floa
         sys.stdout.flush()
     _lib.check(rc)
     return rep
+
+
+def phi0Init(phi, nx: int, ny: int, nz: int, dx: float, xLo, minX, maxX, surfX, surfElem) -> None:
+    """Inside/outside initialisation of the main program (set3d.f90:196-268) as one call.
+
+    phi (numpy F-ordered or torch CUDA, see module docstring) receives sgn in (-1,1) within 3 cells of the
+    surface bounding box and 1.0 elsewhere.  surfX: (nSurfNode,3) float64, surfElem: (nSurfElem,3) int32,
+    1-based, as stlRead returns them (subs.f90:17-121); xLo/minX/maxX as the host computes them
+    (set3d.f90:94-157).  Bit-identical to the reference.
+    """
+    lib = _lib.load()
+    sX = np.asfortranarray(surfX, dtype=np.float64)
+    sE = np.asfortranarray(surfElem, dtype=np.int32)
+    lo, mn, mx = (np.ascontiguousarray(v, dtype=np.float64) for v in (xLo, minX, maxX))
+    args = (nx, ny, nz, float(dx), lo.ctypes.data, mn.ctypes.data, mx.ctypes.data, sX.ctypes.data, sX.shape[0],
+            sE.ctypes.data, sE.shape[0])
+    if _is_torch(phi):
+        import torch
+
+        st = _stream_and_device(phi)
+        rc = lib.lsf_phi0_device(_dev_ptr(phi, torch.float64, nx, ny, nz, "phi"), *args, st)
+    else:
+        rc = lib.lsf_phi0(_host_ptr(phi, np.float64, nx, ny, nz, "phi"), *args)
+    _lib.check(rc)

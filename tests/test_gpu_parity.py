@@ -247,3 +247,26 @@ def test_zero_iterations_and_errors(lsf):
     assert rep.count == 0 and np.all(phi == 1.0)
     with pytest.raises(lsf.LsfError):
         lsf.reinit(np.ones((2, 2, 2), order="F"), None, None, 1, 1, 1, 0, 0.1, 0.01)  # nx must be >= 2
+
+
+# ---------------------------------------------------------------------------------- phi0
+def test_phi0_matches_reference(lsf, cube40, twocube):
+    """set3d.f90:196-268 on the GPU: bit-identical to the phi0 the reference's main program computed."""
+    import os
+    import time
+
+    import stl_io
+    from conftest import GOLDEN
+
+    s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    for tag, gold in (("cube40", cube40), ("twocube10", twocube)):
+        X, E = s[tag + "_surfX"].astype(np.float64), s[tag + "_surfElem"]
+        n, xLo, mn, mx = stl_io.grid_from_surface(X)
+        phi = np.ones(tuple(v + 1 for v in n), order="F")
+        t0 = time.perf_counter()
+        lsf.phi0Init(phi, n[0], n[1], n[2], 0.05, xLo, mn, mx, X, E)
+        print(tag, "phi0 on GPU", time.perf_counter() - t0, "s")
+        assert np.array_equal(phi, gold["phi0"])
+        t = _dev(np.zeros_like(phi))
+        lsf.phi0Init(t, n[0], n[1], n[2], 0.05, xLo, mn, mx, X, E)
+        assert np.array_equal(_host(t, phi.shape), gold["phi0"])
