@@ -288,6 +288,38 @@ def main() -> None:
                     else "exact Gauss-Seidel ordering of the reference",
         }
 
+    if world == 1 and not args.no_secondary:
+        # min/max-flow sweep (set3d.f90:394-462) on the same grid: 16 B per grid point per iteration
+        # (SURVEY.md 8d); input = exact two-sphere distance so that the narrow band is a thin shell
+        del phi, phi0, phiS
+        x, y, z, dxm = fields.grid_axes((N, N, N))
+        dmin = None
+        for c in ((-0.6, 0.0, 0.0), (0.6, 0.0, 0.0)):
+            r = np.sqrt((x[:, None, None] - c[0]) ** 2 + (y[None, :, None] - c[1]) ** 2 + (z[None, None, :] - c[2]) ** 2) - 0.5
+            dmin = r if dmin is None else np.minimum(dmin, r)
+        sdf = torch.from_numpy(np.asfortranarray(dmin).reshape(-1, order="F")).to(dev)
+        del dmin, r
+        mm = {}
+        KM = 10
+        for order_ in ("gs", "jacobi"):
+            f = sdf.clone()
+            nb = torch.zeros(f.numel(), dtype=torch.int32, device=dev)
+            sb = torch.zeros_like(nb)
+            lsf.narrowBand(nx, ny, nz, dxm, f, nb, sb)
+            lsf.minmaxFlow(f, nb, sb, nx, ny, nz, 2, dxm, 0.1 * h, tol=0.0, order=order_)
+            barrier()
+            t0 = time.perf_counter()
+            lsf.minmaxFlow(f, nb, sb, nx, ny, nz, KM, dxm, 0.1 * h, tol=0.0, order=order_)
+            barrier()
+            dtm = time.perf_counter() - t0
+            mm[order_] = {"ms_per_iteration": dtm / KM * 1e3, "points_per_s": float(N) ** 3 * KM / dtm,
+                          "algorithmic_GBps": 16.0 * float(N) ** 3 * KM / dtm / 1e9,
+                          "frac_of_hbm_peak": 16.0 * float(N) ** 3 * KM / dtm / 1e9 / HBM_PEAK_GBS}
+            del f, nb, sb
+        mm["note"] = ("min/max-flow iteration at the same size, narrow band = |phi| < 4.1 dx of an exact two-sphere distance; "
+                      "gs = the reference's (+,+,+) raster order reproduced exactly, jacobi = double-buffered")
+        out["minmax"] = mm
+
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N)

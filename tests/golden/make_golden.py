@@ -84,7 +84,8 @@ def ref_reinit_worker(inp, outp, nx, ny, nz, it, dx, h):
     def go():
         f(phi.ctypes.data, gp.ctypes.data, gm.ctypes.data, *[ctypes.addressof(v) for v in keep])
 
-    threading.stack_size(1 << 30)
+    # reinit keeps two automatic arrays (phiS, phiN) on the stack (subs.f90:724)
+    threading.stack_size(int(3 * phi.nbytes) + (64 << 20))
     t = threading.Thread(target=go)
     t.start()
     t.join()

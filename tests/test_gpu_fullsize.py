@@ -94,3 +94,36 @@ def test_jacobi_centre_block_matches_oracle(big, oracle):
     # inside the block, cells 4+3s..w-5-3s from the block walls use the WENO branch with true data
     a, b = 4 + 3 * s + 1, w - 5 - 3 * s - 1
     assert np.array_equal(got[lo + a:lo + b, lo + a:lo + b, lo + a:lo + b], blk[a:b, a:b, a:b])
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_full_size_field_equals_the_reference_itself(n):
+    """BASELINE sizes against the reference's own reinit (amdflang build, called through ctypes in the build
+    container by tests/golden/make_golden_big.py): SHA-256 of the whole field after 8 sweeps at 256^3 (all
+    8 raster directions) and 2 sweeps at 512^3 must match bit for bit."""
+    import hashlib
+    import os
+
+    import torch
+
+    import levelsetfortran_amd as lsf
+    from conftest import GOLDEN
+    from levelsetfortran_amd import fields
+
+    path = os.path.join(GOLDEN, "synth_big.npz")
+    if not os.path.exists(path):
+        pytest.skip("synth_big.npz not generated")
+    g = np.load(path)
+    sweeps = int(g[f"n{n}_sweeps"])
+    phi0, dx = fields.two_sphere_phi0((n, n, n))
+    h = fields.reinit_step(dx)
+    assert dx == float(g[f"n{n}_dx"]) and h == float(g[f"n{n}_h"])
+    t = torch.from_numpy(phi0.reshape(-1, order="F")).cuda()
+    del phi0
+    rep = lsf.reinit(t, None, None, n - 1, n - 1, n - 1, sweeps - 1, dx, h, arith="strict")
+    got = t.cpu().numpy()
+    assert rep.count == sweeps
+    assert hashlib.sha256(got.tobytes()).hexdigest() == str(g[f"n{n}_sha"])
+    assert np.array_equal(got.reshape((n, n, n), order="F")[::16, ::16, ::16], g[f"n{n}_sample"])
+    # the reference sums 1.3e8 squares sequentially (rounding ~ n*eps ~ 1e-8); the device sum is a tree
+    assert np.allclose(rep.rms, g[f"n{n}_rms"], rtol=1e-7, atol=0)
