@@ -57,7 +57,7 @@ struct TileList {
     std::vector<int> off; // plane offsets, size nplanes+1
 };
 
-enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_NSLOTS };
+enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_NSLOTS };
 
 struct Ctx {
     Buf slot[S_NSLOTS];
@@ -336,9 +336,11 @@ int narrowband_core(const double* d_phi, int32_t* d_nb, int32_t* d_sb, size_t n,
     return LSF_OK;
 }
 
-int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int nz, int iter, double dx,
-                double h1, double tol, int mode, int* iters_done, double* rms_trace, int trace_cap,
-                hipStream_t st)
+constexpr int MM_MAX_FIX = 8; // fix passes per min/max iteration before the fixed point counts as uncertified
+
+int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int nz, int iter, double dx,
+                     double h1, double tol, int mode, int* iters_done, double* rms_trace, int trace_cap,
+                     hipStream_t st, bool use_tiles, bool* inexact)
 {
     int rc = check_dims(nx, ny, nz);
     if (rc) return rc;
@@ -358,7 +360,19 @@ int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int
     TileList* tl = nullptr;
     int nTi = 0, nTj = 0, nTk = 0, jblocks = 0;
     long n_part;
-    if (order == LSF_ORDER_GS) {
+    const bool fixed_point = order == LSF_ORDER_GS && !use_tiles;
+    const long fp_blocks = (long)((n + MM_CH - 1) / MM_CH);
+    int *bflag = nullptr, *chg = nullptr;
+    double* part2 = nullptr;
+    if (fixed_point) {
+        n_part = fp_blocks;
+        if ((rc = ws(c.slot[S_BFLAG], (size_t)fp_blocks * sizeof(int)))) return rc;
+        if ((rc = ws(c.slot[S_CHG], 64))) return rc;
+        if ((rc = ws(c.slot[S_PART2], 256 * sizeof(double)))) return rc;
+        bflag = (int*)c.slot[S_BFLAG].p;
+        chg = (int*)c.slot[S_CHG].p;
+        part2 = (double*)c.slot[S_PART2].p;
+    } else if (order == LSF_ORDER_GS) {
         nTi = cdiv(nx + 1, MM_TA), nTj = cdiv(ny + 1, 8), nTk = cdiv(nz + 1, 8);
         if ((rc = get_tiles(nTi, nTj, nTk, &tl))) return rc;
         n_part = (long)nTi * nTj * nTk;
@@ -371,12 +385,25 @@ int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int
     const double den = rms_denominator(nx, ny, nz);
 
     double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
-    int host_ctl[3] = {0, 0, 0};
+    int host_ctl[4] = {0, 0, 0, 0};
     for (int it = 0; it < iter; ++it) { // DO n = 1,iter (set3d.f90:394)
         const double* A = bufs[it & 1];
         double* B = bufs[(it + 1) & 1];
         const int32_t* mask = it == 0 ? d_nb : nullptr;
-        if (order == LSF_ORDER_GS) {
+        if (fixed_point) {
+            HIPCHK(hipMemsetAsync(chg, 0, 64, st));
+            const dim3 g((unsigned)fp_blocks), gs((unsigned)std::min<long>(fp_blocks, 4096)), b(256);
+            hipLaunchKernelGGL((k_minmax_fp<0>), g, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, fp_blocks,
+                               (const int*)nullptr, (int*)nullptr, part, ctl);
+            for (int f = 0; f < MM_MAX_FIX; ++f)
+                hipLaunchKernelGGL((k_minmax_fp<1>), gs, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, fp_blocks,
+                                   f == 0 ? (const int*)nullptr : (const int*)(chg + f - 1), chg + f, part, ctl);
+            hipLaunchKernelGGL((k_minmax_fp<2>), gs, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, fp_blocks,
+                               (const int*)(chg + MM_MAX_FIX - 1), (int*)nullptr, part, ctl);
+            hipLaunchKernelGGL(k_reduce_slices, dim3(256), dim3(256), 0, st, (const double*)part, fp_blocks, part2);
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, (const double*)part2, 256L, den, tol, d_trace,
+                               std::max(iter, 1), ctl);
+        } else if (order == LSF_ORDER_GS) {
             const int nplanes = (int)tl->off.size() - 1;
             for (int P = 0; P < nplanes; ++P) {
                 const int cnt = tl->off[P + 1] - tl->off[P];
@@ -388,17 +415,20 @@ int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int
             hipLaunchKernelGGL(k_minmax_jacobi, dim3(jblocks), dim3(256), 0, st, A, B, mask, nx, ny, nz, dx, h1, part,
                                ctl);
         }
-        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, n_part, den, tol, d_trace, std::max(iter, 1),
-                           ctl);
+        if (!fixed_point)
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, n_part, den, tol, d_trace, std::max(iter, 1),
+                               ctl);
         if ((it + 1) % CHECK_EVERY == 0 && it + 1 < iter) {
             HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            if (host_ctl[0]) break;
+            if (host_ctl[0] || host_ctl[3]) break;
         }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (inexact) *inexact = host_ctl[3] != 0;
+    if (host_ctl[3]) return LSF_OK; // caller restores the input and reruns with the tile wavefront
     const int nit = host_ctl[1];
     const bool stopped_early = host_ctl[0] != 0; // converged or NaN: EXIT/STOP before narrowBand
     // masks the host would hold now (set3d.f90:448-460)
@@ -417,6 +447,39 @@ int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int
     if (iters_done) *iters_done = nit;
     if (host_ctl[2]) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, set3d.f90:458)");
     return LSF_OK;
+}
+
+// Exact ordering: fixed-point passes (fast); if a fixed point is ever not certified within MM_MAX_FIX passes
+// (never observed), restore the input and redo the call with the tile-hyperplane wavefront.
+int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int nz, int iter, double dx,
+                double h1, double tol, int mode, int* iters_done, double* rms_trace, int trace_cap,
+                hipStream_t st)
+{
+    const char* e = getenv("LSF_MINMAX_TILES");
+    const bool force_tiles = e && atoi(e) != 0;
+    if ((mode & LSF_ORDER_MASK) != LSF_ORDER_GS || force_tiles || !d_phi || !d_nb || !d_sb || iter <= 0 ||
+        check_dims(nx, ny, nz))
+        return minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace,
+                                trace_cap, st, true, nullptr);
+    Ctx& c = ctx();
+    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    int rc = ws(c.slot[S_BACKUP], n * (sizeof(double) + 2 * sizeof(int32_t)));
+    if (rc) return rc;
+    char* bk = (char*)c.slot[S_BACKUP].p;
+    HIPCHK(hipMemcpyAsync(bk, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(bk + n * sizeof(double), d_nb, n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(bk + n * (sizeof(double) + sizeof(int32_t)), d_sb, n * sizeof(int32_t),
+                          hipMemcpyDeviceToDevice, st));
+    bool inexact = false;
+    rc = minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap, st,
+                          false, &inexact);
+    if (rc != LSF_OK || !inexact) return rc;
+    HIPCHK(hipMemcpyAsync(d_phi, bk, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_nb, bk + n * sizeof(double), n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_sb, bk + n * (sizeof(double) + sizeof(int32_t)), n * sizeof(int32_t),
+                          hipMemcpyDeviceToDevice, st));
+    return minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap,
+                            st, true, nullptr);
 }
 
 int box_ok(const lsf_box* b, const int lo[3], const int hi[3])

@@ -621,6 +621,117 @@ __global__ __launch_bounds__(256) void k_minmax_jacobi(const double* __restrict_
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exact Gauss-Seidel ordering by fixed-point iteration (the fast exact path).
+// In pass B of the reference (set3d.f90:417-431) a band cell depends on its already-visited
+// neighbours (i-1, j-1, k-1) ONLY through the sign test pAve < 0 (subs.f90:473-481): the curvature
+// is frozen.  The in-place result is therefore the unique fixed point X of
+//     X(c) = A(c) + h1 * F(curv_A(c), sign(pAve(A(c), X(i-1), A(i+1), A(j+1), X(j-1), A(k+1), X(k-1))))
+// (the dependency graph is acyclic).  Start from the Jacobi result and re-evaluate every band cell
+// with the current X of its three upstream neighbours until a whole pass changes nothing.  A cell is
+// final one pass after its upstream cells are final, whatever mixture of old/new values a racing
+// read observes, so the passes may update in place; "no cell changed" certifies the fixed point.
+// Sign flips need |pAve| ~ h1*|curv|, i.e. a handful of cells hugging phi = 0: 2-3 passes in practice.
+// Fixed point-to-block map (MM_CH points per block) -> per-block band flags and deterministic RMS.
+// ---------------------------------------------------------------------------------------------
+constexpr int MM_CH = 2048;
+
+template <int PASS> // 0: scan (copy + Jacobi update + band flags), 1: fix pass, 2: RMS partials
+__global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A, double* __restrict__ B,
+                                                   const int32_t* __restrict__ nbmask, int nx, int ny, int nz,
+                                                   double dx, double h1, int* __restrict__ blockflag, long nchunks,
+                                                   const int* __restrict__ changed_prev,
+                                                   int* __restrict__ changed_cur, double* __restrict__ partials,
+                                                   int* __restrict__ ctl)
+{
+    __shared__ double red[4];
+    __shared__ int flag;
+    if (ctl[0]) return;
+    if (PASS == 1 && changed_prev && *changed_prev == 0) return;
+    const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1), n = sxy * (nz + 1);
+    const double dxx = 1. / (dx * dx);
+    // chunks of MM_CH consecutive points; the grid strides over them so that the (mostly empty) fix and
+    // RMS passes cost a few thousand blocks instead of one block per chunk
+    for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (PASS != 0 && !blockflag[chunk]) {
+            if (PASS == 2 && threadIdx.x == 0) partials[chunk] = 0.0;
+            continue;
+        }
+        if (threadIdx.x == 0) flag = 0;
+        __syncthreads();
+        double acc = 0.0;
+        int mine = 0;
+#pragma unroll
+        for (int t = 0; t < MM_CH / 256; ++t) {
+            const long p = chunk * MM_CH + t * 256 + threadIdx.x;
+            if (p >= n) break;
+            const int i = p % sx, j = (p / sx) % (ny + 1), k = p / sxy;
+            const double c = A[p];
+            const bool interior = i >= 1 && i <= nx - 1 && j >= 1 && j <= ny - 1 && k >= 1 && k <= nz - 1;
+            const bool band = interior && in_band(nbmask, p, c, dx);
+            if (PASS == 0) {
+                double out = c;
+                if (band) {
+                    const double xm = A[p - 1], xp = A[p + 1], ym = A[p - sx], yp = A[p + sx], zm = A[p - sxy],
+                                 zp = A[p + sxy];
+                    out = minmax_update(c, xm, xp, yp, ym, zp, zm, minmax_curv(c, xp, xm, yp, ym, zp, zm, dxx), h1);
+                    mine = 1;
+                }
+                B[p] = out;
+            } else if (band) {
+                if (PASS == 1) {
+                    const double xm = A[p - 1], xp = A[p + 1], ym = A[p - sx], yp = A[p + sx], zm = A[p - sxy],
+                                 zp = A[p + sxy];
+                    const double curv = minmax_curv(c, xp, xm, yp, ym, zp, zm, dxx);
+                    // upstream neighbours from the evolving field (B holds A wherever nothing was updated)
+                    const double nv = minmax_update(c, B[p - 1], xp, yp, B[p - sx], zp, B[p - sxy], curv, h1);
+                    const double cur = B[p];
+                    if (!(nv == cur)) {
+                        B[p] = nv;
+                        mine = 1;
+                    }
+                } else {
+                    const double d = B[p] - c;
+                    acc += d * d;
+                }
+            }
+        }
+        if (PASS == 2) {
+            acc = wave_sum(acc);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+            __syncthreads();
+            if (threadIdx.x == 0) partials[chunk] = red[0] + red[1] + red[2] + red[3];
+        } else {
+            if (mine) flag = 1;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                if (PASS == 0) blockflag[chunk] = flag;
+                else if (flag) *changed_cur = 1;
+            }
+        }
+        __syncthreads();
+    }
+    // the last allowed fix pass still changed something: the fixed point is not certified
+    if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0 && changed_prev && *changed_prev != 0) ctl[3] = 1;
+}
+
+// deterministic two-stage reduction of many partials: block b sums its contiguous slice
+__global__ __launch_bounds__(256) void k_reduce_slices(const double* __restrict__ in, long n, double* __restrict__ out)
+{
+    __shared__ double red[256];
+    const long per = (n + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * per, hi = min(lo + per, n);
+    double t = 0.0;
+    for (long p = lo + threadIdx.x; p < hi; p += 256) t += in[p];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
 // Exact Gauss-Seidel ordering of set3d.f90:417-431 (always the (+,+,+) raster): tile = TA x 8 x 8
 // POINTS anchored at point 0, same lane/skew mapping as the reinit kernel, halo 1.
 // LDS: box [10][10][TA+2] of in-place values + [8][8][TA] frozen curvature.

@@ -14,4 +14,18 @@ for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_$M" -- python3 bench.py --steps 2 --warmup 0 --mode $M --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/pmc_${C}_$M.log"
   done
 done
+cat > "$OUT/cal.py" <<'PY'
+import sys, torch
+sys.path.insert(0, '.')
+import levelsetfortran_amd as L
+n = 511
+phi = torch.rand((n + 1) ** 3, dtype=torch.float64, device='cuda')
+nb = torch.zeros(phi.numel(), dtype=torch.int32, device='cuda'); sb = torch.zeros_like(nb)
+for _ in range(2):
+    L.narrowBand(n, n, n, 0.01, phi, nb, sb)
+torch.cuda.synchronize()
+PY
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_cal" -- python3 "$OUT/cal.py" > /dev/null 2> "$OUT/pmc_${C}_cal.log"
+done
 python3 profiles/summarize.py "$OUT" "$TAG"

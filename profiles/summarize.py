@@ -33,7 +33,7 @@ if stats:
 res = {"unit": "bytes per sweep", "N": 512, "note": "sum over the sweep-kernel dispatches of one sweep; counters are in KiB "
        "(rocprofv3 FETCH_SIZE/WRITE_SIZE); fetch_corrected = 2 x fetch_raw (gfx950 wide-read correction, upper bound)"}
 traffic = {}
-for mode, kern in (("gs", "k_reinit_gs_plane"), ("jacobi", "k_reinit_jacobi")):
+for mode, kern in (("gs", "k_reinit_gs_quad"), ("jacobi", "k_reinit_jacobi")):
     entry = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         f = one(f"pmc_{ctr}_{mode}/**/*counter_collection.csv")
@@ -53,6 +53,23 @@ for mode, kern in (("gs", "k_reinit_gs_plane"), ("jacobi", "k_reinit_jacobi")):
                               "hbm_corrected": 2 * fr + wr, "algorithmic": 24.0 * 510 ** 3}
         traffic[kern] = {"512": 2 * fr + wr}
     res[kern] = entry
+# calibration of the counters on a kernel with a known byte count in the same access width (8 B per lane):
+# k_narrowband reads n doubles and writes 2n int32 -> 8n bytes each way
+cal = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = one(f"pmc_{ctr}_cal/**/*counter_collection.csv")
+    if f:
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_narrowband" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+        if vals:
+            cal[ctr] = {"measured_bytes": vals[-1] * 1024, "true_bytes": 8.0 * 512 ** 3, "ratio": vals[-1] * 1024 / (8.0 * 512 ** 3)}
+res["calibration_k_narrowband_512"] = cal
+if "FETCH_SIZE" in cal:
+    # use the measured ratio instead of the blanket x2 for the committed traffic numbers
+    for kern in list(traffic):
+        e = res[kern]["per_sweep"]
+        e["fetch_calibrated"] = e["fetch_raw"] / cal["FETCH_SIZE"]["ratio"]
+        e["hbm_calibrated"] = e["fetch_calibrated"] + e["write"] / cal.get("WRITE_SIZE", {"ratio": 1.0})["ratio"]
+        traffic[kern] = {"512": e["hbm_calibrated"]}
 json.dump(res, open(os.path.join(here, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 if traffic:
     json.dump(traffic, open(os.path.join(here, "traffic.json"), "w"), indent=1)

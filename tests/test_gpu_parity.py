@@ -270,3 +270,15 @@ def test_phi0_matches_reference(lsf, cube40, twocube):
         t = _dev(np.zeros_like(phi))
         lsf.phi0Init(t, n[0], n[1], n[2], 0.05, xLo, mn, mx, X, E)
         assert np.array_equal(_host(t, phi.shape), gold["phi0"])
+
+
+def test_minmax_tile_wavefront_path(lsf, oracle, cube40, monkeypatch):
+    """The exact ordering has two implementations: fixed-point passes (default) and the tile-hyperplane
+    wavefront (fallback when a fixed point is not certified).  Force the fallback and re-check parity."""
+    monkeypatch.setenv("LSF_MINMAX_TILES", "1")
+    nx, ny, nz = _n(cube40)
+    phi, nb, sb = F(cube40["phi_reinit"]), F(cube40["NB0"].astype(np.int32)), F(cube40["SB0"].astype(np.int32))
+    rep = lsf.minmaxFlow(phi, nb, sb, nx, ny, nz, 10000, float(cube40["dx"]), float(cube40["h1"]))
+    assert rep.count == 406 and np.array_equal(phi, cube40["phi_minmax"])
+    assert np.array_equal(nb, cube40["NBfinal"]) and np.array_equal(sb, cube40["SBfinal"])
+    test_minmax_vs_oracle_other_shapes(lsf, oracle)
