@@ -216,7 +216,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seconds = float(t.item())
 
-    kernel = {"gs": "k_reinit_gs_quad", "jacobi": "k_reinit_jacobi"}[order]
+    kernel = {"gs": "k_reinit_gs_flow", "jacobi": "k_reinit_jacobi"}[order]
 
     def roofline(prof_, cells_per_sweep):
         if not prof_ or not prof_.get("sweeps"):
@@ -279,7 +279,7 @@ def main() -> None:
         other = "jacobi" if order == "gs" else "gs"
         sec2, prof2 = timed(other)
         cells2 = float(nx - 1) * (ny - 1) * (nz - 1) * K
-        kernel = {"gs": "k_reinit_gs_quad", "jacobi": "k_reinit_jacobi"}[other]
+        kernel = {"gs": "k_reinit_gs_flow", "jacobi": "k_reinit_jacobi"}[other]
         out[other] = {
             "value": cells2 / sec2, "unit": "cell-updates/s", "ms_per_step": sec2 / K * 1e3,
             "roofline": roofline(prof2, cells2 / K),

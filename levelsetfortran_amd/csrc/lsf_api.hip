@@ -9,10 +9,12 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/lsf.h"
 #include "lsf_kernels.hpp"
+#include "lsf_flow.hpp"
 
 using namespace lsf;
 
@@ -57,7 +59,7 @@ struct TileList {
     std::vector<int> off; // plane offsets, size nplanes+1
 };
 
-enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_NSLOTS };
+enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_FLAGS, S_FLOWCTL, S_COLSUM, S_ORDER, S_NSLOTS };
 
 struct Ctx {
     Buf slot[S_NSLOTS];
@@ -206,6 +208,14 @@ int check_dims(int nx, int ny, int nz)
     return LSF_OK;
 }
 
+int gs_schedule();
+int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
+                     double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace, int trace_cap,
+                     hipStream_t st);
+int reinit_flow_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
+                     double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace, int trace_cap,
+                     hipStream_t st);
+
 // ---------------------------------------------------------------------------------------------
 int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx,
                 double h, double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace,
@@ -219,6 +229,12 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     const bool strict = (mode & LSF_ARITH_STRICT) != 0;
     if (order != LSF_ORDER_GS && order != LSF_ORDER_JACOBI) return fail(LSF_ERR_INVALID, "unknown ordering");
     if (!d_phi) return fail(LSF_ERR_INVALID, "phi is NULL");
+    if (order == LSF_ORDER_GS && gs_schedule() == 1)
+        return reinit_slot_core(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done,
+                                rms_trace, trace_cap, st);
+    if (order == LSF_ORDER_GS && gs_schedule() == 2)
+        return reinit_flow_core(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done,
+                                rms_trace, trace_cap, st);
     Ctx& c = ctx();
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
     const int max_sweeps = iter + 1; // DO n=0,iter (subs.f90:735)
@@ -272,9 +288,15 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
         prof_mark(st);
         if (order == LSF_ORDER_GS) {
             hipLaunchKernelGGL(k_copy_walls, bgrid, dim3(64), 0, st, A, B, nx, ny, nz, ctl);
-            const int nplanes = (int)tl->off.size() - 1;
+            int nplanes = (int)tl->off.size() - 1;
+            // timing experiment only (results are wrong): all tiles in one launch = the pure work term
+            static const bool nodeps = getenv("LSF_GS_NODEPS_EXPERIMENT") != nullptr;
             for (int P = 0; P < nplanes; ++P) {
-                const int cnt = tl->off[P + 1] - tl->off[P];
+                int cnt = tl->off[P + 1] - tl->off[P];
+                if (nodeps) {
+                    if (P > 0) break;
+                    cnt = tl->off[nplanes];
+                }
                 if (cnt <= 0) continue;
 #define LSF_LAUNCH_QUAD(TA_, ST_)                                                                                  \
     hipLaunchKernelGGL((k_reinit_gs_quad<TA_, ST_>), dim3(cnt), dim3(64), 0, st, A, B, d_phiS, nx, ny, nz, sg[0],   \
@@ -325,6 +347,356 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     HIPCHK(hipStreamSynchronize(st));
     if (sweeps_done) *sweeps_done = nsw;
     if (host_ctl[2]) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, subs.f90:926)");
+    return LSF_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Exact-GS reinit as persistent dataflow launches (lsf_flow.hpp): one launch per batch of <= 8 sweeps.
+// ---------------------------------------------------------------------------------------------
+constexpr int FLOW_TA = 16;
+constexpr int FLOW_BATCH = 8;
+
+struct OrderKey {
+    int nTi, nTj, nTk, first, ns;
+    bool operator<(const OrderKey& o) const
+    {
+        return std::tie(nTi, nTj, nTk, first, ns) < std::tie(o.nTi, o.nTj, o.nTk, o.first, o.ns);
+    }
+};
+struct OrderList {
+    uint2* d = nullptr;
+    long total = 0;
+};
+std::map<std::pair<int, OrderKey>, OrderList> g_orders;
+
+// Task list of a batch: sweep s occupies time slots start[s] + P (P = tile hyperplane in its own frame); the
+// merged list sorted by slot is a topological order of the dependency graph if
+//   start[s+1] >= start[s] + (sum over flipped axes of nT-1) + 2      (tile + face neighbours of sweep s)
+//   start[s+2] >= start[s] + nPlanes + 1                              (verdict of sweep s)
+int get_order(int nTi, int nTj, int nTk, int first_dir, int ns, TileList* tl, OrderList** out)
+{
+    const OrderKey key{nTi, nTj, nTk, first_dir, ns};
+    auto it = g_orders.find({g_device, key});
+    if (it == g_orders.end()) {
+        const int np = nTi + nTj + nTk - 2;
+        const int nT[3] = {nTi, nTj, nTk};
+        std::vector<int> start(ns, 0);
+        for (int s = 1; s < ns; ++s) {
+            const int* da = RASTER_SIGN[(first_dir + s - 1) & 7];
+            const int* db = RASTER_SIGN[(first_dir + s) & 7];
+            int H = 2;
+            for (int ax = 0; ax < 3; ++ax)
+                if (da[ax] != db[ax]) H += nT[ax] - 1;
+            start[s] = start[s - 1] + H;
+            if (s >= 2) start[s] = std::max(start[s], start[s - 2] + np + 1);
+        }
+        // download the plane-sorted frame tile list once
+        std::vector<uint32_t> tiles((size_t)tl->off.back());
+        HIPCHK(hipMemcpy(tiles.data(), tl->d, tiles.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<uint2> h;
+        h.reserve(tiles.size() * (size_t)ns);
+        const int last_slot = start[ns - 1] + np;
+        for (int slot = 0; slot < last_slot; ++slot)
+            for (int s = 0; s < ns; ++s) {
+                const int P = slot - start[s];
+                if (P < 0 || P >= np) continue;
+                for (int q = tl->off[P]; q < tl->off[P + 1]; ++q) h.push_back(make_uint2(tiles[q], (unsigned)s));
+            }
+        OrderList ol;
+        ol.total = (long)h.size();
+        HIPCHK(hipMalloc((void**)&ol.d, h.size() * sizeof(uint2)));
+        HIPCHK(hipMemcpy(ol.d, h.data(), h.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        // keep at most a handful of lists alive (each is 8 bytes per tile per sweep)
+        if (g_orders.size() > 12) {
+            for (auto& kv : g_orders)
+                if (kv.second.d) (void)hipFree(kv.second.d);
+            g_orders.clear();
+        }
+        it = g_orders.emplace(std::make_pair(g_device, key), ol).first;
+    }
+    *out = &it->second;
+    return LSF_OK;
+}
+
+// LSF_GS_SCHEDULE selects how the exact Gauss-Seidel tile graph is executed (all three are bit-identical):
+//   "slots"  (default) overlapped sweeps, one launch per time slot            reinit_slot_core
+//   "planes"           one launch per tile hyperplane of one sweep (simplest)   reinit_core
+//   "flow"             persistent dataflow kernel with flag polling (experimental: correct, but the polling
+//                      waves slow the memory system down -- measurements in DESIGN.md)  reinit_flow_core
+int gs_schedule()
+{
+    const char* e = getenv("LSF_GS_SCHEDULE");
+    if (e && std::strcmp(e, "planes") == 0) return 0;
+    if (e && std::strcmp(e, "flow") == 0) return 2;
+    return 1;
+}
+
+int reinit_flow_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
+                     double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace, int trace_cap,
+                     hipStream_t st)
+{
+    int rc = check_dims(nx, ny, nz);
+    if (rc) return rc;
+    if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
+    if (first_raster < 0 || first_raster > 7) return fail(LSF_ERR_INVALID, "first_raster must be 0..7");
+    if (!d_phi) return fail(LSF_ERR_INVALID, "phi is NULL");
+    const bool strict = (mode & LSF_ARITH_STRICT) != 0;
+    Ctx& c = ctx();
+    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    const int max_sweeps = iter + 1;
+    if ((rc = ws(c.slot[S_PONG], n * sizeof(double)))) return rc;
+    const double* d_phiS = d_phiS_in;
+    if (!d_phiS) {
+        if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
+        HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        d_phiS = (const double*)c.slot[S_PHIS].p;
+    }
+    const int nTi = cdiv(nx - 1, FLOW_TA), nTj = cdiv(ny - 1, 4), nTk = cdiv(nz - 1, 4);
+    const long nTiles = (long)nTi * nTj * nTk;
+    TileList* tl = nullptr;
+    if ((rc = get_tiles(nTi, nTj, nTk, &tl))) return rc;
+    if ((rc = ws(c.slot[S_CTL], 64))) return rc;
+    if ((rc = ws(c.slot[S_TRACE], (size_t)max_sweeps * sizeof(double)))) return rc;
+    if ((rc = ws(c.slot[S_FLAGS], (size_t)nTiles * sizeof(int)))) return rc;
+    if ((rc = ws(c.slot[S_FLOWCTL], 256))) return rc;
+    if ((rc = ws(c.slot[S_COLSUM], (size_t)2 * nTj * nTk * sizeof(double)))) return rc;
+    int* ctl = (int*)c.slot[S_CTL].p;
+    int* fctl = (int*)c.slot[S_FLOWCTL].p; // [0] ticket, [1] verdict, [8..15] tiles_done
+    HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
+    HIPCHK(hipMemsetAsync(fctl, 0, 256, st));
+    HIPCHK(hipMemsetAsync(c.slot[S_FLAGS].p, 0, (size_t)nTiles * sizeof(int), st));
+    // the pong buffer must carry valid wall points for the first sweep's loader never to read garbage that it
+    // then consumes: it does not consume them (walls always come from the input buffer), nothing to do.
+
+    int host_ctl[4] = {0, 0, 0, 0};
+    prof_begin();
+    hipDeviceProp_t pr;
+    HIPCHK(hipGetDeviceProperties(&pr, g_device));
+    const char* bpc = getenv("LSF_FLOW_BLOCKS_PER_CU");
+    const int resident = pr.multiProcessorCount * (bpc ? atoi(bpc) : 12);
+    for (int g0 = 0; g0 < max_sweeps; g0 += FLOW_BATCH) {
+        const int ns = std::min(FLOW_BATCH, max_sweeps - g0);
+        const int first_dir = (first_raster + g0) & 7;
+        OrderList* ol = nullptr;
+        if ((rc = get_order(nTi, nTj, nTk, first_dir, ns, tl, &ol))) return rc;
+        FlowArgs fa;
+        fa.buf[0] = d_phi;
+        fa.buf[1] = (double*)c.slot[S_PONG].p;
+        fa.phiS = d_phiS;
+        fa.nx = nx, fa.ny = ny, fa.nz = nz, fa.nTi = nTi, fa.nTj = nTj, fa.nTk = nTk;
+        fa.dx = dx, fa.h = h;
+        fa.order = ol->d;
+        fa.total = ol->total;
+        fa.nsweeps = ns;
+        fa.g0 = g0;
+        for (int s = 0; s < 8; ++s)
+            for (int ax = 0; ax < 3; ++ax) fa.sign[s][ax] = RASTER_SIGN[(first_dir + s) & 7][ax];
+        fa.flags = (int*)c.slot[S_FLAGS].p;
+        fa.ticket = fctl;
+        fa.verdict = fctl + 1;
+        fa.tiles_done = fctl + 8;
+        fa.colsum = (double*)c.slot[S_COLSUM].p;
+        fa.trace = (double*)c.slot[S_TRACE].p;
+        fa.trace_cap = max_sweeps;
+        fa.den = rms_denominator(nx, ny, nz);
+        fa.tol = tol;
+        fa.ctl = ctl;
+        fa.nTiles = nTiles;
+        {
+            const char* kb = getenv("LSF_FLOW_KNOBS");
+            fa.knobs = kb ? atoi(kb) : 0;
+            fa.dbg = nullptr;
+            if (getenv("LSF_FLOW_DEBUG")) {
+                fa.dbg = (unsigned long long*)(fctl + 32);
+                HIPCHK(hipMemsetAsync(fctl + 32, 0, 64, st));
+            }
+        }
+        // per batch: ticket and per-sweep tile counters restart, flags/verdict keep counting
+        HIPCHK(hipMemsetAsync(fctl, 0, 4, st));
+        HIPCHK(hipMemsetAsync(fctl + 8, 0, 32, st));
+        const unsigned grid = (unsigned)std::min<long>(ol->total, resident);
+        prof_mark(st);
+        if (strict)
+            hipLaunchKernelGGL((k_reinit_gs_flow<FLOW_TA, true, false>), dim3(grid), dim3(64), 0, st, fa);
+        else
+            hipLaunchKernelGGL((k_reinit_gs_flow<FLOW_TA, false, false>), dim3(grid), dim3(64), 0, st, fa);
+        prof_mark(st);
+        prof_mark(st);
+        prof_mark(st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (getenv("LSF_FLOW_DEBUG")) {
+            unsigned long long d[5];
+            HIPCHK(hipMemcpy(d, fctl + 32, sizeof d, hipMemcpyDeviceToHost));
+            const double k = d[4] ? 1e-2 / (double)d[4] : 0; // ticks of 10 ns -> us per task
+            fprintf(stderr, "[flow] tasks %llu  per task (us): wait %.2f  acquire+load %.2f  march %.2f  store+publish %.2f\n",
+                    d[4], d[0] * k, d[1] * k, d[2] * k, d[3] * k);
+        }
+        if (host_ctl[0]) break;
+    }
+    const int nsw = host_ctl[1];
+    // the profile brackets whole batches: spread the time over the sweeps of the call
+    if (g_prof.on) {
+        double ms = 0;
+        for (size_t b = 0; b + 3 < g_prof.ev.size(); b += 4) {
+            float a = 0;
+            (void)hipEventElapsedTime(&a, g_prof.ev[b], g_prof.ev[b + 1]);
+            ms += a;
+        }
+        g_prof.sweep_ms = ms;
+        g_prof.bc_ms = g_prof.finish_ms = 0;
+        g_prof.sweeps = nsw;
+        g_prof.sweep_launches = (long)(g_prof.ev.size() / 4);
+    }
+    double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
+    if (bufs[nsw & 1] != d_phi)
+        HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (rms_trace && trace_cap > 0 && nsw > 0)
+        HIPCHK(hipMemcpyAsync(rms_trace, c.slot[S_TRACE].p, sizeof(double) * (size_t)std::min(nsw, trace_cap),
+                              hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (sweeps_done) *sweeps_done = nsw;
+    if (host_ctl[2] == 2) return fail(LSF_ERR_HIP, "dataflow kernel timed out waiting for a predecessor tile");
+    if (host_ctl[2] == 1) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, subs.f90:926)");
+    return LSF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact-GS reinit, slot-synchronous schedule with overlapped sweeps (default).
+// One launch per time slot; a slot holds the tile hyperplane P = slot - start[g] of every sweep g in flight
+// (at most two).  start[] obeys the two spacing rules of get_order(), so every predecessor of a task ran in
+// an earlier launch.  Compared with one launch per hyperplane of one sweep this halves the number of
+// dependent launches per sweep and fuses the BC, the wall mirror and the RMS epilogue into the tile kernel.
+// ---------------------------------------------------------------------------------------------
+int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
+                     double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace, int trace_cap,
+                     hipStream_t st)
+{
+    int rc = check_dims(nx, ny, nz);
+    if (rc) return rc;
+    const bool strict = (mode & LSF_ARITH_STRICT) != 0;
+    Ctx& c = ctx();
+    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    const int max_sweeps = iter + 1;
+    if ((rc = ws(c.slot[S_PONG], n * sizeof(double)))) return rc;
+    const double* d_phiS = d_phiS_in;
+    if (!d_phiS) {
+        if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
+        HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        d_phiS = (const double*)c.slot[S_PHIS].p;
+    }
+    const int ta = gs_ta() == 32 ? 32 : 16;
+    const int nTi = cdiv(nx - 1, ta), nTj = cdiv(ny - 1, 4), nTk = cdiv(nz - 1, 4);
+    const int nT[3] = {nTi, nTj, nTk};
+    const int np = nTi + nTj + nTk - 2;
+    TileList* tl = nullptr;
+    if ((rc = get_tiles(nTi, nTj, nTk, &tl))) return rc;
+    if ((rc = ws(c.slot[S_CTL], 64))) return rc;
+    if ((rc = ws(c.slot[S_TRACE], (size_t)max_sweeps * sizeof(double)))) return rc;
+    if ((rc = ws(c.slot[S_COLSUM], (size_t)2 * nTj * nTk * sizeof(double)))) return rc;
+    int* ctl = (int*)c.slot[S_CTL].p;
+    HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
+
+    FlowArgs fa;
+    std::memset(&fa, 0, sizeof fa);
+    fa.buf[0] = d_phi;
+    fa.buf[1] = (double*)c.slot[S_PONG].p;
+    fa.phiS = d_phiS;
+    fa.nx = nx, fa.ny = ny, fa.nz = nz, fa.nTi = nTi, fa.nTj = nTj, fa.nTk = nTk;
+    fa.dx = dx, fa.h = h;
+    fa.colsum = (double*)c.slot[S_COLSUM].p;
+    fa.trace = (double*)c.slot[S_TRACE].p;
+    fa.trace_cap = max_sweeps;
+    fa.den = rms_denominator(nx, ny, nz);
+    fa.tol = tol;
+    fa.ctl = ctl;
+    fa.nTiles = (long)nTi * nTj * nTk;
+
+    // start slot of sweep g, generated on demand
+    std::vector<long> start{0};
+    auto start_of = [&](int g) -> long {
+        while ((int)start.size() <= g) {
+            const int q = (int)start.size();
+            const int* da = RASTER_SIGN[(first_raster + q - 1) & 7];
+            const int* db = RASTER_SIGN[(first_raster + q) & 7];
+            long H = 2;
+            for (int ax = 0; ax < 3; ++ax)
+                if (da[ax] != db[ax]) H += nT[ax] - 1;
+            long s0 = start[q - 1] + H;
+            if (q >= 2) s0 = std::max(s0, start[q - 2] + np + 1);
+            start.push_back(s0);
+        }
+        return start[g];
+    };
+    int host_ctl[4] = {0, 0, 0, 0};
+    prof_begin();
+    prof_mark(st);
+    long launches = 0;
+    int lo = 0;            // first sweep that still has hyperplanes to launch
+    int epilogues = 0;     // sweeps whose last hyperplane has been launched
+    bool stop = false;
+    for (long slot = 0; !stop && lo < max_sweeps; ++slot) {
+        int nseg = 0;
+        fa.seg_count[0] = fa.seg_count[1] = 0;
+        for (int g = lo; g < max_sweeps && start_of(g) <= slot; ++g) {
+            const long P = slot - start_of(g);
+            if (P >= np) continue;
+            const int cnt = tl->off[P + 1] - tl->off[P];
+            if (cnt <= 0) continue;
+            if (nseg == 2) return fail(LSF_ERR_HIP, "internal: more than two sweeps in flight");
+            fa.seg_tiles[nseg] = tl->d + tl->off[P];
+            fa.seg_count[nseg] = cnt;
+            fa.seg_g[nseg] = g;
+            for (int ax = 0; ax < 3; ++ax) fa.seg_sign[nseg][ax] = RASTER_SIGN[(first_raster + g) & 7][ax];
+            ++nseg;
+            if (P == np - 1) ++epilogues;
+        }
+        while (lo < max_sweeps && start_of(lo) + np <= slot + 1) ++lo;
+        const int grid = fa.seg_count[0] + fa.seg_count[1];
+        if (grid > 0) {
+#define LSF_LAUNCH_SLOT(TA_, ST_) \
+    hipLaunchKernelGGL((k_reinit_gs_flow<TA_, ST_, true>), dim3(grid), dim3(64), 0, st, fa)
+            if (strict) {
+                if (ta == 16) LSF_LAUNCH_SLOT(16, true);
+                else LSF_LAUNCH_SLOT(32, true);
+            } else {
+                if (ta == 16) LSF_LAUNCH_SLOT(16, false);
+                else LSF_LAUNCH_SLOT(32, false);
+            }
+#undef LSF_LAUNCH_SLOT
+            ++launches;
+        }
+        if (epilogues >= CHECK_EVERY && lo < max_sweeps) {
+            epilogues = 0;
+            HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (host_ctl[0]) stop = true;
+        }
+    }
+    prof_mark(st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int nsw = host_ctl[1];
+    if (g_prof.on && g_prof.ev.size() >= 2) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, g_prof.ev[0], g_prof.ev[1]);
+        g_prof.sweep_ms = ms;
+        g_prof.bc_ms = g_prof.finish_ms = 0;
+        g_prof.sweeps = nsw;
+        g_prof.sweep_launches = launches;
+    }
+    double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
+    if (bufs[nsw & 1] != d_phi)
+        HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (rms_trace && trace_cap > 0 && nsw > 0)
+        HIPCHK(hipMemcpyAsync(rms_trace, c.slot[S_TRACE].p, sizeof(double) * (size_t)std::min(nsw, trace_cap),
+                              hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (sweeps_done) *sweeps_done = nsw;
+    if (host_ctl[2] == 1) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, subs.f90:926)");
     return LSF_OK;
 }
 

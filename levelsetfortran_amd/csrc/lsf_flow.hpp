@@ -1,0 +1,413 @@
+// lsf_flow.hpp -- exact Gauss-Seidel reinit as ONE persistent dataflow launch per batch of sweeps.
+//
+// The plane-by-plane schedule (k_reinit_gs_quad, one launch per tile hyperplane) costs
+//     T = n_planes x L_tile  +  tiles / X_saturated        (286 x 17 us + 4.6 ms at 512^3)
+// i.e. half of the time is the latency of 286 dependent launches during which the chip is mostly idle.
+// Here every tile is a task; a block takes tasks from a global ticket counter in an order that is a
+// topological order of the dependency graph, waits for its predecessors' completion flags, computes the
+// tile exactly like the quad kernel, publishes its results and its flag.  Consecutive sweeps (different
+// raster directions) overlap: a tile of sweep g+1 may start as soon as the tile and its six face
+// neighbours are done in sweep g, so the ramp-down of one sweep fills up with the ramp-up of the next.
+//
+// Dependencies of tile T in (global) sweep g, reading buf[g&1] ("old") and writing buf[(g+1)&1]:
+//   a. T and its 6 face neighbours finished sweep g-1        (their old values; nobody still reads what T
+//                                                             overwrites in buf[(g+1)&1])
+//   b. the <= 3 upstream neighbours (sweep frame) finished sweep g   (their new values)
+//   c. the stop verdict of sweep g-2 is known                 (sweep g overwrites the result of sweep g-2's
+//                                                             successor only after it is known not to be final)
+// flags[tile] = number of sweeps the tile has completed; verdict = number of sweeps whose RMS test is done.
+//
+// No deadlock: a block only waits on tasks with a lower ticket (the task list is a topological order, built
+// on the host), and every lower ticket has been taken by a block that is running or finished; no assumption
+// on dispatch order or residency.  Every spin is bounded (s_memrealtime) and raises ctl[2]=2 on timeout.
+//
+// Memory model (cdna_hip_programming.md G16, form R1 + acquire): results are stored write-through (sc1),
+// every storing wave drains vmcnt before its flag store (agent-scope atomic), consumers poll with relaxed
+// agent-scope loads, then one agent-scope acquire, and read everything that was written in this launch with
+// sc1 loads.
+//
+// The extrapolation BC (subs.f90:859-897) is fused: a wall point is written by the tile that owns the interior
+// cell it clamps to (its value depends on that cell only), and its RMS contribution is added there.
+// RMS partials are accumulated per (tj,tk) tile column along the dependency chain (deterministic), the last
+// tile of a sweep reduces the columns, writes the trace, applies the stop/NaN test and publishes the verdict.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lsf_kernels.hpp"
+
+namespace lsf {
+
+struct FlowArgs {
+    double* buf[2];
+    const double* phiS;
+    int nx, ny, nz, nTi, nTj, nTk;
+    double dx, h;
+    const uint2* order; // task list: x = packed frame tile (10 bits per axis), y = local sweep index
+    long total;
+    int nsweeps;        // sweeps in this batch
+    int g0;             // global index of the first sweep of the batch
+    int sign[8][3];     // raster signs of each local sweep
+    int* flags;         // [nTiles] completed-sweep counters (absolute tile index)
+    int* ticket;        // task counter
+    int* tiles_done;    // [8] per local sweep
+    int* verdict;       // number of sweeps with a verdict
+    double* colsum;     // [2][nTj*nTk]
+    double* trace;
+    int trace_cap;
+    double den, tol;
+    int* ctl;           // [0] done, [1] sweeps completed, [2] status (1 NaN, 2 timeout), [3] unused
+    long nTiles;
+    // SLOT mode (one launch per time slot, dependencies resolved by launch order): up to two tile-plane
+    // segments, one per sweep in flight; blockIdx.x < seg_count[0] belongs to segment 0
+    const uint32_t* seg_tiles[2];
+    int seg_count[2];
+    int seg_g[2];       // global sweep index of each segment
+    int seg_sign[2][3];
+    unsigned long long* dbg; // optional phase timers (s_memrealtime ticks): wait, load, march, publish, tasks
+    int knobs;          // experiment bits: 1 no acquire fence, 2 plain (non-sc1) loads, 4 long sleep, 8 plain stores
+};
+
+__device__ __forceinline__ double ld_sc1(const double* p)
+{
+    return __longlong_as_double(__hip_atomic_load((const long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1(double* p, double v)
+{
+    __hip_atomic_store((long long*)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_flag(const int* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_flag(int* p, int v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr unsigned long long FLOW_TIMEOUT_TICKS = 400000000ull; // 4 s of the 100 MHz s_memrealtime clock
+
+// SLOT = false: persistent dataflow (ticket loop, flag polling, write-through hand-off).
+// SLOT = true : one block per task of one time slot; every predecessor ran in an earlier launch, so there is
+//               nothing to wait for and plain loads/stores suffice (kernel boundaries order them).
+template <int TA, bool STRICT, bool SLOT>
+__global__ __launch_bounds__(64) void k_reinit_gs_flow(FlowArgs a)
+{
+    using T = QuadTile<TA>;
+    __shared__ double lds[T::TOTAL];
+    const int lane = threadIdx.x;
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1);
+    const double dx = a.dx, h = a.h;
+    const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
+    const int ncol = a.nTj * a.nTk;
+
+    for (;;) {
+        // ---- next task -----------------------------------------------------------------------------
+        int s, g, si, sj, sk;
+        uint32_t packed;
+        if constexpr (SLOT) {
+            const int seg = (int)blockIdx.x < a.seg_count[0] ? 0 : 1;
+            const int q = (int)blockIdx.x - (seg ? a.seg_count[0] : 0);
+            packed = a.seg_tiles[seg][q];
+            g = a.seg_g[seg], s = 0;
+            si = a.seg_sign[seg][0], sj = a.seg_sign[seg][1], sk = a.seg_sign[seg][2];
+        } else {
+            int tk_ = 0;
+            if (lane == 0) tk_ = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long task = __builtin_amdgcn_readfirstlane(tk_);
+            if (task >= a.total) break;
+            const uint2 e = a.order[task];
+            packed = e.x;
+            s = (int)e.y, g = a.g0 + s;
+            si = a.sign[s][0], sj = a.sign[s][1], sk = a.sign[s][2];
+        }
+        const int fA = packed & 0x3ff, fB = (packed >> 10) & 0x3ff, fC = (packed >> 20) & 0x3ff;
+        const int ti = si > 0 ? fA : a.nTi - 1 - fA;
+        const int tj = sj > 0 ? fB : a.nTj - 1 - fB;
+        const int tk = sk > 0 ? fC : a.nTk - 1 - fC;
+        const long tile = ti + (long)a.nTi * (tj + (long)a.nTj * tk);
+
+        const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+        // ---- wait for the predecessors -----------------------------------------------------------------
+        if constexpr (!SLOT) {
+            const int* addr = nullptr;
+            int need = 0;
+            if (lane < 7) {
+                // lane 0: the tile itself; 1,2: i-1,i+1; 3,4: j-1,j+1; 5,6: k-1,k+1
+                const int ax = (lane - 1) >> 1, dir = (lane & 1) ? -1 : +1; // lane 1 -> axis 0 dir -1, lane 2 -> +1 ...
+                int ni_ = ti, nj_ = tj, nk_ = tk;
+                bool exists = true, upstream = false;
+                if (lane > 0) {
+                    if (ax == 0) { ni_ += dir; exists = ni_ >= 0 && ni_ < a.nTi; upstream = (dir < 0) == (si > 0); }
+                    else if (ax == 1) { nj_ += dir; exists = nj_ >= 0 && nj_ < a.nTj; upstream = (dir < 0) == (sj > 0); }
+                    else { nk_ += dir; exists = nk_ >= 0 && nk_ < a.nTk; upstream = (dir < 0) == (sk > 0); }
+                }
+                if (exists) {
+                    addr = a.flags + (ni_ + (long)a.nTi * (nj_ + (long)a.nTj * nk_));
+                    need = upstream ? g + 1 : g;
+                }
+            } else if (lane == 7) {
+                addr = a.verdict;
+                need = g - 1;
+            }
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                const bool ok = addr == nullptr || ld_flag(addr) >= need;
+                if (__all(ok)) break;
+                if (ld_flag(a.ctl + 0) != 0) break; // converged, NaN or timeout elsewhere: drain
+                if (__builtin_amdgcn_s_memrealtime() - t0 > FLOW_TIMEOUT_TICKS) {
+                    if (lane == 0) {
+                        st_flag(a.ctl + 2, 2);
+                        st_flag(a.ctl + 0, 1);
+                    }
+                    break;
+                }
+                if (a.knobs & 4) __builtin_amdgcn_s_sleep(127);
+                else __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        // converged / failed earlier: do not compute, but keep the dataflow draining
+        if (ld_flag(a.ctl + 0) != 0) {
+            if constexpr (SLOT) return;
+            if (lane == 0) st_flag(a.flags + tile, g + 1);
+            continue;
+        }
+        const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
+        if constexpr (!SLOT)
+            if (!(a.knobs & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
+        const double* in = a.buf[g & 1];
+        double* out = a.buf[(g + 1) & 1];
+        const long dOI = out - in; // element offset that turns an `in` address into an `out` address
+        const int i_lo = 1 + ti * TA, j_lo = 1 + tj * 4, k_lo = 1 + tk * 4;
+        const int ni = min(TA, nx - i_lo), nj = min(4, ny - j_lo), nk = min(4, nz - k_lo);
+        double* core = lds;
+
+        // ---- load (see k_reinit_gs_quad); upstream interior cells from `out`, everything else from `in` ----
+        {
+            constexpr int RPI = 64 / TA, NROW = 80 / RPI;
+            const int xx = lane & (TA - 1), rsub = lane / TA;
+            const int gi = min(i_lo + xx, nx);
+            const bool gi_int = gi <= nx - 1;
+            double v[NROW];
+            int dst[NROW];
+#pragma unroll
+            for (int u = 0; u < NROW; ++u) {
+                const int r = u * RPI + rsub;
+                int gj, gk;
+                bool up = false;
+                const double* base = in;
+                if (u * RPI < 16) {
+                    const int zz = r >> 2, yy = r & 3;
+                    gj = j_lo + yy, gk = k_lo + zz;
+                    dst[u] = (zz * 4 + yy) * T::RA + 3 + xx;
+                } else if (u * RPI < 40) {
+                    const int q = r - 16, zz = q / 6, hy = q - 6 * zz;
+                    gj = j_lo + (hy < 3 ? hy - 3 : nj + hy - 3), gk = k_lo + zz;
+                    up = (hy < 3) == (sj > 0);
+                    dst[u] = T::CORE + q * TA + xx;
+                } else if (u * RPI < 64) {
+                    const int q = r - 40, hz = q >> 2, yy = q & 3;
+                    gj = j_lo + yy, gk = k_lo + (hz < 3 ? hz - 3 : nk + hz - 3);
+                    up = (hz < 3) == (sk > 0);
+                    dst[u] = T::CORE + T::YH + q * TA + xx;
+                } else {
+                    const int q = r - 64, zz = q >> 2, yy = q & 3;
+                    gj = j_lo + yy, gk = k_lo + zz;
+                    base = a.phiS;
+                    dst[u] = T::CORE + T::YH + T::ZH + q * TA + xx;
+                }
+                const bool row_int = gj >= 1 && gj <= ny - 1 && gk >= 1 && gk <= nz - 1;
+                gj = min(max(gj, 0), ny), gk = min(max(gk, 0), nz);
+                const long off = gi + sx * gj + sxy * gk + ((up && row_int && gi_int) ? dOI : 0);
+                if constexpr (SLOT) v[u] = base[off];
+                else v[u] = (u * RPI < 64 && !(a.knobs & 2)) ? ld_sc1(base + off) : base[off];
+            }
+            double vh[2];
+            int dh[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = min(lane + 64 * u, 95), row = idx / 6, ee = idx - 6 * row;
+                const int x = ee < 3 ? ee - 3 : TA + ee - 3;
+                const int gih = min(max(i_lo + x, 0), nx);
+                const int gj = min(j_lo + (row & 3), ny), gk = min(k_lo + (row >> 2), nz);
+                const bool interior = gih >= 1 && gih <= nx - 1 && gj <= ny - 1 && gk <= nz - 1;
+                const bool up = (ee < 3) ? (si > 0) : (si < 0 && ni == TA);
+                {
+                    const double* ph = in + gih + sx * gj + sxy * gk + ((up && interior) ? dOI : 0);
+                    if constexpr (SLOT) vh[u] = *ph;
+                    else vh[u] = (a.knobs & 2) ? *ph : ld_sc1(ph);
+                }
+                dh[u] = row * T::RA + 3 + x;
+            }
+#pragma unroll
+            for (int u = 0; u < NROW; ++u) lds[dst[u]] = v[u];
+            lds[dh[0]] = vh[0];
+            if (lane + 64 < 96) lds[dh[1]] = vh[1];
+        }
+        __syncthreads();
+
+        const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
+        // ---- per-lane constants (as in the quad kernel) ------------------------------------------------
+        const int axis = lane & 3, cell = lane >> 2;
+        const int b = cell & 3, c = cell >> 2;
+        const bool row_ok = b < nj && c < nk;
+        const int y = sj > 0 ? b : nj - 1 - b, z = sk > 0 ? c : nk - 1 - c;
+        const int yc = row_ok ? y : 0, zc = row_ok ? z : 0;
+        const int gj = j_lo + yc, gk = k_lo + zc;
+        const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
+        const bool yquirk = axis == 1;
+        int off[7];
+        const int row_core = (zc * 4 + yc) * T::RA + 3;
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            const int d = m - 3;
+            const int yy = yc + (axis == 1 ? d : 0), zz = zc + (axis == 2 ? d : 0), dxm = (axis == 1 || axis == 2) ? 0 : d;
+            const bool in_y = yy >= 0 && yy < nj, in_z = zz >= 0 && zz < nk;
+            const int o_core = (zz * 4 + yy) * T::RA + 3 + dxm;
+            const int o_yh = T::CORE + (zc * 6 + (yy < 0 ? yy + 3 : yy - nj + 3)) * TA;
+            const int o_zh = T::CORE + T::YH + ((zz < 0 ? zz + 3 : zz - nk + 3) * 4 + yc) * TA;
+            off[m] = !in_y ? o_yh : (!in_z ? o_zh : o_core);
+        }
+        const int ps_row = T::CORE + T::YH + T::ZH + (zc * 4 + yc) * TA;
+        double acc = 0.0;
+        const int nsteps = ni + nj + nk - 2;
+
+        // ---- march ------------------------------------------------------------------------------------
+        for (int st = 0; st < nsteps; ++st) {
+            const int aa = st - b - c;
+            const bool active = row_ok && aa >= 0 && aa < ni;
+            const int ac = active ? aa : 0;
+            const int x = si > 0 ? ac : ni - 1 - ac;
+            double q[7];
+#pragma unroll
+            for (int m = 0; m < 7; ++m) q[m] = lds[off[m] + x];
+            const double pS = lds[ps_row + x];
+            const int gi = i_lo + x;
+            const bool weno_ok = yz_weno && gi > 3 && gi < nx - 4;
+            double dm, dp;
+            axis_pair<STRICT>(q, weno_ok, yquirk, dx, floor2, dm, dp);
+            const double gg = axis_godunov<STRICT>(q[3], dm, dp);
+            const double gX = quad_bcast(gg, 0), gY = quad_bcast(gg, 1), gZ = quad_bcast(gg, 2);
+            const double newv = finish_update<STRICT>(q[3], gX, gY, gZ, pS, dx, inv_dx, h);
+            if (active && axis == 0) {
+                lds[row_core + x] = newv;
+                const double dlt = newv - q[3];
+                acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
+            }
+            __syncthreads();
+        }
+
+        const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
+        // ---- write back (write-through) ---------------------------------------------------------------
+        {
+            constexpr int RPI = 64 / TA;
+            const int xx = lane & (TA - 1), rsub = lane / TA;
+#pragma unroll
+            for (int u = 0; u < 16 / RPI; ++u) {
+                const int r = u * RPI + rsub, zz = r >> 2, yy = r & 3;
+                if (xx < ni && yy < nj && zz < nk) {
+                    double* po = out + (long)(i_lo + xx) + sx * (j_lo + yy) + sxy * (k_lo + zz);
+                    if (SLOT || (a.knobs & 8)) *po = core[r * T::RA + 3 + xx];
+                    else st_sc1(po, core[r * T::RA + 3 + xx]);
+                }
+            }
+        }
+        // ---- fused extrapolation BC for the wall points this tile owns (closed form, subs.f90:859-897) ----
+        const bool touches_wall = i_lo == 1 || i_lo + ni == nx || j_lo == 1 || j_lo + nj == ny || k_lo == 1 || k_lo + nk == nz;
+        if (touches_wall) {
+            const int e0 = ni + 2, e1 = nj + 2, e2 = nk + 2;
+            for (int idx = lane; idx < e0 * e1 * e2; idx += 64) {
+                const int ex = idx % e0 - 1, ey = (idx / e0) % e1 - 1, ez = idx / (e0 * e1) - 1;
+                const int gi = i_lo + ex, gj2 = j_lo + ey, gk2 = k_lo + ez;
+                const bool wi = gi == 0 || gi == nx, wj = gj2 == 0 || gj2 == ny, wk = gk2 == 0 || gk2 == nz;
+                const int nb = (int)wi + (int)wj + (int)wk;
+                if (nb == 0) continue;
+                if ((!wi && (ex < 0 || ex >= ni)) || (!wj && (ey < 0 || ey >= nj)) || (!wk && (ez < 0 || ez >= nk))) continue;
+                const int nh = (int)(gi == nx) + (int)(gj2 == ny) + (int)(gk2 == nz);
+                const int m = min(nb, 1 + nh);
+                const int cx = min(max(gi, 1), nx - 1) - i_lo, cy = min(max(gj2, 1), ny - 1) - j_lo,
+                          cz = min(max(gk2, 1), nz - 1) - k_lo;
+                double val = core[(cz * 4 + cy) * T::RA + 3 + cx];
+                {
+#pragma clang fp contract(off)
+                    for (int t = 0; t < m; ++t) val = val + dx;
+                }
+                const long p = gi + sx * gj2 + sxy * gk2;
+                double oldw;
+                if constexpr (SLOT) { oldw = in[p]; out[p] = val; }
+                else { oldw = ld_sc1(in + p); st_sc1(out + p, val); }
+                const double dlt = val - oldw;
+                acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
+            }
+        }
+        acc = wave_sum(acc);
+        // ---- RMS column accumulation, publish ---------------------------------------------------------
+        int last = 0;
+        if constexpr (SLOT) {
+            // the column's previous tile ran in an earlier launch; the far-corner tile (alone on the last
+            // hyperplane of its sweep) runs the sweep epilogue, every other tile of the sweep is already done
+            if (lane == 0) {
+                double* slot = a.colsum + (long)(g & 1) * ncol + (tj + (long)a.nTj * tk);
+                *slot = ((fA == 0) ? 0.0 : *slot) + acc;
+            }
+            last = fA == a.nTi - 1 && fB == a.nTj - 1 && fC == a.nTk - 1;
+            __syncthreads();
+        } else {
+            if (lane == 0) {
+                double* slot = a.colsum + (long)(g & 1) * ncol + (tj + (long)a.nTj * tk);
+                const double prev = (fA == 0) ? 0.0 : ld_sc1(slot);
+                st_sc1(slot, prev + acc);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                st_flag(a.flags + tile, g + 1);
+                last = __hip_atomic_fetch_add(a.tiles_done + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.nTiles - 1;
+            }
+            last = __builtin_amdgcn_readfirstlane(last);
+            if (a.dbg && lane == 0) {
+                const unsigned long long ts4 = __builtin_amdgcn_s_memrealtime();
+                atomicAdd(a.dbg + 0, ts1 - ts0);
+                atomicAdd(a.dbg + 1, ts2 - ts1);
+                atomicAdd(a.dbg + 2, ts3 - ts2);
+                atomicAdd(a.dbg + 3, ts4 - ts3);
+                atomicAdd(a.dbg + 4, 1ull);
+            }
+        }
+        if (last) {
+            // ---- sweep epilogue: RMS, trace, stop / NaN test (subs.f90:902-926), verdict ---------------
+            if constexpr (!SLOT) {
+                // epilogues run in sweep order: wait for the verdict of sweep g-1 (it may still be summing)
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (ld_flag(a.verdict) < g && ld_flag(a.ctl + 0) == 0) {
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > FLOW_TIMEOUT_TICKS) {
+                        if (lane == 0) { st_flag(a.ctl + 2, 2); st_flag(a.ctl + 0, 1); }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            const double* cs = a.colsum + (long)(g & 1) * ncol;
+            double t = 0.0;
+            for (int p = lane; p < ncol; p += 64) t += SLOT ? cs[p] : ld_sc1(cs + p);
+            t = wave_sum(t);
+            if (lane == 0 && ld_flag(a.ctl + 0) == 0) {
+                const double rms = __builtin_sqrt(t / a.den);
+                if (g < a.trace_cap) a.trace[g] = rms;
+                st_flag(a.ctl + 1, g + 1);
+                if (rms < a.tol) st_flag(a.ctl + 0, 1);
+                else if (rms != rms) { st_flag(a.ctl + 2, 1); st_flag(a.ctl + 0, 1); }
+                if constexpr (!SLOT) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    st_flag(a.verdict, g + 1);
+                }
+            }
+        }
+        if constexpr (SLOT) return;
+        __syncthreads(); // LDS image is reused by the next task
+    }
+}
+
+} // namespace lsf

@@ -33,7 +33,7 @@ if stats:
 res = {"unit": "bytes per sweep", "N": 512, "note": "sum over the sweep-kernel dispatches of one sweep; counters are in KiB "
        "(rocprofv3 FETCH_SIZE/WRITE_SIZE); fetch_corrected = 2 x fetch_raw (gfx950 wide-read correction, upper bound)"}
 traffic = {}
-for mode, kern in (("gs", "k_reinit_gs_quad"), ("jacobi", "k_reinit_jacobi")):
+for mode, kern in (("gs", "k_reinit_gs_flow"), ("jacobi", "k_reinit_jacobi")):
     entry = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         f = one(f"pmc_{ctr}_{mode}/**/*counter_collection.csv")

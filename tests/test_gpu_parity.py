@@ -282,3 +282,26 @@ def test_minmax_tile_wavefront_path(lsf, oracle, cube40, monkeypatch):
     assert rep.count == 406 and np.array_equal(phi, cube40["phi_minmax"])
     assert np.array_equal(nb, cube40["NBfinal"]) and np.array_equal(sb, cube40["SBfinal"])
     test_minmax_vs_oracle_other_shapes(lsf, oracle)
+
+
+@pytest.mark.parametrize("schedule", ["planes", "flow"])
+def test_reinit_alternative_schedules(lsf, synth, cube40, monkeypatch, schedule):
+    """The exact-GS tile graph has three executors (LSF_GS_SCHEDULE): overlapped slot launches (default, used by
+    every other test), one launch per hyperplane, and the experimental persistent dataflow kernel.  All must be
+    bit-identical to the reference."""
+    monkeypatch.setenv("LSF_GS_SCHEDULE", schedule)
+    nx, ny, nz = _n(synth)
+    phi = F(synth["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, 15, float(synth["dx"]), float(synth["h"]), arith="strict")
+    assert rep.count == 16 and np.array_equal(phi, synth["phi_16"])
+    nx, ny, nz = _n(cube40)
+    phi = F(cube40["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, 63, float(cube40["dx"]), float(cube40["h"]), arith="strict")
+    assert rep.count == 64 and sha(phi) == str(cube40["re64_sha"])
+    # stop test: converge on a loose tolerance and compare the stop sweep and field with the default schedule
+    phi = F(cube40["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, 200, float(cube40["dx"]), float(cube40["h"]), tol=3.0e-3, arith="strict")
+    monkeypatch.delenv("LSF_GS_SCHEDULE")
+    phi2 = F(cube40["phi0"])
+    rep2 = lsf.reinit(phi2, None, None, nx, ny, nz, 200, float(cube40["dx"]), float(cube40["h"]), tol=3.0e-3, arith="strict")
+    assert rep.count == rep2.count and 1 < rep.count < 200 and rep.converged and np.array_equal(phi, phi2)
