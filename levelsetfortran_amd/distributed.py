@@ -172,11 +172,14 @@ def halo_plan(b: Block):
 class HipBackend:
     """Device arithmetic through the C ABI; tensors are 1-D torch CUDA float64, i fastest."""
 
-    def __init__(self, device, arith: str = "fast"):
+    def __init__(self, device, arith: str = "fast", host_staging: bool = False):
         import torch
 
         from . import _lib
 
+        # host_staging: route the halo messages through pinned host buffers (for transports that cannot
+        # read device memory, e.g. gloo in the single-GPU tests); RCCL moves device buffers directly
+        self.host_staging = host_staging
         self.torch = torch
         self.L = _lib
         self.lib = _lib.load()
@@ -260,6 +263,12 @@ class DistributedReinit:
         self.plan = halo_plan(block)
         self.send_bufs = [backend.empty(_vol(s)) for (_, s, _, _, _) in self.plan]
         self.recv_bufs = [backend.empty(_vol(r)) for (_, _, r, _, _) in self.plan]
+        self.staging = bool(getattr(backend, "host_staging", False))
+        if self.staging:
+            import torch
+
+            self.send_host = [torch.empty(b.numel(), dtype=torch.float64).pin_memory() for b in self.send_bufs]
+            self.recv_host = [torch.empty(b.numel(), dtype=torch.float64).pin_memory() for b in self.recv_bufs]
         self.sumsq = backend.zeros(1)
         # INTEGER*4 product nx*ny*nz of the GLOBAL grid (subs.f90:914), wrapping like the reference
         nx, ny, nz = block.n
@@ -275,13 +284,22 @@ class DistributedReinit:
             ops = []
             for (peer, s_box, _r, _a, _s), sb in zip(self.plan, self.send_bufs):
                 be.pack(f, self.b, s_box, sb, be.comm)
-            for (peer, _s, _r, a, side), sb, rb in zip(self.plan, self.send_bufs, self.recv_bufs):
+            send_bufs, recv_bufs = self.send_bufs, self.recv_bufs
+            if self.staging:
+                for hb, sb in zip(self.send_host, self.send_bufs):
+                    hb.copy_(sb, non_blocking=True)
+                be.comm.synchronize()
+                send_bufs, recv_bufs = self.send_host, self.recv_host
+            for (peer, _s, _r, a, side), sb, rb in zip(self.plan, send_bufs, recv_bufs):
                 # tag by (axis, direction of travel) so the two messages between a pair of ranks that are
                 # neighbours on both sides of a periodic-free 2-rank axis cannot be confused
                 ops.append(dist.P2POp(dist.isend, sb, peer, group=self.group, tag=2 * a + (0 if side < 0 else 1)))
                 ops.append(dist.P2POp(dist.irecv, rb, peer, group=self.group, tag=2 * a + (1 if side < 0 else 0)))
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+            if self.staging:
+                for hb, rb in zip(self.recv_host, self.recv_bufs):
+                    rb.copy_(hb, non_blocking=True)
             for (peer, _s, r_box, _a, _sd), rb in zip(self.plan, self.recv_bufs):
                 be.unpack(f, self.b, r_box, rb, be.comm)
 
