@@ -24,165 +24,26 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // =============================================================================================
-// Reinit, exact Gauss-Seidel ordering: one wavefront per tile, tiles released plane by plane.
+// Reinit, exact Gauss-Seidel ordering: one wavefront per tile, lane-per-axis ("quad") form.
 // =============================================================================================
-// Tile = TA x 8 x 8 cells (i x j x k), anchored at cell 1.  The 64 lanes are the 8x8 (j,k) cross
-// section; lane (b,c) marches its i-row with skew a = s - b - c (all in the SWEEP frame, i.e.
-// reflected for negative directions), so every cell sees its -1..-3 neighbours already updated and
-// its +1..+3 neighbours not yet updated: exactly the reference's in-place raster order
-// (SURVEY.md appendix B).  Ping-pong: old values come from A, already-new values of upstream
-// tiles from B, results go to B.
-//
-// LDS image (doubles), ABSOLUTE orientation, star shaped:
-//   core [8][8][TA+6]  : x in [-3,TA+3) for the tile's own (y,z)
-//   yh   [8][6][TA]    : y in {-3,-2,-1, nj, nj+1, nj+2} (stored as 0..5), x in [0,TA)
-//   zh   [6][8][TA]    : z likewise
-template <int TA>
-struct GsTile {
-    static constexpr int RA = TA + 6;
-    static constexpr int CORE = 64 * RA;
-    static constexpr int YH = 8 * 6 * TA;
-    static constexpr int ZH = 6 * 8 * TA;
-    static constexpr int PS = 64 * TA; // phiS of the tile's own cells
-    static constexpr int TOTAL = CORE + YH + ZH + PS;
-};
-
-template <int TA, bool STRICT>
-__global__ __launch_bounds__(64) void k_reinit_gs_plane(const double* __restrict__ A, double* __restrict__ B,
-                                                        const double* __restrict__ phiS, int nx, int ny,
-                                                        int nz, int si, int sj, int sk,
-                                                        const uint32_t* __restrict__ tiles, int nTi, int nTj,
-                                                        int nTk, double dx, double h,
-                                                        double* __restrict__ partials,
-                                                        const int* __restrict__ done)
-{
-    using T = GsTile<TA>;
-    __shared__ double lds[T::TOTAL];
-    if (*done) return;
-
-    const int lane = threadIdx.x;
-    const uint32_t packed = tiles[blockIdx.x];
-    const int fA = packed & 0x3ff, fB = (packed >> 10) & 0x3ff, fC = (packed >> 20) & 0x3ff;
-    const int ti = si > 0 ? fA : nTi - 1 - fA;
-    const int tj = sj > 0 ? fB : nTj - 1 - fB;
-    const int tk = sk > 0 ? fC : nTk - 1 - fC;
-    const int i_lo = 1 + ti * TA, j_lo = 1 + tj * 8, k_lo = 1 + tk * 8;
-    const int ni = min(TA, nx - i_lo), nj = min(8, ny - j_lo), nk = min(8, nz - k_lo);
-    const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1);
-
-    double* core = lds;
-    double* yh = lds + T::CORE;
-    double* zh = lds + T::CORE + T::YH;
-    double* ps = lds + T::CORE + T::YH + T::ZH;
-
-    // ---- load ---------------------------------------------------------------------------
-    // value for global point (gi,gj,gk): B if it is an interior cell of an upstream tile, else A
-    auto fetch = [&](int gi, int gj, int gk) -> double {
-        if (gi < 0 || gi > nx || gj < 0 || gj > ny || gk < 0 || gk > nz) return 0.0;
-        const bool interior = gi >= 1 && gi <= nx - 1 && gj >= 1 && gj <= ny - 1 && gk >= 1 && gk <= nz - 1;
-        const bool up = (si > 0 ? gi < i_lo : gi >= i_lo + ni) || (sj > 0 ? gj < j_lo : gj >= j_lo + nj) ||
-                        (sk > 0 ? gk < k_lo : gk >= k_lo + nk);
-        const long g = gi + sx * gj + sxy * gk;
-        return (interior && up) ? B[g] : A[g];
-    };
-    for (int idx = lane; idx < T::CORE; idx += 64) {
-        const int x = idx % T::RA - 3, yz = idx / T::RA;
-        core[idx] = fetch(i_lo + x, j_lo + (yz & 7), k_lo + (yz >> 3));
-    }
-    for (int idx = lane; idx < T::YH; idx += 64) {
-        const int x = idx % TA, r = idx / TA, hy = r % 6, z = r / 6;
-        const int y = hy < 3 ? hy - 3 : nj + hy - 3;
-        yh[idx] = fetch(i_lo + x, j_lo + y, k_lo + z);
-    }
-    for (int idx = lane; idx < T::ZH; idx += 64) {
-        const int x = idx % TA, r = idx / TA, y = r & 7, hz = r >> 3;
-        const int z = hz < 3 ? hz - 3 : nk + hz - 3;
-        zh[idx] = fetch(i_lo + x, j_lo + y, k_lo + z);
-    }
-    for (int idx = lane; idx < T::PS; idx += 64) {
-        const int x = idx % TA, yz = idx / TA, yy = yz & 7, zz = yz >> 3;
-        ps[idx] = (x < ni && yy < nj && zz < nk) ? phiS[(long)(i_lo + x) + sx * (j_lo + yy) + sxy * (k_lo + zz)] : 0.0;
-    }
-    __syncthreads();
-
-    // ---- march ----------------------------------------------------------------------------
-    const int b = lane & 7, c = lane >> 3;          // frame coordinates of this lane's row
-    const bool row_ok = b < nj && c < nk;
-    const int y = sj > 0 ? b : nj - 1 - b;          // absolute offsets of the row
-    const int z = sk > 0 ? c : nk - 1 - c;
-    const int gj = j_lo + y, gk = k_lo + z;
-    const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
-    const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
-    double acc = 0.0;
-    const int nsteps = ni + nj + nk - 2;
-
-    auto lds_y = [&](int x, int yy) -> double { // value at (x, yy, z), yy possibly outside [0,nj)
-        if (yy >= 0 && yy < nj) return core[(z * 8 + yy) * T::RA + x + 3];
-        const int hy = yy < 0 ? yy + 3 : yy - nj + 3;
-        return yh[(z * 6 + hy) * TA + x];
-    };
-    auto lds_z = [&](int x, int zz) -> double {
-        if (zz >= 0 && zz < nk) return core[(zz * 8 + y) * T::RA + x + 3];
-        const int hz = zz < 0 ? zz + 3 : zz - nk + 3;
-        return zh[(hz * 8 + y) * TA + x];
-    };
-
-    for (int s = 0; s < nsteps; ++s) {
-        const int a = s - b - c;
-        const bool active = row_ok && a >= 0 && a < ni;
-        double newv = 0.0;
-        int x = 0;
-        if (active) {
-            x = si > 0 ? a : ni - 1 - a;
-            const double pS = ps[(z * 8 + y) * TA + x];
-            const int gi = i_lo + x;
-            const bool weno_ok = yz_weno && gi > 3 && gi < nx - 4;
-            double qx[7], qy[7], qz[7];
-            const double* row = &core[(z * 8 + y) * T::RA + x]; // row[m] = (x+m-3)
-#pragma unroll
-            for (int m = 0; m < 7; ++m) qx[m] = row[m];
-            if (weno_ok) {
-#pragma unroll
-                for (int m = 0; m < 7; ++m) {
-                    qy[m] = (m == 3) ? qx[3] : lds_y(x, y + m - 3);
-                    qz[m] = (m == 3) ? qx[3] : lds_z(x, z + m - 3);
-                }
-            } else {
-#pragma unroll
-                for (int m = 0; m < 7; ++m) { qy[m] = 0.0; qz[m] = 0.0; }
-                qy[2] = lds_y(x, y - 1); qy[3] = qx[3]; qy[4] = lds_y(x, y + 1);
-                qz[2] = lds_z(x, z - 1); qz[3] = qx[3]; qz[4] = lds_z(x, z + 1);
-            }
-            newv = cell_update<STRICT>(qx, qy, qz, weno_ok, pS, dx, inv_dx, floor2, h);
-            const double dlt = newv - qx[3];
-            acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
-        }
-        // one wavefront per tile: its LDS operations execute in program order, so the reads of this
-        // step are done before the write below; the fence makes the write visible to the next step
-        if (active) core[(z * 8 + y) * T::RA + x + 3] = newv;
-        __syncthreads();
-    }
-
-    // ---- write back -------------------------------------------------------------------------
-    for (int idx = lane; idx < 64 * TA; idx += 64) {
-        const int x = idx % TA, yz = idx / TA, yy = yz & 7, zz = yz >> 3;
-        if (x < ni && yy < nj && zz < nk)
-            B[(long)(i_lo + x) + sx * (j_lo + yy) + sxy * (k_lo + zz)] = core[(zz * 8 + yy) * T::RA + x + 3];
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) partials[ti + nTi * (tj + (long)nTj * tk)] = acc;
-}
-
-// =============================================================================================
-// Reinit, exact Gauss-Seidel ordering, lane-per-axis form ("quad" kernel).
-// =============================================================================================
-// The plane kernel above is latency bound: one lane evaluates all three axes of a cell (~750
-// instructions per marching step) and a lone wave issues an fp64 instruction only every ~8 cycles.
-// Here the x, y and z one-sided derivatives of a cell are computed by three lanes of a quad
+// Tile = TA x 4 x 4 cells (i x j x k), anchored at cell 1; tiles are released in tile-hyperplane order
+// (any schedule in which a cell's -1..-3 neighbours of the sweep frame are updated
+// before it and its +1..+3 neighbours after it equals the reference's in-place raster loops).
+// The x, y and z one-sided derivatives of a cell are computed by three lanes of a quad
 // (lane = 4*cell + axis, the 4th lane idles along), the three Godunov terms are exchanged with DPP
-// quad broadcasts, and a wave covers a 4x4 (j,k) cross-section: a marching step is ~3x shorter, the
-// skew ramp is 6 steps instead of 14, and there are 4x as many tiles per hyperplane to fill the
-// chip.  Same tile-hyperplane schedule, same ping-pong, same LDS image (with 4x4 cross-section).
+// quad broadcasts.  The 16 cells of a wave are the 4x4 (j,k) cross-section; cell (b,c) marches its
+// i-row with skew a = s - b - c in the SWEEP frame (reflected for negative directions), so the
+// neighbour (b-m,c) is always m cells ahead and (b+m,c) m cells behind: in-place Gauss-Seidel inside
+// the LDS image.  Ping-pong: old values come from A, already-new values of upstream tiles from B,
+// results go to B.  (A first version with one lane per cell and an 8x8 cross-section needed ~750
+// instructions per marching step and a 14-step skew ramp; a lone wave issues an fp64 instruction only
+// every ~8 cycles, so tile latency is what matters.)
+//
+// LDS image (doubles), ABSOLUTE orientation, star shaped (faces only):
+//   core [4][4][TA+6]  : x in [-3,TA+3) for the tile's own (y,z)
+//   yh   [4][6][TA]    : y in {-3,-2,-1, nj, nj+1, nj+2} (stored as 0..5), x in [0,TA)
+//   zh   [6][4][TA]    : z likewise
+//   ps   [4][4][TA]    : phiS of the tile's own cells
 template <int TA>
 struct QuadTile {
     static constexpr int RA = TA + 6;
