@@ -36,15 +36,17 @@ int fail(int code, const std::string& msg)
             return fail(LSF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
     } while (0)
 
-// tile length along i of the exact-GS reinit (quad) kernel; cross-section 4x4.  LSF_GS_TA=8|16|32 overrides.
+// Exact-GS tile geometry: TA cells along i (LSF_GS_TA=16|32), NY x 4 cells in the cross-section
+// (LSF_GS_NY=5: three lanes per cell, default; 4: four lanes per cell with one idle)
 int gs_ta()
 {
-    static int v = [] {
-        const char* e = getenv("LSF_GS_TA");
-        const int t = e ? atoi(e) : 16;
-        return (t == 8 || t == 16 || t == 32) ? t : 16;
-    }();
-    return v;
+    const char* e = getenv("LSF_GS_TA");
+    return (e && atoi(e) == 32) ? 32 : 16;
+}
+int gs_ny()
+{
+    const char* e = getenv("LSF_GS_NY");
+    return (e && atoi(e) == 4) ? 4 : 5;
 }
 constexpr int MM_TA = 32;      // tile length along i of the exact-GS min/max kernel
 constexpr int CHECK_EVERY = 8; // sweeps between host reads of the device stop flag
@@ -229,10 +231,10 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     const bool strict = (mode & LSF_ARITH_STRICT) != 0;
     if (order != LSF_ORDER_GS && order != LSF_ORDER_JACOBI) return fail(LSF_ERR_INVALID, "unknown ordering");
     if (!d_phi) return fail(LSF_ERR_INVALID, "phi is NULL");
-    if (order == LSF_ORDER_GS && gs_schedule() == 1)
+    if (order == LSF_ORDER_GS && gs_schedule() != 2)
         return reinit_slot_core(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done,
                                 rms_trace, trace_cap, st);
-    if (order == LSF_ORDER_GS && gs_schedule() == 2)
+    if (order == LSF_ORDER_GS)
         return reinit_flow_core(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done,
                                 rms_trace, trace_cap, st);
     Ctx& c = ctx();
@@ -252,19 +254,9 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     double* d_trace = (double*)c.slot[S_TRACE].p;
     HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
 
-    // sweep geometry
-    TileList* tl = nullptr;
-    int nTi = 0, nTj = 0, nTk = 0;
-    dim3 jgrid;
-    long n_sweep_part = 0;
-    if (order == LSF_ORDER_GS) {
-        nTi = cdiv(nx - 1, gs_ta()), nTj = cdiv(ny - 1, 4), nTk = cdiv(nz - 1, 4);
-        if ((rc = get_tiles(nTi, nTj, nTk, &tl))) return rc;
-        n_sweep_part = (long)nTj * nTk; // one RMS slot per (tj,tk) tile column
-    } else {
-        jgrid = dim3(cdiv(nx - 1, JAC_BX), cdiv(ny - 1, JAC_BY), cdiv(nz - 1, JAC_KC));
-        n_sweep_part = (long)jgrid.x * jgrid.y * jgrid.z;
-    }
+    // sweep geometry (Jacobi only from here on; the exact ordering returned above)
+    const dim3 jgrid(cdiv(nx - 1, JAC_BX), cdiv(ny - 1, JAC_BY), cdiv(nz - 1, JAC_KC));
+    const long n_sweep_part = (long)jgrid.x * jgrid.y * jgrid.z;
     const dim3 bgrid = bc_grid(nx + 1, ny + 1, nz + 1);
     const long n_bc_part = (long)bgrid.x * bgrid.y * bgrid.z;
     const long n_part = n_sweep_part + n_bc_part;
@@ -276,51 +268,17 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
     int host_ctl[3] = {0, 0, 0};
     prof_begin();
-    long launches_per_sweep = 1;
-    if (order == LSF_ORDER_GS) {
-        launches_per_sweep = 0;
-        for (size_t P = 0; P + 1 < tl->off.size(); ++P) launches_per_sweep += tl->off[P + 1] > tl->off[P];
-    }
+    const long launches_per_sweep = 1;
     for (int s = 0; s < max_sweeps; ++s) {
         const double* A = bufs[s & 1];
         double* B = bufs[(s + 1) & 1];
-        const int* sg = RASTER_SIGN[(first_raster + s) & 7];
         prof_mark(st);
-        if (order == LSF_ORDER_GS) {
-            hipLaunchKernelGGL(k_copy_walls, bgrid, dim3(64), 0, st, A, B, nx, ny, nz, ctl);
-            int nplanes = (int)tl->off.size() - 1;
-            // timing experiment only (results are wrong): all tiles in one launch = the pure work term
-            static const bool nodeps = getenv("LSF_GS_NODEPS_EXPERIMENT") != nullptr;
-            for (int P = 0; P < nplanes; ++P) {
-                int cnt = tl->off[P + 1] - tl->off[P];
-                if (nodeps) {
-                    if (P > 0) break;
-                    cnt = tl->off[nplanes];
-                }
-                if (cnt <= 0) continue;
-#define LSF_LAUNCH_QUAD(TA_, ST_)                                                                                  \
-    hipLaunchKernelGGL((k_reinit_gs_quad<TA_, ST_>), dim3(cnt), dim3(64), 0, st, A, B, d_phiS, nx, ny, nz, sg[0],   \
-                       sg[1], sg[2], tl->d + tl->off[P], nTi, nTj, nTk, dx, h, part, ctl)
-                const int ta = gs_ta();
-                if (strict) {
-                    if (ta == 8) LSF_LAUNCH_QUAD(8, true);
-                    else if (ta == 16) LSF_LAUNCH_QUAD(16, true);
-                    else LSF_LAUNCH_QUAD(32, true);
-                } else {
-                    if (ta == 8) LSF_LAUNCH_QUAD(8, false);
-                    else if (ta == 16) LSF_LAUNCH_QUAD(16, false);
-                    else LSF_LAUNCH_QUAD(32, false);
-                }
-#undef LSF_LAUNCH_QUAD
-            }
-        } else {
-            if (strict)
-                hipLaunchKernelGGL((k_reinit_jacobi<true>), jgrid, dim3(JAC_BX, JAC_BY), 0, st, A, B, d_phiS, bx, 1, 1,
-                                   1, nx, ny, nz, dx, h, part, ctl);
-            else
-                hipLaunchKernelGGL((k_reinit_jacobi<false>), jgrid, dim3(JAC_BX, JAC_BY), 0, st, A, B, d_phiS, bx, 1,
-                                   1, 1, nx, ny, nz, dx, h, part, ctl);
-        }
+        if (strict)
+            hipLaunchKernelGGL((k_reinit_jacobi<true>), jgrid, dim3(JAC_BX, JAC_BY), 0, st, A, B, d_phiS, bx, 1, 1, 1,
+                               nx, ny, nz, dx, h, part, ctl);
+        else
+            hipLaunchKernelGGL((k_reinit_jacobi<false>), jgrid, dim3(JAC_BX, JAC_BY), 0, st, A, B, d_phiS, bx, 1, 1, 1,
+                               nx, ny, nz, dx, h, part, ctl);
         prof_mark(st);
         hipLaunchKernelGGL(k_bc, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, dx,
                            part + n_sweep_part, ctl);
@@ -421,7 +379,7 @@ int get_order(int nTi, int nTj, int nTk, int first_dir, int ns, TileList* tl, Or
 
 // LSF_GS_SCHEDULE selects how the exact Gauss-Seidel tile graph is executed (all three are bit-identical):
 //   "slots"  (default) overlapped sweeps, one launch per time slot            reinit_slot_core
-//   "planes"           one launch per tile hyperplane of one sweep (simplest)   reinit_core
+//   "planes"           one launch per tile hyperplane, one sweep at a time     reinit_slot_core (no overlap)
 //   "flow"             persistent dataflow kernel with flag polling (experimental: correct, but the polling
 //                      waves slow the memory system down -- measurements in DESIGN.md)  reinit_flow_core
 int gs_schedule()
@@ -518,9 +476,9 @@ int reinit_flow_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         const unsigned grid = (unsigned)std::min<long>(ol->total, resident);
         prof_mark(st);
         if (strict)
-            hipLaunchKernelGGL((k_reinit_gs_flow<FLOW_TA, true, false>), dim3(grid), dim3(64), 0, st, fa);
+            hipLaunchKernelGGL((k_reinit_gs_flow<FLOW_TA, 4, true, false>), dim3(grid), dim3(64), 0, st, fa);
         else
-            hipLaunchKernelGGL((k_reinit_gs_flow<FLOW_TA, false, false>), dim3(grid), dim3(64), 0, st, fa);
+            hipLaunchKernelGGL((k_reinit_gs_flow<FLOW_TA, 4, false, false>), dim3(grid), dim3(64), 0, st, fa);
         prof_mark(st);
         prof_mark(st);
         prof_mark(st);
@@ -587,8 +545,9 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st));
         d_phiS = (const double*)c.slot[S_PHIS].p;
     }
-    const int ta = gs_ta() == 32 ? 32 : 16;
-    const int nTi = cdiv(nx - 1, ta), nTj = cdiv(ny - 1, 4), nTk = cdiv(nz - 1, 4);
+    const int ta = gs_ta(), nyc = gs_ny();
+    const bool overlap = gs_schedule() == 1; // "planes": one sweep at a time (start[g+1] = start[g] + nPlanes)
+    const int nTi = cdiv(nx - 1, ta), nTj = cdiv(ny - 1, nyc), nTk = cdiv(nz - 1, 4);
     const int nT[3] = {nTi, nTj, nTk};
     const int np = nTi + nTj + nTk - 2;
     TileList* tl = nullptr;
@@ -626,6 +585,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
                 if (da[ax] != db[ax]) H += nT[ax] - 1;
             long s0 = start[q - 1] + H;
             if (q >= 2) s0 = std::max(s0, start[q - 2] + np + 1);
+            if (!overlap) s0 = start[q - 1] + np;
             start.push_back(s0);
         }
         return start[g];
@@ -656,15 +616,21 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         while (lo < max_sweeps && start_of(lo) + np <= slot + 1) ++lo;
         const int grid = fa.seg_count[0] + fa.seg_count[1];
         if (grid > 0) {
-#define LSF_LAUNCH_SLOT(TA_, ST_) \
-    hipLaunchKernelGGL((k_reinit_gs_flow<TA_, ST_, true>), dim3(grid), dim3(64), 0, st, fa)
+#define LSF_LAUNCH_SLOT(TA_, NY_, ST_) \
+    hipLaunchKernelGGL((k_reinit_gs_flow<TA_, NY_, ST_, true>), dim3(grid), dim3(64), 0, st, fa)
+#define LSF_LAUNCH_SLOT_NY(TA_, ST_)           \
+    do {                                       \
+        if (nyc == 5) LSF_LAUNCH_SLOT(TA_, 5, ST_); \
+        else LSF_LAUNCH_SLOT(TA_, 4, ST_);     \
+    } while (0)
             if (strict) {
-                if (ta == 16) LSF_LAUNCH_SLOT(16, true);
-                else LSF_LAUNCH_SLOT(32, true);
+                if (ta == 16) LSF_LAUNCH_SLOT_NY(16, true);
+                else LSF_LAUNCH_SLOT_NY(32, true);
             } else {
-                if (ta == 16) LSF_LAUNCH_SLOT(16, false);
-                else LSF_LAUNCH_SLOT(32, false);
+                if (ta == 16) LSF_LAUNCH_SLOT_NY(16, false);
+                else LSF_LAUNCH_SLOT_NY(32, false);
             }
+#undef LSF_LAUNCH_SLOT_NY
 #undef LSF_LAUNCH_SLOT
             ++launches;
         }

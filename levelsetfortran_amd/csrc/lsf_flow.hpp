@@ -85,15 +85,43 @@ __device__ __forceinline__ void st_flag(int* p, int v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Tile geometry: TA cells along i, NY x 4 cells in the (j,k) cross-section.
+//   NY = 4: 16 cells per wave, 4 lanes per cell (x, y, z, idle), Godunov terms exchanged by DPP quad_perm
+//   NY = 5: 20 cells per wave, 3 lanes per cell inside each 16-lane row (5 cells + 1 idle lane),
+//           Godunov terms gathered at the x lane by DPP row_shl:1 / row_shl:2
+// LDS image (doubles), ABSOLUTE orientation, star shaped (faces only), x is the unit-stride index everywhere:
+//   core [4][NY][TA+6], y-halo [4][6][TA], z-halo [6][NY][TA], phiS [4][NY][TA]
+template <int TA, int NY>
+struct GsTile {
+    static constexpr int RA = TA + 6;
+    static constexpr int NCORE = 4 * NY;          // rows
+    static constexpr int CORE = NCORE * RA;
+    static constexpr int YH = 4 * 6 * TA;
+    static constexpr int ZH = 6 * NY * TA;
+    static constexpr int PS = NCORE * TA;
+    static constexpr int TOTAL = CORE + YH + ZH + PS;
+    static constexpr int NROWS = NCORE + 24 + 6 * NY + NCORE; // rows of TA doubles to load
+    static constexpr int R1 = NCORE, R2 = NCORE + 24, R3 = NCORE + 24 + 6 * NY;
+};
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 constexpr unsigned long long FLOW_TIMEOUT_TICKS = 400000000ull; // 4 s of the 100 MHz s_memrealtime clock
 
 // SLOT = false: persistent dataflow (ticket loop, flag polling, write-through hand-off).
 // SLOT = true : one block per task of one time slot; every predecessor ran in an earlier launch, so there is
 //               nothing to wait for and plain loads/stores suffice (kernel boundaries order them).
-template <int TA, bool STRICT, bool SLOT>
+template <int TA, int NY, bool STRICT, bool SLOT>
 __global__ __launch_bounds__(64) void k_reinit_gs_flow(FlowArgs a)
 {
-    using T = QuadTile<TA>;
+    using T = GsTile<TA, NY>;
     __shared__ double lds[T::TOTAL];
     const int lane = threadIdx.x;
     const int nx = a.nx, ny = a.ny, nz = a.nz;
@@ -180,78 +208,93 @@ __global__ __launch_bounds__(64) void k_reinit_gs_flow(FlowArgs a)
         const double* in = a.buf[g & 1];
         double* out = a.buf[(g + 1) & 1];
         const long dOI = out - in; // element offset that turns an `in` address into an `out` address
-        const int i_lo = 1 + ti * TA, j_lo = 1 + tj * 4, k_lo = 1 + tk * 4;
-        const int ni = min(TA, nx - i_lo), nj = min(4, ny - j_lo), nk = min(4, nz - k_lo);
+        const int i_lo = 1 + ti * TA, j_lo = 1 + tj * NY, k_lo = 1 + tk * 4;
+        const int ni = min(TA, nx - i_lo), nj = min(NY, ny - j_lo), nk = min(4, nz - k_lo);
         double* core = lds;
 
         // ---- load (see k_reinit_gs_quad); upstream interior cells from `out`, everything else from `in` ----
         {
-            constexpr int RPI = 64 / TA, NROW = 80 / RPI;
+            // Four row segments (core, y halo, z halo, phiS), each enumerated in whole wave instructions
+            // (64/TA rows each; a segment whose row count is not a multiple repeats its last row, harmless):
+            // the segment of every load is known at compile time, addresses are clamped into the array
+            // (clamped entries are never consumed), no branches, all loads in flight before the first LDS write.
+            constexpr int RPI = 64 / TA;
+            constexpr int U0 = (T::NCORE + RPI - 1) / RPI, U1 = (24 + RPI - 1) / RPI, U2 = (6 * NY + RPI - 1) / RPI;
+            constexpr int NROW = U0 + U1 + U2 + U0;
             const int xx = lane & (TA - 1), rsub = lane / TA;
             const int gi = min(i_lo + xx, nx);
             const bool gi_int = gi <= nx - 1;
             double v[NROW];
             int dst[NROW];
-#pragma unroll
-            for (int u = 0; u < NROW; ++u) {
-                const int r = u * RPI + rsub;
-                int gj, gk;
-                bool up = false;
-                const double* base = in;
-                if (u * RPI < 16) {
-                    const int zz = r >> 2, yy = r & 3;
-                    gj = j_lo + yy, gk = k_lo + zz;
-                    dst[u] = (zz * 4 + yy) * T::RA + 3 + xx;
-                } else if (u * RPI < 40) {
-                    const int q = r - 16, zz = q / 6, hy = q - 6 * zz;
-                    gj = j_lo + (hy < 3 ? hy - 3 : nj + hy - 3), gk = k_lo + zz;
-                    up = (hy < 3) == (sj > 0);
-                    dst[u] = T::CORE + q * TA + xx;
-                } else if (u * RPI < 64) {
-                    const int q = r - 40, hz = q >> 2, yy = q & 3;
-                    gj = j_lo + yy, gk = k_lo + (hz < 3 ? hz - 3 : nk + hz - 3);
-                    up = (hz < 3) == (sk > 0);
-                    dst[u] = T::CORE + T::YH + q * TA + xx;
-                } else {
-                    const int q = r - 64, zz = q >> 2, yy = q & 3;
-                    gj = j_lo + yy, gk = k_lo + zz;
-                    base = a.phiS;
-                    dst[u] = T::CORE + T::YH + T::ZH + q * TA + xx;
-                }
+            auto ld_row = [&](int u, int gj, int gk, bool up, bool from_phis) {
                 const bool row_int = gj >= 1 && gj <= ny - 1 && gk >= 1 && gk <= nz - 1;
                 gj = min(max(gj, 0), ny), gk = min(max(gk, 0), nz);
-                const long off = gi + sx * gj + sxy * gk + ((up && row_int && gi_int) ? dOI : 0);
-                if constexpr (SLOT) v[u] = base[off];
-                else v[u] = (u * RPI < 64 && !(a.knobs & 2)) ? ld_sc1(base + off) : base[off];
-            }
-            double vh[2];
-            int dh[2];
+                const long off = gi + sx * gj + sxy * gk;
+                const double* ptr = from_phis ? a.phiS + off : in + off + ((up && row_int && gi_int) ? dOI : 0);
+                if constexpr (SLOT) v[u] = *ptr;
+                else v[u] = (from_phis || (a.knobs & 2)) ? *ptr : ld_sc1(ptr);
+            };
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = min(lane + 64 * u, 95), row = idx / 6, ee = idx - 6 * row;
+            for (int u = 0; u < U0; ++u) { // core rows, own cells: old values
+                const int r = min(u * RPI + rsub, T::NCORE - 1), zz = r / NY, yy = r - NY * zz;
+                dst[u] = r * T::RA + 3 + xx;
+                ld_row(u, j_lo + yy, k_lo + zz, false, false);
+            }
+#pragma unroll
+            for (int u = 0; u < U1; ++u) { // y halo
+                const int q = min(u * RPI + rsub, 23), zz = q / 6, hy = q - 6 * zz;
+                dst[U0 + u] = T::CORE + q * TA + xx;
+                ld_row(U0 + u, j_lo + (hy < 3 ? hy - 3 : nj + hy - 3), k_lo + zz, (hy < 3) == (sj > 0), false);
+            }
+#pragma unroll
+            for (int u = 0; u < U2; ++u) { // z halo
+                const int q = min(u * RPI + rsub, 6 * NY - 1), hz = q / NY, yy = q - NY * hz;
+                dst[U0 + U1 + u] = T::CORE + T::YH + q * TA + xx;
+                ld_row(U0 + U1 + u, j_lo + yy, k_lo + (hz < 3 ? hz - 3 : nk + hz - 3), (hz < 3) == (sk > 0), false);
+            }
+#pragma unroll
+            for (int u = 0; u < U0; ++u) { // phiS of the own cells
+                const int q = min(u * RPI + rsub, T::NCORE - 1), zz = q / NY, yy = q - NY * zz;
+                dst[U0 + U1 + U2 + u] = T::CORE + T::YH + T::ZH + q * TA + xx;
+                ld_row(U0 + U1 + U2 + u, j_lo + yy, k_lo + zz, false, true);
+            }
+            // x halo of the core rows: entries x = -3..-1 and x = TA..TA+2 (6 per row)
+            constexpr int NXH = 6 * T::NCORE, NH = (NXH + 63) / 64;
+            double vh[NH];
+            int dh[NH];
+#pragma unroll
+            for (int u = 0; u < NH; ++u) {
+                const int idx = min(lane + 64 * u, NXH - 1), row = idx / 6, ee = idx - 6 * row;
                 const int x = ee < 3 ? ee - 3 : TA + ee - 3;
                 const int gih = min(max(i_lo + x, 0), nx);
-                const int gj = min(j_lo + (row & 3), ny), gk = min(k_lo + (row >> 2), nz);
+                const int zz = row / NY, yy = row - NY * zz;
+                const int gj = min(j_lo + yy, ny), gk = min(k_lo + zz, nz);
                 const bool interior = gih >= 1 && gih <= nx - 1 && gj <= ny - 1 && gk <= nz - 1;
                 const bool up = (ee < 3) ? (si > 0) : (si < 0 && ni == TA);
-                {
-                    const double* ph = in + gih + sx * gj + sxy * gk + ((up && interior) ? dOI : 0);
-                    if constexpr (SLOT) vh[u] = *ph;
-                    else vh[u] = (a.knobs & 2) ? *ph : ld_sc1(ph);
-                }
+                const double* ph = in + gih + sx * gj + sxy * gk + ((up && interior) ? dOI : 0);
+                if constexpr (SLOT) vh[u] = *ph;
+                else vh[u] = (a.knobs & 2) ? *ph : ld_sc1(ph);
                 dh[u] = row * T::RA + 3 + x;
             }
 #pragma unroll
             for (int u = 0; u < NROW; ++u) lds[dst[u]] = v[u];
-            lds[dh[0]] = vh[0];
-            if (lane + 64 < 96) lds[dh[1]] = vh[1];
+#pragma unroll
+            for (int u = 0; u < NH; ++u)
+                if (lane + 64 * u < NXH) lds[dh[u]] = vh[u];
         }
         __syncthreads();
 
         const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
         // ---- per-lane constants (as in the quad kernel) ------------------------------------------------
-        const int axis = lane & 3, cell = lane >> 2;
-        const int b = cell & 3, c = cell >> 2;
+        // lane -> (cell (b,c) of the NY x 4 cross-section, axis); see GsTile
+        int axis, b, c;
+        if constexpr (NY == 4) {
+            axis = lane & 3;
+            b = (lane >> 2) & 3, c = lane >> 4;
+        } else {
+            const int t = lane & 15;
+            b = t / 3, axis = t - 3 * b, c = lane >> 4; // t = 15: b = 5 >= nj, idle
+        }
         const bool row_ok = b < nj && c < nk;
         const int y = sj > 0 ? b : nj - 1 - b, z = sk > 0 ? c : nk - 1 - c;
         const int yc = row_ok ? y : 0, zc = row_ok ? z : 0;
@@ -259,18 +302,18 @@ __global__ __launch_bounds__(64) void k_reinit_gs_flow(FlowArgs a)
         const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
         const bool yquirk = axis == 1;
         int off[7];
-        const int row_core = (zc * 4 + yc) * T::RA + 3;
+        const int row_core = (zc * NY + yc) * T::RA + 3;
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
             const int d = m - 3;
             const int yy = yc + (axis == 1 ? d : 0), zz = zc + (axis == 2 ? d : 0), dxm = (axis == 1 || axis == 2) ? 0 : d;
             const bool in_y = yy >= 0 && yy < nj, in_z = zz >= 0 && zz < nk;
-            const int o_core = (zz * 4 + yy) * T::RA + 3 + dxm;
+            const int o_core = (zz * NY + yy) * T::RA + 3 + dxm;
             const int o_yh = T::CORE + (zc * 6 + (yy < 0 ? yy + 3 : yy - nj + 3)) * TA;
-            const int o_zh = T::CORE + T::YH + ((zz < 0 ? zz + 3 : zz - nk + 3) * 4 + yc) * TA;
+            const int o_zh = T::CORE + T::YH + ((zz < 0 ? zz + 3 : zz - nk + 3) * NY + yc) * TA;
             off[m] = !in_y ? o_yh : (!in_z ? o_zh : o_core);
         }
-        const int ps_row = T::CORE + T::YH + T::ZH + (zc * 4 + yc) * TA;
+        const int ps_row = T::CORE + T::YH + T::ZH + (zc * NY + yc) * TA;
         double acc = 0.0;
         const int nsteps = ni + nj + nk - 2;
 
@@ -289,7 +332,12 @@ __global__ __launch_bounds__(64) void k_reinit_gs_flow(FlowArgs a)
             double dm, dp;
             axis_pair<STRICT>(q, weno_ok, yquirk, dx, floor2, dm, dp);
             const double gg = axis_godunov<STRICT>(q[3], dm, dp);
-            const double gX = quad_bcast(gg, 0), gY = quad_bcast(gg, 1), gZ = quad_bcast(gg, 2);
+            double gX, gY, gZ; // valid on the axis-0 lane of every cell (on all lanes for NY = 4)
+            if constexpr (NY == 4) {
+                gX = dpp_mov<0x00>(gg), gY = dpp_mov<0x55>(gg), gZ = dpp_mov<0xAA>(gg); // quad_perm broadcasts
+            } else {
+                gX = gg, gY = dpp_mov<0x101>(gg), gZ = dpp_mov<0x102>(gg);               // row_shl:1, row_shl:2
+            }
             const double newv = finish_update<STRICT>(q[3], gX, gY, gZ, pS, dx, inv_dx, h);
             if (active && axis == 0) {
                 lds[row_core + x] = newv;
@@ -305,9 +353,9 @@ __global__ __launch_bounds__(64) void k_reinit_gs_flow(FlowArgs a)
             constexpr int RPI = 64 / TA;
             const int xx = lane & (TA - 1), rsub = lane / TA;
 #pragma unroll
-            for (int u = 0; u < 16 / RPI; ++u) {
-                const int r = u * RPI + rsub, zz = r >> 2, yy = r & 3;
-                if (xx < ni && yy < nj && zz < nk) {
+            for (int u = 0; u < (T::NCORE + RPI - 1) / RPI; ++u) {
+                const int r = u * RPI + rsub, zz = r / NY, yy = r - NY * zz;
+                if (r < T::NCORE && xx < ni && yy < nj && zz < nk) {
                     double* po = out + (long)(i_lo + xx) + sx * (j_lo + yy) + sxy * (k_lo + zz);
                     if (SLOT || (a.knobs & 8)) *po = core[r * T::RA + 3 + xx];
                     else st_sc1(po, core[r * T::RA + 3 + xx]);
@@ -329,7 +377,7 @@ __global__ __launch_bounds__(64) void k_reinit_gs_flow(FlowArgs a)
                 const int m = min(nb, 1 + nh);
                 const int cx = min(max(gi, 1), nx - 1) - i_lo, cy = min(max(gj2, 1), ny - 1) - j_lo,
                           cz = min(max(gk2, 1), nz - 1) - k_lo;
-                double val = core[(cz * 4 + cy) * T::RA + 3 + cx];
+                double val = core[(cz * NY + cy) * T::RA + 3 + cx];
                 {
 #pragma clang fp contract(off)
                     for (int t = 0; t < m; ++t) val = val + dx;

@@ -24,217 +24,6 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // =============================================================================================
-// Reinit, exact Gauss-Seidel ordering: one wavefront per tile, lane-per-axis ("quad") form.
-// =============================================================================================
-// Tile = TA x 4 x 4 cells (i x j x k), anchored at cell 1; tiles are released in tile-hyperplane order
-// (any schedule in which a cell's -1..-3 neighbours of the sweep frame are updated
-// before it and its +1..+3 neighbours after it equals the reference's in-place raster loops).
-// The x, y and z one-sided derivatives of a cell are computed by three lanes of a quad
-// (lane = 4*cell + axis, the 4th lane idles along), the three Godunov terms are exchanged with DPP
-// quad broadcasts.  The 16 cells of a wave are the 4x4 (j,k) cross-section; cell (b,c) marches its
-// i-row with skew a = s - b - c in the SWEEP frame (reflected for negative directions), so the
-// neighbour (b-m,c) is always m cells ahead and (b+m,c) m cells behind: in-place Gauss-Seidel inside
-// the LDS image.  Ping-pong: old values come from A, already-new values of upstream tiles from B,
-// results go to B.  (A first version with one lane per cell and an 8x8 cross-section needed ~750
-// instructions per marching step and a 14-step skew ramp; a lone wave issues an fp64 instruction only
-// every ~8 cycles, so tile latency is what matters.)
-//
-// LDS image (doubles), ABSOLUTE orientation, star shaped (faces only):
-//   core [4][4][TA+6]  : x in [-3,TA+3) for the tile's own (y,z)
-//   yh   [4][6][TA]    : y in {-3,-2,-1, nj, nj+1, nj+2} (stored as 0..5), x in [0,TA)
-//   zh   [6][4][TA]    : z likewise
-//   ps   [4][4][TA]    : phiS of the tile's own cells
-template <int TA>
-struct QuadTile {
-    static constexpr int RA = TA + 6;
-    static constexpr int CORE = 16 * RA;     // [4 z][4 y][RA]
-    static constexpr int YH = 4 * 6 * TA;    // [4 z][6][TA]
-    static constexpr int ZH = 6 * 4 * TA;    // [6][4 y][TA]
-    static constexpr int PS = 16 * TA;       // [4 z][4 y][TA]
-    static constexpr int TOTAL = CORE + YH + ZH + PS;
-};
-
-__device__ __forceinline__ double quad_bcast(double v, int which)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    if (which == 1) {
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x55, 0xf, 0xf, false); // quad_perm:[1,1,1,1]
-        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x55, 0xf, 0xf, false);
-    } else if (which == 2) {
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xAA, 0xf, 0xf, false); // quad_perm:[2,2,2,2]
-        hi = __builtin_amdgcn_update_dpp(hi, hi, 0xAA, 0xf, 0xf, false);
-    } else {
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x00, 0xf, 0xf, false); // quad_perm:[0,0,0,0]
-        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x00, 0xf, 0xf, false);
-    }
-    return __hiloint2double(hi, lo);
-}
-
-template <int TA, bool STRICT>
-__global__ __launch_bounds__(64) void k_reinit_gs_quad(const double* __restrict__ A, double* __restrict__ B,
-                                                       const double* __restrict__ phiS, int nx, int ny, int nz,
-                                                       int si, int sj, int sk, const uint32_t* __restrict__ tiles,
-                                                       int nTi, int nTj, int nTk, double dx, double h,
-                                                       double* __restrict__ partials,
-                                                       const int* __restrict__ done)
-{
-    using T = QuadTile<TA>;
-    __shared__ double lds[T::TOTAL];
-    if (*done) return;
-
-    const int lane = threadIdx.x;
-    const uint32_t packed = tiles[blockIdx.x];
-    const int fA = packed & 0x3ff, fB = (packed >> 10) & 0x3ff, fC = (packed >> 20) & 0x3ff;
-    const int ti = si > 0 ? fA : nTi - 1 - fA;
-    const int tj = sj > 0 ? fB : nTj - 1 - fB;
-    const int tk = sk > 0 ? fC : nTk - 1 - fC;
-    const int i_lo = 1 + ti * TA, j_lo = 1 + tj * 4, k_lo = 1 + tk * 4;
-    const int ni = min(TA, nx - i_lo), nj = min(4, ny - j_lo), nk = min(4, nz - k_lo);
-    const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1);
-
-    double* core = lds;
-
-    // ---- load -----------------------------------------------------------------------------------------
-    // Old values come from A, values of upstream tiles from B (the caller has copied the wall points of A
-    // into B, so "upstream" needs no interior test).  The image is 80 rows of TA contiguous doubles
-    // (16 core + 24 y-halo + 24 z-halo + 16 phiS) plus the 6 x-halo entries of the 16 core rows.  A wave
-    // instruction loads 64/TA whole rows; which segment a row belongs to is known at compile time, all
-    // addresses are clamped into the array (clamped entries are never consumed), no branches, and every
-    // load of a lane is in flight before the first LDS write.
-    {
-        constexpr int RPI = 64 / TA;              // rows per wave instruction
-        constexpr int NROW = 80 / RPI;            // unrolled row loads per lane
-        const int xx = lane & (TA - 1), rsub = lane / TA;
-        const long dBA = B - A;                   // element offset that turns an A address into a B address
-        const int gi = min(i_lo + xx, nx);
-        double v[NROW];
-        int dst[NROW];
-#pragma unroll
-        for (int u = 0; u < NROW; ++u) {
-            const int r = u * RPI + rsub;         // row id; u*RPI selects the segment at compile time
-            int gj, gk;
-            long sel = 0;
-            const double* base = A;
-            if (u * RPI < 16) {                   // core rows, own cells: old values
-                const int zz = r >> 2, yy = r & 3;
-                gj = j_lo + yy, gk = k_lo + zz;
-                dst[u] = (zz * 4 + yy) * T::RA + 3 + xx;
-            } else if (u * RPI < 40) {            // y halo
-                const int q = r - 16, zz = q / 6, hy = q - 6 * zz;
-                gj = j_lo + (hy < 3 ? hy - 3 : nj + hy - 3), gk = k_lo + zz;
-                sel = ((hy < 3) == (sj > 0)) ? dBA : 0;
-                dst[u] = T::CORE + q * TA + xx;
-            } else if (u * RPI < 64) {            // z halo
-                const int q = r - 40, hz = q >> 2, yy = q & 3;
-                gj = j_lo + yy, gk = k_lo + (hz < 3 ? hz - 3 : nk + hz - 3);
-                sel = ((hz < 3) == (sk > 0)) ? dBA : 0;
-                dst[u] = T::CORE + T::YH + q * TA + xx;
-            } else {                              // phiS of the own cells
-                const int q = r - 64, zz = q >> 2, yy = q & 3;
-                gj = j_lo + yy, gk = k_lo + zz;
-                base = phiS;
-                dst[u] = T::CORE + T::YH + T::ZH + q * TA + xx;
-            }
-            gj = min(max(gj, 0), ny), gk = min(max(gk, 0), nz);
-            v[u] = base[gi + sx * gj + sxy * gk + sel];
-        }
-        // x halo of the 16 core rows: entries x = -3..-1 and x = TA..TA+2 (6 per row, 96 in all)
-        double vh[2];
-        int dh[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = min(lane + 64 * u, 95), row = idx / 6, e = idx - 6 * row;
-            const int x = e < 3 ? e - 3 : TA + e - 3;
-            const int gih = min(max(i_lo + x, 0), nx);
-            const int gj = min(j_lo + (row & 3), ny), gk = min(k_lo + (row >> 2), nz);
-            // low side is upstream for si > 0, high side for si < 0; beyond a partial tile there is only wall
-            const bool up = (e < 3) ? (si > 0) : (si < 0 && ni == TA);
-            vh[u] = A[gih + sx * gj + sxy * gk + (up ? dBA : 0)];
-            dh[u] = row * T::RA + 3 + x;
-        }
-#pragma unroll
-        for (int u = 0; u < NROW; ++u) lds[dst[u]] = v[u];
-        lds[dh[0]] = vh[0];
-        if (lane + 64 < 96) lds[dh[1]] = vh[1];
-    }
-    __syncthreads();
-
-    // ---- per-lane constants --------------------------------------------------------------------
-    const int axis = lane & 3;                    // 0:x 1:y 2:z 3:idle (mirrors x, contributes nothing)
-    const int cell = lane >> 2;
-    const int b = cell & 3, c = cell >> 2;        // frame coordinates of the cell's row
-    const bool row_ok = b < nj && c < nk;
-    const int y = sj > 0 ? b : nj - 1 - b;        // absolute offsets of the row (garbage-safe if !row_ok)
-    const int z = sk > 0 ? c : nk - 1 - c;
-    const int yc = row_ok ? y : 0, zc = row_ok ? z : 0;
-    const int gj = j_lo + yc, gk = k_lo + zc;
-    const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
-    const bool yquirk = axis == 1;
-    // LDS element offset (at x = 0) of stencil entry m = 0..6 along this lane's axis; all arrays have x
-    // as the unit-stride index, so entry m at position x is lds[off[m] + x]
-    int off[7];
-    const int row_core = (zc * 4 + yc) * T::RA + 3;
-#pragma unroll
-    for (int m = 0; m < 7; ++m) { // branch-free: the three candidates are cheap integer expressions
-        const int d = m - 3;
-        const int yy = yc + (axis == 1 ? d : 0), zz = zc + (axis == 2 ? d : 0), dxm = (axis == 1 || axis == 2) ? 0 : d;
-        const bool in_y = yy >= 0 && yy < nj, in_z = zz >= 0 && zz < nk;
-        const int o_core = (zz * 4 + yy) * T::RA + 3 + dxm;
-        const int o_yh = T::CORE + (zc * 6 + (yy < 0 ? yy + 3 : yy - nj + 3)) * TA;
-        const int o_zh = T::CORE + T::YH + ((zz < 0 ? zz + 3 : zz - nk + 3) * 4 + yc) * TA;
-        off[m] = !in_y ? o_yh : (!in_z ? o_zh : o_core);
-    }
-    const int ps_row = T::CORE + T::YH + T::ZH + (zc * 4 + yc) * TA;
-    const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
-    double acc = 0.0;
-    const int nsteps = ni + nj + nk - 2;
-
-    // ---- march ------------------------------------------------------------------------------------
-    for (int s = 0; s < nsteps; ++s) {
-        const int a = s - b - c;
-        const bool active = row_ok && a >= 0 && a < ni;
-        const int ac = active ? a : 0;
-        const int x = si > 0 ? ac : ni - 1 - ac;
-        double q[7];
-#pragma unroll
-        for (int m = 0; m < 7; ++m) q[m] = lds[off[m] + x];
-        const double pS = lds[ps_row + x];
-        const int gi = i_lo + x;
-        const bool weno_ok = yz_weno && gi > 3 && gi < nx - 4;
-        double dm, dp;
-        axis_pair<STRICT>(q, weno_ok, yquirk, dx, floor2, dm, dp);
-        const double g = axis_godunov<STRICT>(q[3], dm, dp);
-        const double gX = quad_bcast(g, 0), gY = quad_bcast(g, 1), gZ = quad_bcast(g, 2);
-        const double newv = finish_update<STRICT>(q[3], gX, gY, gZ, pS, dx, inv_dx, h);
-        if (active && axis == 0) {
-            lds[row_core + x] = newv;
-            const double dlt = newv - q[3];
-            acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
-        }
-        __syncthreads(); // single wave: an LDS fence; step s+1 reads what step s wrote
-    }
-
-    // ---- write back + RMS partial ------------------------------------------------------------------
-    {
-        constexpr int RPI = 64 / TA;
-        const int xx = lane & (TA - 1), rsub = lane / TA;
-#pragma unroll
-        for (int u = 0; u < 16 / RPI; ++u) {
-            const int r = u * RPI + rsub, zz = r >> 2, yy = r & 3;
-            if (xx < ni && yy < nj && zz < nk)
-                B[(long)(i_lo + xx) + sx * (j_lo + yy) + sxy * (k_lo + zz)] = core[r * T::RA + 3 + xx];
-        }
-    }
-    acc = wave_sum(acc);
-    // one RMS slot per (tj,tk) column: the tiles of a column lie on different hyperplanes, i.e. in
-    // different launches, visited in a fixed order -> deterministic accumulation without atomics
-    if (lane == 0) {
-        double* slot = &partials[tj + (long)nTj * tk];
-        *slot = (fA == 0) ? acc : *slot + acc;
-    }
-}
-
-// =============================================================================================
 // Reinit, Jacobi ordering on a box region.  Thread (i,j) marches KC cells in k with a 7-deep
 // register window; x/y neighbours come through the vector L1/L2.
 // =============================================================================================
@@ -356,27 +145,6 @@ __global__ __launch_bounds__(64) void k_bc(const double* __restrict__ A, double*
     }
     contrib = wave_sum(contrib);
     if (threadIdx.x == 0) partials[blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)] = contrib;
-}
-
-// =============================================================================================
-// Copy the wall points of A into B (same grid/ownership as k_bc).  The exact-GS tile loader reads the
-// already-updated side of a tile from B; with the walls mirrored it needs no interior test.
-// =============================================================================================
-__global__ __launch_bounds__(64) void k_copy_walls(const double* __restrict__ A, double* __restrict__ Bout, int nx,
-                                                   int ny, int nz, const int* __restrict__ done)
-{
-    if (done && *done) return;
-    const int face = blockIdx.z, axis = face >> 1;
-    const int u = blockIdx.x * 64 + threadIdx.x, v = blockIdx.y;
-    const int n[3] = {nx, ny, nz};
-    const int a1 = axis == 0 ? 1 : 0, a2 = axis == 2 ? 1 : 2;
-    if (u > n[a1] || v > n[a2]) return;
-    int l[3];
-    l[axis] = (face & 1) ? n[axis] : 0;
-    l[a1] = u;
-    l[a2] = v;
-    const long p = l[0] + (long)(nx + 1) * (l[1] + (long)(ny + 1) * l[2]);
-    Bout[p] = A[p];
 }
 
 // =============================================================================================

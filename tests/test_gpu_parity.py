@@ -284,6 +284,27 @@ def test_minmax_tile_wavefront_path(lsf, oracle, cube40, monkeypatch):
     test_minmax_vs_oracle_other_shapes(lsf, oracle)
 
 
+@pytest.mark.parametrize("geometry", [("4", "16"), ("5", "32"), ("4", "32")])
+def test_reinit_alternative_tile_geometries(lsf, oracle, synth, monkeypatch, geometry):
+    """Default tiles are 16 x 5 x 4 cells with three lanes per cell; 4-lane cells and 32-long tiles are kept."""
+    from levelsetfortran_amd import fields
+
+    monkeypatch.setenv("LSF_GS_NY", geometry[0])
+    monkeypatch.setenv("LSF_GS_TA", geometry[1])
+    nx, ny, nz = _n(synth)
+    phi = F(synth["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, 15, float(synth["dx"]), float(synth["h"]), arith="strict")
+    assert rep.count == 16 and np.array_equal(phi, synth["phi_16"])
+    npts = (70, 21, 45)
+    phi0, dx = fields.sphere_phi0(npts, radius=0.7, centers=((0.1, -0.2, 0.05),))
+    h = fields.reinit_step(dx)
+    ref = phi0.copy(order="F")
+    oracle.reinit(ref, 69, 20, 44, 9, dx, h, tol=0.0)
+    got = phi0.copy(order="F")
+    lsf.reinit(got, None, None, 69, 20, 44, 9, dx, h, tol=0.0, arith="strict")
+    assert np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("schedule", ["planes", "flow"])
 def test_reinit_alternative_schedules(lsf, synth, cube40, monkeypatch, schedule):
     """The exact-GS tile graph has three executors (LSF_GS_SCHEDULE): overlapped slot launches (default, used by
