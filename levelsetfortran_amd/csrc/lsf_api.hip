@@ -600,10 +600,13 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     for (long slot = 0; !stop && lo < max_sweeps; ++slot) {
         int nseg = 0;
         fa.seg_count[0] = fa.seg_count[1] = 0;
+        // timing experiment only (results are wrong): every tile of a sweep in ONE launch = the pure work term
+        static const bool nodeps = getenv("LSF_GS_NODEPS_EXPERIMENT") != nullptr;
         for (int g = lo; g < max_sweeps && start_of(g) <= slot; ++g) {
             const long P = slot - start_of(g);
             if (P >= np) continue;
-            const int cnt = tl->off[P + 1] - tl->off[P];
+            int cnt = tl->off[P + 1] - tl->off[P];
+            if (nodeps) cnt = P == 0 ? tl->off[np] : 0;
             if (cnt <= 0) continue;
             if (nseg == 2) return fail(LSF_ERR_HIP, "internal: more than two sweeps in flight");
             fa.seg_tiles[nseg] = tl->d + tl->off[P];

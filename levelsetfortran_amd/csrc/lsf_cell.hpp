@@ -135,30 +135,35 @@ __device__ __forceinline__ double rcp_nr(double x)
     return __builtin_fma(r, e, r);
 }
 
-// smoothness indicator (13 (x-y)^2 + 3 t^2) / 13 with t supplied by the caller.  Only ratios of
-// (eps + IS) enter the weights, so the common factor 1/13 is folded into the epsilon constants.
-__device__ __forceinline__ double is_form(double diff, double t)
-{
-    return __builtin_fma(diff, diff, (3.0 / 13.0) * (t * t));
-}
-
 // One axis, unscaled: returns dm*dx and dp*dx (the caller multiplies by 1/dx once).
 // floor2 = 1e-99 * dx^2 / 13 (the reference's epsilon floor in unscaled units, /13 like the IS).
+//
+// Algebra used (same mathematics as subs.f90:509-552, fewer operations):
+//  * the six smoothness indicators need only four distinct differences of second differences,
+//    e.g. IS1m uses (bm-cm)^2 = (cp-bm)^2, which IS2p already has;
+//  * with q_k = eps + IS_k the weights are w0 = n0/D, w2 = 3 m2/D, n0 = (q1 q2)^2, n1 = (q0 q2)^2,
+//    m2 = (q0 q1)^2, D = n0 + 6 n1 + 3 m2 (one reciprocal per side), and the correction term is
+//        PW = 1/3 w0 (a-2b+c) + 1/6 (w2 - 1/2) (b-2c+d) = r (n0/3 Sa + m2/2 S0) - S0/12,   r = 1/D,
+//    so the weights themselves are never formed.
 __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2, bool yquirk, double& dm,
                                                double& dp)
 {
     // first differences d_k = q[k+1]-q[k]  (p_k * dx)
     const double d0 = q[1] - q[0], d1 = q[2] - q[1], d2 = q[3] - q[2];
     const double d3 = q[4] - q[3], d4 = q[5] - q[4], d5 = q[6] - q[5];
-    // second differences (ap,bp,cp,bm,am)*dx
+    // second differences (am,bm,cp,bp,ap)*dx
     const double am = d1 - d0, bm = d2 - d1, cp = d3 - d2, bp = d4 - d3, ap = d5 - d4;
-
-    const double IS0p = is_form(ap - bp, __builtin_fma(-3.0, bp, ap));
-    const double IS0m = is_form(am - bm, __builtin_fma(-3.0, bm, am));
-    const double IS1p = is_form(bp - cp, bp + cp);
-    const double IS1m = is_form(bm - cp, bm + cp);
-    const double IS2p = is_form(cp - bm, __builtin_fma(3.0, cp, -bm));
-    const double IS2m = is_form(cp - bp, __builtin_fma(3.0, cp, -bp));
+    // the four distinct differences and their squares
+    const double e_ab = ap - bp, e_bc = bp - cp, e_cm = cp - bm, e_mm = am - bm;
+    const double s_ab = e_ab * e_ab, s_bc = e_bc * e_bc, s_cm = e_cm * e_cm, s_mm = e_mm * e_mm;
+    constexpr double K = 3.0 / 13.0;
+    auto isf = [](double sq, double t) { return __builtin_fma(K * t, t, sq); }; // (13 e^2 + 3 t^2)/13
+    const double IS0p = isf(s_ab, __builtin_fma(-3.0, bp, ap));
+    const double IS1p = isf(s_bc, bp + cp);
+    const double IS2p = isf(s_cm, __builtin_fma(3.0, cp, -bm));
+    const double IS0m = isf(s_mm, __builtin_fma(-3.0, bm, am));
+    const double IS1m = isf(s_cm, bm + cp);
+    const double IS2m = isf(s_bc, __builtin_fma(3.0, cp, -bp));
 
     // eps = 1e-6 max(p^2) + 1e-99 (subs.f90:533-534), in unscaled units and divided by 13 like the IS;
     // max of squares = square of the max magnitude (|x| is a free source modifier)
@@ -169,33 +174,27 @@ __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2,
     const double epsp = __builtin_fma((1.E-6 / 13.0) * mp, mp, floor2);
     const double epsm = __builtin_fma((1.E-6 / 13.0) * mm, mm, floor2);
 
-    // alpha_k = c_k / q_k^2, w_k = alpha_k / sum  ->  w0 = (q1 q2)^2 / D, w2 = 3 (q0 q1)^2 / D,
-    // D = (q1 q2)^2 + 6 (q0 q2)^2 + 3 (q0 q1)^2 : one reciprocal per side
-    double w0p, w2p, w0m, w2m;
+    const double S0 = e_bc - e_cm;  // bp - 2cp + bm   (= b-2c+d on both sides)
+    const double S12 = S0 * (1.0 / 12.0);
+    double PWp, PWm;
     {
         const double q0 = epsp + IS0p, q1 = epsp + IS1p, q2 = epsp + IS2p;
         const double t12 = q1 * q2, t02 = q0 * q2, t01 = q0 * q1;
-        const double n0 = t12 * t12, n1 = t02 * t02, n2 = 3.0 * (t01 * t01);
-        const double D = __builtin_fma(6.0, n1, n0) + n2;
+        const double n0 = t12 * t12, n1 = t02 * t02, m2 = t01 * t01;
+        const double D = __builtin_fma(3.0, m2, __builtin_fma(6.0, n1, n0));
         const double r = rcp_nr(__builtin_fmax(D, 1e-300));
-        w0p = n0 * r;
-        w2p = n2 * r;
+        const double Sa = e_ab - e_bc; // ap - 2bp + cp
+        PWp = __builtin_fma(r, __builtin_fma(n0 * (1.0 / 3.0), Sa, (m2 * 0.5) * S0), -S12);
     }
     {
         const double q0 = epsm + IS0m, q1 = epsm + IS1m, q2 = epsm + IS2m;
         const double t12 = q1 * q2, t02 = q0 * q2, t01 = q0 * q1;
-        const double n0 = t12 * t12, n1 = t02 * t02, n2 = 3.0 * (t01 * t01);
-        const double D = __builtin_fma(6.0, n1, n0) + n2;
+        const double n0 = t12 * t12, n1 = t02 * t02, m2 = t01 * t01;
+        const double D = __builtin_fma(3.0, m2, __builtin_fma(6.0, n1, n0));
         const double r = rcp_nr(__builtin_fmax(D, 1e-300));
-        w0m = n0 * r;
-        w2m = n2 * r;
+        const double Sa = e_mm + e_cm; // am - 2bm + cp = (am-bm) - (bm-cp)
+        PWm = __builtin_fma(r, __builtin_fma(n0 * (1.0 / 3.0), Sa, (m2 * 0.5) * S0), -S12);
     }
-    // (ap-2bp+cp), (bp-2cp+bm), (am-2bm+cp)
-    const double Sp = (ap - bp) - (bp - cp);
-    const double S0 = (bp - cp) - (cp - bm);
-    const double Sm = (am - bm) - (bm - cp);
-    const double PWp = __builtin_fma((1.0 / 3.0) * w0p, Sp, (1.0 / 6.0) * (w2p - 0.5) * S0);
-    const double PWm = __builtin_fma((1.0 / 3.0) * w0m, Sm, (1.0 / 6.0) * (w2m - 0.5) * S0);
     const double cen = (1.0 / 12.0) * (7.0 * (d2 + d3) - (d1 + d4));
     dm = cen - PWm;
     dp = cen + PWp;
