@@ -130,6 +130,17 @@ int lsf_phi0_device(double *d_phi, int nx, int ny, int nz, double dx, const doub
                     const double minX[3], const double maxX[3], const double *surfX, int nSurfNode,
                     const int32_t *surfElem, int nSurfElem, void *stream);
 
+/* ---- post-smoothing gradients + surface-node advection (the step after the hot path) ----------
+ * Replaces set3d.f90:470-501: firstDeriv order 8 (subs.f90:309-347, with its
+ * quirks) on the cells of phiSB, then every surface node is moved by x += phiSurf * gradPhiSurf with
+ * setPhiSurf's trilinear interpolation (subs.f90:1056-1170) until phiSurf <= 1e-13 or `iters` (host: 1000)
+ * passes.  surfXX is the host's REAL surfXX(nSurfNode,3) (Fortran-ordered HOST array), in = the nodes,
+ * out = the advected nodes.  Bit-identical to the reference. */
+int lsf_advect_nodes(const double *phi, const int32_t *phiSB, int nx, int ny, int nz, double dx,
+                     const double xLo[3], double *surfXX, int nSurfNode, int iters);
+int lsf_advect_nodes_device(const double *d_phi, const int32_t *d_phiSB, int nx, int ny, int nz, double dx,
+                            const double xLo[3], double *surfXX, int nSurfNode, int iters, void *stream);
+
 /* ---- block-decomposed building blocks (multi-GPU Jacobi; one process per GPU) -------------
  * A rank holds a box of the global field: local extents (lx,ly,lz), whose element (0,0,0) is the
  * global point (gx0,gy0,gz0); global extents are (nx+1,ny+1,nz+1).  The box includes ghost layers

@@ -2,7 +2,7 @@
 WENO5 Hamilton-Jacobi signed-distance reinitialisation and min/max-flow smoothing on a uniform 3-D
 grid, behind the reference's own procedure interface (see levelset.py, include/lsf.h).
 """
-from .levelset import (LsfError, LsfNaNError, SweepReport, minmaxFlow, mode_word, narrowBand, phi0Init,  # noqa: F401
+from .levelset import (LsfError, LsfNaNError, SweepReport, advectNodes, minmaxFlow, mode_word, narrowBand, phi0Init,  # noqa: F401
                        reinit)
 from . import fields  # noqa: F401
 

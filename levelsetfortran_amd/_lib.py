@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, c_double, c_int, c_int32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblsf_hip.so")
+LIB_PATH = os.environ.get("LSF_LIB_PATH") or os.path.join(_HERE, "liblsf_hip.so")  # override: experiments only
 
 # include/lsf.h
 LSF_OK, LSF_ERR_NAN, LSF_ERR_INVALID, LSF_ERR_HIP, LSF_ERR_NO_DEVICE = 0, 1, 2, 3, 4
@@ -61,6 +61,9 @@ SIGNATURES = {
                          c_void_p, c_int]),
     "lsf_phi0_device": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_int, c_void_p]),
+    "lsf_advect_nodes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_int, c_int]),
+    "lsf_advect_nodes_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_int,
+                                        c_int, c_void_p]),
     "lsf_jacobi_sweep_box": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3,
                                      c_double, c_double, c_int, c_void_p, c_void_p]),
     "lsf_bc_box": (c_int, [c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_double, c_void_p,

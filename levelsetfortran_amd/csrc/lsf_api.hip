@@ -61,7 +61,7 @@ struct TileList {
     std::vector<int> off; // plane offsets, size nplanes+1
 };
 
-enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_FLAGS, S_FLOWCTL, S_COLSUM, S_ORDER, S_NSLOTS };
+enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_FLAGS, S_FLOWCTL, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_NSLOTS };
 
 struct Ctx {
     Buf slot[S_NSLOTS];
@@ -1076,6 +1076,57 @@ int lsf_phi0(double* phi, int nx, int ny, int nz, double dx, const double xLo[3]
     if (rc) return rc;
     HIPCHK(hipMemcpy(phi, c.slot[S_HPHI].p, bytes, hipMemcpyDeviceToHost));
     return LSF_OK;
+}
+
+int lsf_advect_nodes_device(const double* d_phi, const int32_t* d_phiSB, int nx, int ny, int nz, double dx,
+                            const double xLo[3], double* surfXX, int nSurfNode, int iters, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = check_dims(nx, ny, nz))) return rc;
+    if (!d_phi || !d_phiSB || !xLo || !surfXX) return fail(LSF_ERR_INVALID, "NULL pointer");
+    if (nSurfNode < 1 || iters < 0) return fail(LSF_ERR_INVALID, "bad node count / iteration count");
+    hipStream_t st = (hipStream_t)stream;
+    Ctx& c = ctx();
+    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    // every node must sit in a cell whose 8 corners exist (the reference would read outside phi otherwise)
+    for (int q = 0; q < nSurfNode; ++q)
+        for (int ax = 0; ax < 3; ++ax) {
+            const double v = surfXX[(size_t)q + (size_t)nSurfNode * ax];
+            const int nn = ax == 0 ? nx : (ax == 1 ? ny : nz);
+            if (!(v >= xLo[ax] && v < xLo[ax] + dx * (nn - 1)))
+                return fail(LSF_ERR_INVALID, "surface node outside the grid");
+        }
+    if ((rc = ws(c.slot[S_GRAD], 3 * n * sizeof(double)))) return rc;
+    if ((rc = ws(c.slot[S_NODES], (size_t)nSurfNode * 3 * sizeof(double)))) return rc;
+    double* grad = (double*)c.slot[S_GRAD].p;
+    double* nodes = (double*)c.slot[S_NODES].p;
+    HIPCHK(hipMemcpyAsync(nodes, surfXX, (size_t)nSurfNode * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_firstderiv8, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, st, d_phi,
+                       d_phiSB, grad, nx, ny, nz, dx);
+    hipLaunchKernelGGL(k_advect_nodes, dim3((unsigned)cdiv(nSurfNode, 64)), dim3(64), 0, st, d_phi, (const double*)grad,
+                       nx, ny, nz, dx, xLo[0], xLo[1], xLo[2], nodes, nSurfNode, iters);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(surfXX, nodes, (size_t)nSurfNode * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return LSF_OK;
+}
+
+int lsf_advect_nodes(const double* phi, const int32_t* phiSB, int nx, int ny, int nz, double dx, const double xLo[3],
+                     double* surfXX, int nSurfNode, int iters)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = check_dims(nx, ny, nz))) return rc;
+    if (!phi || !phiSB) return fail(LSF_ERR_INVALID, "NULL field");
+    Ctx& c = ctx();
+    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    if ((rc = ws(c.slot[S_HPHI], n * sizeof(double)))) return rc;
+    if ((rc = ws(c.slot[S_HSB], n * sizeof(int32_t)))) return rc;
+    HIPCHK(hipMemcpy(c.slot[S_HPHI].p, phi, n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c.slot[S_HSB].p, phiSB, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    return lsf_advect_nodes_device((const double*)c.slot[S_HPHI].p, (const int32_t*)c.slot[S_HSB].p, nx, ny, nz, dx, xLo,
+                                   surfXX, nSurfNode, iters, nullptr);
 }
 
 int lsf_jacobi_sweep_box(const double* d_in, double* d_out, const double* d_phiS, const lsf_box* box,

@@ -27,7 +27,13 @@ __device__ __forceinline__ double wave_sum(double v)
 // Reinit, Jacobi ordering on a box region.  Thread (i,j) marches KC cells in k with a 7-deep
 // register window; x/y neighbours come through the vector L1/L2.
 // =============================================================================================
-constexpr int JAC_BX = 64, JAC_BY = 4, JAC_KC = 16;
+#ifndef LSF_JAC_BY
+#define LSF_JAC_BY 4
+#endif
+#ifndef LSF_JAC_KC
+#define LSF_JAC_KC 32
+#endif
+constexpr int JAC_BX = 64, JAC_BY = LSF_JAC_BY, JAC_KC = LSF_JAC_KC;
 
 template <bool STRICT>
 __global__ __launch_bounds__(JAC_BX* JAC_BY) void k_reinit_jacobi(const double* __restrict__ A,
@@ -519,6 +525,100 @@ __global__ __launch_bounds__(256) void k_phi0(double* __restrict__ phi, int nx, 
 __global__ __launch_bounds__(256) void k_fill(double* __restrict__ p, long n, double v)
 {
     for (long q = blockIdx.x * 256L + threadIdx.x; q < n; q += 256L * gridDim.x) p[q] = v;
+}
+
+// =============================================================================================
+// Post-smoothing gradients and surface-node advection, set3d.f90:464-501.
+// k_firstderiv8: firstDeriv order 8 (subs.f90:309-347) on the stencil-band cells, 0 elsewhere; the y
+// derivative uses phi(i,j+1,k) twice (subs.f90:346) and neighbours are addressed linearly, like the
+// reference; reads outside the allocation (undefined there) yield 0.
+// k_advect_nodes: one thread per surface node; setPhiSurf (subs.f90:1076-1166) + the move of
+// set3d.f90:493-496, repeated until phiSurf <= 1e-13 or `iters` passes.  The reference re-interpolates ALL
+// nodes after every single move (O(iter n^2)); a node's value depends on its own position only.
+// Contraction off, IEEE division / sqrt: bit-identical.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_firstderiv8(const double* __restrict__ phi, const int32_t* __restrict__ sb,
+                                                     double* __restrict__ grad, int nx, int ny, int nz, double dx)
+{
+#pragma clang fp contract(off)
+    const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1), n = sxy * (nz + 1);
+    const double aa1 = 1. / 280., aa2 = -4. / 105., aa3 = 1. / 5., aa4 = -4. / 5., aa6 = 4. / 5, aa7 = -1. / 5.,
+                 aa8 = 4. / 105., aa9 = -1. / 280.;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < n; p += 256L * gridDim.x) {
+        double gx = 0., gy = 0., gz = 0.;
+        if (sb[p] == 1) {
+            auto L = [&](long off) -> double {
+                const long q = p + off;
+                return (q < 0 || q >= n) ? 0.0 : phi[q];
+            };
+            gx = (L(-4) * aa1 + L(-3) * aa2 + L(-2) * aa3 + L(-1) * aa4 + L(1) * aa6 + L(2) * aa7 + L(3) * aa8 +
+                  L(4) * aa9) / dx;
+            gy = (L(-4 * sx) * aa1 + L(-3 * sx) * aa2 + L(-2 * sx) * aa3 + L(-sx) * aa4 + L(sx) * aa6 + L(sx) * aa7 +
+                  L(3 * sx) * aa8 + L(4 * sx) * aa9) / dx;
+            gz = (L(-4 * sxy) * aa1 + L(-3 * sxy) * aa2 + L(-2 * sxy) * aa3 + L(-sxy) * aa4 + L(sxy) * aa6 +
+                  L(2 * sxy) * aa7 + L(3 * sxy) * aa8 + L(4 * sxy) * aa9) / dx;
+        }
+        grad[p] = gx;
+        grad[p + n] = gy;
+        grad[p + 2 * n] = gz;
+    }
+}
+
+__device__ __forceinline__ double interp_node(const double* __restrict__ phi, const double* __restrict__ grad, long sx,
+                                              long sxy, long n, double dx, double lo0, double lo1, double lo2, double x,
+                                              double y, double z, double g[3])
+{
+#pragma clang fp contract(off)
+    const int i0 = (int)__builtin_floor((x - lo0) / dx), j0 = (int)__builtin_floor((y - lo1) / dx),
+              k0 = (int)__builtin_floor((z - lo2) / dx);
+    const double x0 = i0 * dx + lo0, y0 = j0 * dx + lo1, z0 = k0 * dx + lo2;
+    const double x1 = (i0 + 1) * dx + lo0, y1 = (j0 + 1) * dx + lo1, z1 = (k0 + 1) * dx + lo2;
+    const double xd = (x - x0) / (x1 - x0), yd = (y - y0) / (y1 - y0), zd = (z - z0) / (z1 - z0);
+    long p = i0 + sx * j0 + sxy * k0;
+    p = p < 0 ? 0 : (p > n - sxy - sx - 2 ? n - sxy - sx - 2 : p); // stay inside the allocation (defensive)
+    double out[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const double* a = f == 0 ? phi : grad + (long)(f - 1) * n;
+        const double c00 = a[p] * (1. - xd) + a[p + 1] * xd;
+        const double c10 = a[p + sx] * (1. - xd) + a[p + sx + 1] * xd;
+        const double c01 = a[p + sxy] * (1. - xd) + a[p + sxy + 1] * xd;
+        const double c11 = a[p + sxy + sx] * (1. - xd) + a[p + sxy + sx + 1] * xd;
+        const double c0 = c00 * (1. - yd) + c10 * yd;
+        const double c1 = c01 * (1. - yd) + c11 * yd;
+        out[f] = c0 * (1. - zd) + c1 * zd;
+    }
+    g[0] = -out[1], g[1] = -out[2], g[2] = -out[3];
+    const double m2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+    if (m2 < 1.E-7) {
+        g[0] = g[1] = g[2] = 0.;
+    } else {
+        const double m = __builtin_sqrt(m2);
+        g[0] = g[0] / m, g[1] = g[1] / m, g[2] = g[2] / m;
+    }
+    return out[0];
+}
+
+__global__ __launch_bounds__(64) void k_advect_nodes(const double* __restrict__ phi, const double* __restrict__ grad,
+                                                     int nx, int ny, int nz, double dx, double lo0, double lo1,
+                                                     double lo2, double* __restrict__ nodes, int nnode, int iters)
+{
+#pragma clang fp contract(off)
+    const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1), n = sxy * (nz + 1);
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= nnode) return;
+    double x = nodes[t], y = nodes[t + nnode], z = nodes[t + 2L * nnode], g[3];
+    double ps = interp_node(phi, grad, sx, sxy, n, dx, lo0, lo1, lo2, x, y, z, g);
+    for (int it = 0; it < iters; ++it) {
+        if (!(ps > 1E-13)) break;
+        x = x + ps * g[0];
+        y = y + ps * g[1];
+        z = z + ps * g[2];
+        ps = interp_node(phi, grad, sx, sxy, n, dx, lo0, lo1, lo2, x, y, z, g);
+    }
+    nodes[t] = x;
+    nodes[t + nnode] = y;
+    nodes[t + 2L * nnode] = z;
 }
 
 // =============================================================================================

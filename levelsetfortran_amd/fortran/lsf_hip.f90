@@ -10,6 +10,8 @@
 !   minmaxFlow(phi,phiNB,phiSB,nx,ny,nz,iter,dx,h1)     replaces the loop set3d.f90:394-462
 !   phi0Init(phi,nx,ny,nz,dx,xLo,xMin,xMax,surfX,nSurfNode,surfElem,nSurfElem)
 !                                                        replaces the loop set3d.f90:218-268
+!   advectNodes(phi,phiSB,nx,ny,nz,dx,xLo,surfXX,nSurfNode,iter)
+!                                                        replaces set3d.f90:470-479 and :487-501
 !
 ! and reproduces what the reference prints around them (subs.f90:916,923,929 and
 ! set3d.f90:449,456,463) and its STOP on a NaN residual (subs.f90:926, set3d.f90:458).
@@ -27,7 +29,7 @@ MODULE lsf_hip
 USE, INTRINSIC :: iso_c_binding
 IMPLICIT NONE
 PRIVATE
-PUBLIC :: reinit, narrowBand, minmaxFlow, phi0Init, lsf_env_real, lsf_env_int
+PUBLIC :: reinit, narrowBand, minmaxFlow, phi0Init, advectNodes, lsf_env_real, lsf_env_int
 
 INTEGER(c_int), PARAMETER :: LSF_OK = 0, LSF_ERR_NAN = 1
 INTEGER(c_int), PARAMETER :: LSF_ORDER_JACOBI = 1, LSF_ARITH_STRICT = 256
@@ -73,6 +75,16 @@ INTERFACE
       INTEGER(c_int), INTENT(IN) :: surfElem(*)
       INTEGER(c_int) :: rc
    END FUNCTION lsf_phi0
+   FUNCTION lsf_advect_nodes(phi,phiSB,nx,ny,nz,dx,xLo,surfXX,nSurfNode,iters) &
+            BIND(C,NAME='lsf_advect_nodes') RESULT(rc)
+      IMPORT :: c_int, c_double
+      REAL(c_double), INTENT(IN) :: phi(*),xLo(3)
+      INTEGER(c_int), INTENT(IN) :: phiSB(*)
+      INTEGER(c_int), VALUE :: nx,ny,nz,nSurfNode,iters
+      REAL(c_double), VALUE :: dx
+      REAL(c_double), INTENT(INOUT) :: surfXX(*)
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_advect_nodes
    FUNCTION lsf_last_error() BIND(C,NAME='lsf_last_error') RESULT(p)
       IMPORT :: c_ptr
       TYPE(c_ptr) :: p
@@ -220,6 +232,25 @@ rc = lsf_phi0(phi,nx,ny,nz,dx,xLo,xMin,xMax,surfX,nSurfNode,surfElem,nSurfElem)
 IF (rc /= LSF_OK) CALL lsf_fail('lsf_phi0',rc)
 
 END SUBROUTINE phi0Init
+
+!*************************************************************************************!
+! Order-8 gradients on the stencil band + node advection: set3d.f90:470-501 as one call
+! (SURVEY.md section 8f rank 3).  surfXX holds the surface nodes on entry (set3d.f90:485).
+!*************************************************************************************!
+SUBROUTINE advectNodes(phi,phiSB,nx,ny,nz,dx,xLo,surfXX,nSurfNode,iter)
+
+INTEGER,INTENT(IN) :: nx,ny,nz,iter
+INTEGER*4,INTENT(IN) :: nSurfNode
+REAL,INTENT(IN) :: dx,xLo(3)
+REAL,DIMENSION(0:nx,0:ny,0:nz),INTENT(IN) :: phi
+INTEGER,DIMENSION(0:nx,0:ny,0:nz),INTENT(IN) :: phiSB
+REAL,INTENT(INOUT) :: surfXX(nSurfNode,3)
+INTEGER(c_int) :: rc
+
+rc = lsf_advect_nodes(phi,phiSB,nx,ny,nz,dx,xLo,surfXX,nSurfNode,iter)
+IF (rc /= LSF_OK) CALL lsf_fail('lsf_advect_nodes',rc)
+
+END SUBROUTINE advectNodes
 
 !*************************************************************************************!
 ! Run-time overrides of the host's hard-coded parameters (set3d.f90:140,148,298,390,576)

@@ -28,7 +28,7 @@ import numpy as np
 from . import _lib
 from ._lib import LSF_ARITH_FAST, LSF_ARITH_STRICT, LSF_ORDER_GS, LSF_ORDER_JACOBI, LsfError, LsfNaNError
 
-__all__ = ["reinit", "narrowBand", "minmaxFlow", "phi0Init", "SweepReport", "mode_word", "LsfError", "LsfNaNError"]
+__all__ = ["reinit", "narrowBand", "minmaxFlow", "phi0Init", "advectNodes", "SweepReport", "mode_word", "LsfError", "LsfNaNError"]
 
 REINIT_TOL = 1.0e-5  # subs.f90:915
 MINMAX_TOL = 1.0e-7  # set3d.f90:448
@@ -219,4 +219,30 @@ def phi0Init(phi, nx: int, ny: int, nz: int, dx: float, xLo, minX, maxX, surfX, 
         rc = lib.lsf_phi0_device(_dev_ptr(phi, torch.float64, nx, ny, nz, "phi"), *args, st)
     else:
         rc = lib.lsf_phi0(_host_ptr(phi, np.float64, nx, ny, nz, "phi"), *args)
+    _lib.check(rc)
+
+
+def advectNodes(phi, phiSB, nx: int, ny: int, nz: int, dx: float, xLo, surfXX, iter: int = 1000) -> None:
+    """Order-8 gradients on the stencil band + surface-node advection, set3d.f90:470-501, as one call.
+
+    surfXX: (nSurfNode,3) float64 numpy array (Fortran-ordered), the nodes on entry and the advected nodes on
+    return (this is what the host writes to the .s3d file, set3d.f90:606-608).  phi / phiSB as for minmaxFlow.
+    Bit-identical to the reference (including subs.f90:346's repeated j+1 neighbour).
+    """
+    lib = _lib.load()
+    if not (isinstance(surfXX, np.ndarray) and surfXX.dtype == np.float64 and surfXX.ndim == 2
+            and surfXX.shape[1] == 3 and surfXX.flags.f_contiguous and surfXX.flags.writeable):
+        raise ValueError("surfXX must be a writeable Fortran-ordered float64 array of shape (nSurfNode, 3)")
+    lo = np.ascontiguousarray(xLo, dtype=np.float64)
+    if _is_torch(phi):
+        import torch
+
+        st = _stream_and_device(phi)
+        rc = lib.lsf_advect_nodes_device(_dev_ptr(phi, torch.float64, nx, ny, nz, "phi"),
+                                         _dev_ptr(phiSB, torch.int32, nx, ny, nz, "phiSB"), nx, ny, nz, float(dx),
+                                         lo.ctypes.data, surfXX.ctypes.data, surfXX.shape[0], int(iter), st)
+    else:
+        rc = lib.lsf_advect_nodes(_host_ptr(phi, np.float64, nx, ny, nz, "phi"),
+                                  _host_ptr(phiSB, np.int32, nx, ny, nz, "phiSB"), nx, ny, nz, float(dx),
+                                  lo.ctypes.data, surfXX.ctypes.data, surfXX.shape[0], int(iter))
     _lib.check(rc)

@@ -553,3 +553,100 @@ void lsf_oracle_phi0(double *phi, int nx, int ny, int nz, double dx, const doubl
 #undef SE
     free(cen);
 }
+
+/* ---- post-smoothing gradients + surface-node advection, set3d.f90:464-501 ----
+ * firstDeriv order 8 (subs.f90:309-347) on the stencil-band cells, setPhiSurf (subs.f90:1056-1170) and the
+ * advection loop.  Reference quirks kept: the y derivative uses phi(i,j+1,k) twice (subs.f90:346); neighbours
+ * are addressed linearly like Fortran does without bounds checking (a band cell fewer than 4 points from a wall
+ * reads the neighbouring row/plane); a read before the first / after the last element of phi is undefined in
+ * the reference and yields 0 here (such cells lie 8 cells from the surface and are never interpolated).
+ * gradPhi: (0:nx,0:ny,0:nz,3) work array, zero outside the band (set3d.f90:372). */
+static double phi_lin(const double *phi, ptrdiff_t p, ptrdiff_t n)
+{
+    return (p < 0 || p >= n) ? 0.0 : phi[p];
+}
+
+void lsf_oracle_firstderiv8(const double *phi, const int32_t *phiSB, int nx, int ny, int nz, double dx,
+                            double *gradPhi)
+{
+    const ptrdiff_t sx = (ptrdiff_t)nx + 1, sxy = sx * ((ptrdiff_t)ny + 1), n = sxy * ((ptrdiff_t)nz + 1);
+    const double aa1 = 1. / 280., aa2 = -4. / 105., aa3 = 1. / 5., aa4 = -4. / 5., aa6 = 4. / 5, aa7 = -1. / 5.,
+                 aa8 = 4. / 105., aa9 = -1. / 280.;
+    ptrdiff_t p;
+    memset(gradPhi, 0, (size_t)n * 3 * sizeof(double));
+    for (p = 0; p < n; ++p) {
+        double phiX, phiY, phiZ;
+        if (phiSB[p] != 1) continue;
+#define L(off) phi_lin(phi, p + (off), n)
+        phiX = (L(-4) * aa1 + L(-3) * aa2 + L(-2) * aa3 + L(-1) * aa4 + L(1) * aa6 + L(2) * aa7 + L(3) * aa8 + L(4) * aa9) / dx;
+        phiY = (L(-4 * sx) * aa1 + L(-3 * sx) * aa2 + L(-2 * sx) * aa3 + L(-sx) * aa4 + L(sx) * aa6 + L(sx) * aa7 +
+                L(3 * sx) * aa8 + L(4 * sx) * aa9) / dx; /* subs.f90:346: jp1 twice */
+        phiZ = (L(-4 * sxy) * aa1 + L(-3 * sxy) * aa2 + L(-2 * sxy) * aa3 + L(-sxy) * aa4 + L(sxy) * aa6 + L(2 * sxy) * aa7 +
+                L(3 * sxy) * aa8 + L(4 * sxy) * aa9) / dx;
+#undef L
+        gradPhi[p] = phiX;
+        gradPhi[p + n] = phiY;
+        gradPhi[p + 2 * n] = phiZ;
+    }
+}
+
+/* setPhiSurf for one node position; returns phiSurf, fills g[3] = gradPhiSurf (subs.f90:1076-1166) */
+static double interp_node(const double *phi, const double *gradPhi, int nx, int ny, int nz, double dx,
+                          const double xLo[3], const double X[3], double g[3])
+{
+    const ptrdiff_t sx = (ptrdiff_t)nx + 1, sxy = sx * ((ptrdiff_t)ny + 1), n = sxy * ((ptrdiff_t)nz + 1);
+    const double x = X[0], y = X[1], z = X[2];
+    const int i0 = (int)floor((x - xLo[0]) / dx), j0 = (int)floor((y - xLo[1]) / dx), k0 = (int)floor((z - xLo[2]) / dx);
+    const double x0 = i0 * dx + xLo[0], y0 = j0 * dx + xLo[1], z0 = k0 * dx + xLo[2];
+    const int i1 = i0 + 1, j1 = j0 + 1, k1 = k0 + 1;
+    const double x1 = i1 * dx + xLo[0], y1 = j1 * dx + xLo[1], z1 = k1 * dx + xLo[2];
+    const double xd = (x - x0) / (x1 - x0), yd = (y - y0) / (y1 - y0), zd = (z - z0) / (z1 - z0);
+    const ptrdiff_t p000 = i0 + sx * j0 + sxy * k0;
+    double out[4], gradMag2;
+    int f;
+    (void)nz;
+    for (f = 0; f < 4; ++f) {
+        const double *a = f == 0 ? phi : gradPhi + (ptrdiff_t)(f - 1) * n;
+        double c00 = a[p000] * (1. - xd) + a[p000 + 1] * xd;
+        double c10 = a[p000 + sx] * (1. - xd) + a[p000 + sx + 1] * xd;
+        double c01 = a[p000 + sxy] * (1. - xd) + a[p000 + sxy + 1] * xd;
+        double c11 = a[p000 + sxy + sx] * (1. - xd) + a[p000 + sxy + sx + 1] * xd;
+        double c0 = c00 * (1. - yd) + c10 * yd;
+        double c1 = c01 * (1. - yd) + c11 * yd;
+        out[f] = c0 * (1. - zd) + c1 * zd;
+    }
+    g[0] = -out[1];
+    g[1] = -out[2];
+    g[2] = -out[3];
+    gradMag2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+    if (gradMag2 < 1.E-7) {
+        g[0] = g[1] = g[2] = 0.;
+    } else {
+        double m = sqrt(gradMag2);
+        g[0] = g[0] / m;
+        g[1] = g[1] / m;
+        g[2] = g[2] / m;
+    }
+    return out[0];
+}
+
+/* set3d.f90:485-501: surfXX (nSurfNode,3 Fortran-ordered) in = the surface nodes, out = advected nodes */
+void lsf_oracle_advect(const double *phi, const double *gradPhi, int nx, int ny, int nz, double dx,
+                       const double xLo[3], double *surfXX, int nSurfNode, int iters)
+{
+    int n, it;
+    for (n = 0; n < nSurfNode; ++n) {
+        double X[3] = {surfXX[n], surfXX[n + nSurfNode], surfXX[n + 2 * (size_t)nSurfNode]}, g[3];
+        double ps = interp_node(phi, gradPhi, nx, ny, nz, dx, xLo, X, g);
+        for (it = 0; it < iters; ++it) {
+            if (!(ps > 1E-13)) break; /* nothing moves any more: every later pass repeats this test */
+            X[0] = X[0] + ps * g[0];
+            X[1] = X[1] + ps * g[1];
+            X[2] = X[2] + ps * g[2];
+            ps = interp_node(phi, gradPhi, nx, ny, nz, dx, xLo, X, g);
+        }
+        surfXX[n] = X[0];
+        surfXX[n + nSurfNode] = X[1];
+        surfXX[n + 2 * (size_t)nSurfNode] = X[2];
+    }
+}

@@ -74,6 +74,14 @@ void lsf_oracle_phi0(double *phi, int nx, int ny, int nz, double dx, const doubl
                      const double minX[3], const double maxX[3], const double *surfX, int nSurfNode,
                      const int32_t *surfElem, int nSurfElem);
 
+/* set3d.f90:464-501: order-8 gradients on the stencil band (subs.f90:309-347, with
+ * its quirks) into gradPhi (0:nx,0:ny,0:nz,3), and the surface-node advection through setPhiSurf
+ * (subs.f90:1056-1170).  surfXX is (nSurfNode,3) Fortran-ordered, in/out. */
+void lsf_oracle_firstderiv8(const double *phi, const int32_t *phiSB, int nx, int ny, int nz, double dx,
+                            double *gradPhi);
+void lsf_oracle_advect(const double *phi, const double *gradPhi, int nx, int ny, int nz, double dx,
+                       const double xLo[3], double *surfXX, int nSurfNode, int iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,8 @@
  *                                           c = n is the call ending min/max iteration n)
  *                                           only for c listed in $LSF_REF_NB_DUMPS ("0,1,10")
  *   nb.count                                number of narrowBand calls so far
+ *   advect_surfXX.f64, advect.meta          the advected surface nodes surfXX(nSurfNode,3) after the loop
+ *                                           set3d.f90:491-501, and "nSurfNode  setPhiSurf-call-count"
  * $LSF_REF_STOP_AT_REINIT2=1 ends the program (exit 0) when reinit is entered the
  * second time, after dumping its input (= phi after min/max flow); the reference
  * never writes the result of that second call anywhere.
@@ -29,6 +31,16 @@ void __real__QMset_subsPreinit(double *phi, double *gradPhi, double *gradPhiMag,
                                int *nz, int *iter, double *dx, double *h);
 void __real__QMset_subsPnarrowband(int *nx, int *ny, int *nz, double *dx, double *phi, int *phiNB,
                                    int *phiSB);
+void __real__QMset_subsPsetphisurf(double *xLo, int *nx, int *ny, int *nz, double *dx, double *phiSurf,
+                                   double *phi, int *nSurfNode, double *surfX, double *gradPhiSurf,
+                                   double *gradPhi);
+
+/* set3d.f90:487-501 advects a copy of the surface nodes (surfXX) by calling setPhiSurf once per move;
+ * remember where that array lives so that its final state can be dumped when the main program reaches
+ * its second reinit call (set3d.f90:582), i.e. right after the advection loop. */
+static double *g_nodes = 0;
+static int g_nnodes = 0;
+static long g_setphisurf_calls = 0;
 
 static void dump(const char *name, const void *p, size_t bytes)
 {
@@ -69,6 +81,12 @@ void __wrap__QMset_subsPreinit(double *phi, double *gradPhi, double *gradPhiMag,
     snprintf(meta, sizeof meta, "%d %d %d %d %.17g %.17g\n", *nx, *ny, *nz, *iter, *dx, *h);
     snprintf(name, sizeof name, "reinit%d.meta", call);
     dump(name, meta, strlen(meta));
+    if (call == 2 && g_nodes) {
+        char cnt[64];
+        dump("advect_surfXX.f64", g_nodes, (size_t)g_nnodes * 3 * sizeof(double));
+        snprintf(cnt, sizeof cnt, "%d %ld\n", g_nnodes, g_setphisurf_calls);
+        dump("advect.meta", cnt, strlen(cnt));
+    }
     if (call == 2 && getenv("LSF_REF_STOP_AT_REINIT2")) {
         fflush(stdout);
         exit(0);
@@ -96,4 +114,14 @@ void __wrap__QMset_subsPnarrowband(int *nx, int *ny, int *nz, double *dx, double
     snprintf(cnt, sizeof cnt, "%d\n", call);
     dump("nb.count", cnt, strlen(cnt));
     ++call;
+}
+
+void __wrap__QMset_subsPsetphisurf(double *xLo, int *nx, int *ny, int *nz, double *dx, double *phiSurf,
+                                   double *phi, int *nSurfNode, double *surfX, double *gradPhiSurf,
+                                   double *gradPhi)
+{
+    g_nodes = surfX;
+    g_nnodes = *nSurfNode;
+    ++g_setphisurf_calls;
+    __real__QMset_subsPsetphisurf(xLo, nx, ny, nz, dx, phiSurf, phi, nSurfNode, surfX, gradPhiSurf, gradPhi);
 }

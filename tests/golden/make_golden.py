@@ -12,6 +12,7 @@ Fixtures
   cube40_62.npz      the shipped case `./set3d.exec cube40.stl` (62^3, dx=0.05): phi0, phi after
                      reinit #1 (2155 sweeps), phi after min/max flow (406 iterations), masks, both
                      RMS traces as printed, strided samples + SHA-256 of intermediate states
+  cube40_advect.npz  the advected surface nodes surfXX after the node-advection loop (set3d.f90:464-501)
   twocube10.npz      `./set3d.exec twoCube10.stl` (262x42x42): phi0, RMS trace up to the NaN at
                      sweep 272 where the reference STOPs, sample + SHA-256 of phi after 64 sweeps
   surfaces.npz       nodes (REAL*4) and 1-based connectivity of cube40.stl / twoCube10.stl as the
@@ -154,6 +155,11 @@ def main():
         f, _ = ref_reinit(phi0, nx, ny, nz, sweeps - 1, dx, h)
         out[f"re{sweeps}_sha"] = sha(f)
         out[f"re{sweeps}_sample"] = sample(f)
+    # advected surface nodes after set3d.f90:491-501 (dumped by ref_wrap.c when reinit #2 is entered)
+    nnode, ncalls = (int(v) for v in open(os.path.join(td, "advect.meta")).read().split())
+    np.savez_compressed(os.path.join(HERE, "cube40_advect.npz"),
+                        surfXX=np.fromfile(os.path.join(td, "advect_surfXX.f64")).reshape((nnode, 3), order="F"),
+                        setphisurf_calls=ncalls, xLo=np.array([-1.5, -1.5, -1.5]))
     out["phi_reinit_sha"] = sha(phi_re)
     out["phi_minmax_sha"] = sha(phi_mm)
     np.savez_compressed(os.path.join(HERE, "cube40_62.npz"), **out)

@@ -104,3 +104,20 @@ def phi0(nx, ny, nz, dx, xLo, minX, maxX, surfX, surfElem):
     lo, mn, mx = a3(xLo), a3(minX), a3(maxX)
     lib().lsf_oracle_phi0(_d(phi), nx, ny, nz, dx, _d(lo), _d(mn), _d(mx), _d(sX), sX.shape[0], _i(sE), sE.shape[0])
     return phi
+
+
+def advect(phi, phiSB, nx, ny, nz, dx, xLo, surfX, iters=1000):
+    """set3d.f90:464-501: order-8 gradients on the stencil band, then the node advection.  Returns surfXX."""
+    L = lib()
+    vp = ctypes.c_void_p
+    L.lsf_oracle_firstderiv8.restype = None
+    L.lsf_oracle_firstderiv8.argtypes = [vp, vp, c_int, c_int, c_int, c_double, vp]
+    L.lsf_oracle_advect.restype = None
+    L.lsf_oracle_advect.argtypes = [vp, vp, c_int, c_int, c_int, c_double, vp, vp, c_int, c_int]
+    grad = np.zeros(phi.shape + (3,), order="F")
+    sb = np.asfortranarray(phiSB, dtype=np.int32)
+    lo = np.ascontiguousarray(xLo, dtype=np.float64)
+    XX = np.array(surfX, dtype=np.float64, order="F", copy=True)
+    L.lsf_oracle_firstderiv8(phi.ctypes.data, sb.ctypes.data, nx, ny, nz, dx, grad.ctypes.data)
+    L.lsf_oracle_advect(phi.ctypes.data, grad.ctypes.data, nx, ny, nz, dx, lo.ctypes.data, XX.ctypes.data, XX.shape[0], iters)
+    return XX

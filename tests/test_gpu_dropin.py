@@ -36,4 +36,10 @@ def test_cube40_as_shipped_through_the_fortran_host(tmp_path, cube40):
     shape = (62, 62, 62)
     assert np.array_equal(stl_io.vti_read_phi(tmp_path / "signedDistanceFunction.vti", shape), cube40["phi_reinit"])
     assert np.array_equal(stl_io.vti_read_phi(tmp_path / "smoothedDistanceFunction.vti", shape), cube40["phi_minmax"])
-    assert os.path.exists(tmp_path / "cube40.s3d")
+    # the .s3d mesh (set3d.f90:601-612) carries the surface nodes advected on the GPU (advectNodes)
+    lines = open(tmp_path / "cube40.s3d").read().split("\n")
+    nelem, nnode = (int(v) for v in lines[0].split()[:2])
+    nodes = np.array([[float(v) for v in ln.split()] for ln in lines[1 + nelem:1 + nelem + nnode]])
+    adv = np.load(os.path.join(GOLDEN, "cube40_advect.npz"))["surfXX"]
+    assert nodes.shape == adv.shape == (9140, 3)
+    assert np.allclose(nodes, adv, rtol=1e-15, atol=0)  # list-directed output prints 17 significant digits

@@ -326,3 +326,26 @@ def test_reinit_alternative_schedules(lsf, synth, cube40, monkeypatch, schedule)
     phi2 = F(cube40["phi0"])
     rep2 = lsf.reinit(phi2, None, None, nx, ny, nz, 200, float(cube40["dx"]), float(cube40["h"]), tol=3.0e-3, arith="strict")
     assert rep.count == rep2.count and 1 < rep.count < 200 and rep.converged and np.array_equal(phi, phi2)
+
+
+# ---------------------------------------------------------------------------------- advection
+def test_node_advection_matches_reference(lsf, cube40):
+    """set3d.f90:464-501 on the GPU: bit-identical advected nodes (host and device seam)."""
+    import os
+
+    from conftest import GOLDEN
+
+    s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    adv = np.load(os.path.join(GOLDEN, "cube40_advect.npz"))
+    nx, ny, nz = _n(cube40)
+    phi, sb = F(cube40["phi_minmax"]), F(cube40["SBfinal"].astype(np.int32))
+    XX = np.array(s["cube40_surfX"], dtype=np.float64, order="F")
+    lsf.advectNodes(phi, sb, nx, ny, nz, float(cube40["dx"]), adv["xLo"], XX)
+    assert np.array_equal(XX, adv["surfXX"])
+    XX = np.array(s["cube40_surfX"], dtype=np.float64, order="F")
+    lsf.advectNodes(_dev(phi), _dev(sb), nx, ny, nz, float(cube40["dx"]), adv["xLo"], XX)
+    assert np.array_equal(XX, adv["surfXX"])
+    with pytest.raises(lsf.LsfError):
+        bad = XX.copy(order="F")
+        bad[0, 0] = 99.0  # a node outside the grid would make the reference read outside phi
+        lsf.advectNodes(phi, sb, nx, ny, nz, float(cube40["dx"]), adv["xLo"], bad)

@@ -135,3 +135,19 @@ def test_jacobi_differs_from_reference_ordering(oracle, synth):
     oracle.reinit(phi, nx, ny, nz, 15, float(synth["dx"]), float(synth["h"]), order=oracle.JACOBI)
     d = np.abs(phi - synth["phi_16"]).max()
     assert 1e-9 < d < 1e-2
+
+
+def test_node_advection_cube40(oracle, cube40):
+    """set3d.f90:464-501 restated (order-8 gradients with the reference's j+1 typo, setPhiSurf, the move loop):
+    the advected nodes equal the reference's bit for bit."""
+    import os
+
+    from conftest import GOLDEN
+
+    s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    adv = np.load(os.path.join(GOLDEN, "cube40_advect.npz"))
+    nx, ny, nz = _n(cube40)
+    XX = oracle.advect(F(cube40["phi_minmax"]), cube40["SBfinal"].astype(np.int32), nx, ny, nz, float(cube40["dx"]),
+                       adv["xLo"], s["cube40_surfX"].astype(np.float64))
+    assert np.array_equal(XX, adv["surfXX"])
+    assert np.abs(XX - s["cube40_surfX"]).max() > 0.05  # the nodes really moved
