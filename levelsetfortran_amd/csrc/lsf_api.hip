@@ -29,6 +29,20 @@ int fail(int code, const std::string& msg)
     return code;
 }
 
+// LSF_TRACE=1: one stderr line per ABI call (the Fortran host buffers its stdout, so a crash loses it)
+struct Trace {
+    const char* name;
+    bool on;
+    explicit Trace(const char* n) : name(n), on(getenv("LSF_TRACE") != nullptr)
+    {
+        if (on) fprintf(stderr, "[lsf] -> %s\n", name);
+    }
+    ~Trace()
+    {
+        if (on) fprintf(stderr, "[lsf] <- %s\n", name);
+    }
+};
+
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
@@ -910,6 +924,7 @@ int lsf_reinit_device(double* d_phi, const double* d_phiS, int nx, int ny, int n
                       double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace,
                       int trace_cap, void* stream)
 {
+    Trace trace_("lsf_reinit_device");
     int rc = ensure_device();
     if (rc) return rc;
     return reinit_core(d_phi, d_phiS, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done, rms_trace,
@@ -919,6 +934,7 @@ int lsf_reinit_device(double* d_phi, const double* d_phiS, int nx, int ny, int n
 int lsf_reinit(double* phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,
                int* sweeps_done, double* rms_trace, int trace_cap)
 {
+    Trace trace_("lsf_reinit");
     int rc = ensure_device();
     if (rc) return rc;
     if ((rc = check_dims(nx, ny, nz))) return rc;
@@ -941,6 +957,7 @@ int lsf_minmax_device(double* d_phi, int32_t* d_phiNB, int32_t* d_phiSB, int nx,
                       double dx, double h1, double tol, int mode, int* iters_done, double* rms_trace,
                       int trace_cap, void* stream)
 {
+    Trace trace_("lsf_minmax_device");
     int rc = ensure_device();
     if (rc) return rc;
     return minmax_core(d_phi, d_phiNB, d_phiSB, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace,
@@ -950,6 +967,7 @@ int lsf_minmax_device(double* d_phi, int32_t* d_phiNB, int32_t* d_phiSB, int nx,
 int lsf_minmax(double* phi, int32_t* phiNB, int32_t* phiSB, int nx, int ny, int nz, int iter, double dx,
                double h1, double tol, int mode, int* iters_done, double* rms_trace, int trace_cap)
 {
+    Trace trace_("lsf_minmax");
     int rc = ensure_device();
     if (rc) return rc;
     if ((rc = check_dims(nx, ny, nz))) return rc;
@@ -979,6 +997,7 @@ int lsf_minmax(double* phi, int32_t* phiNB, int32_t* phiSB, int nx, int ny, int 
 int lsf_narrowband_device(const double* d_phi, int32_t* d_phiNB, int32_t* d_phiSB, int nx, int ny, int nz,
                           double dx, void* stream)
 {
+    Trace trace_("lsf_narrowband_device");
     int rc = ensure_device();
     if (rc) return rc;
     if ((rc = check_dims(nx, ny, nz))) return rc;
@@ -991,6 +1010,7 @@ int lsf_narrowband_device(const double* d_phi, int32_t* d_phiNB, int32_t* d_phiS
 
 int lsf_narrowband(const double* phi, int32_t* phiNB, int32_t* phiSB, int nx, int ny, int nz, double dx)
 {
+    Trace trace_("lsf_narrowband");
     int rc = ensure_device();
     if (rc) return rc;
     if ((rc = check_dims(nx, ny, nz))) return rc;
@@ -1013,6 +1033,7 @@ int lsf_phi0_device(double* d_phi, int nx, int ny, int nz, double dx, const doub
                     const double maxX[3], const double* surfX, int nSurfNode, const int32_t* surfElem, int nSurfElem,
                     void* stream)
 {
+    Trace trace_("lsf_phi0_device");
     int rc = ensure_device();
     if (rc) return rc;
     if ((rc = check_dims(nx, ny, nz))) return rc;
@@ -1064,6 +1085,7 @@ int lsf_phi0_device(double* d_phi, int nx, int ny, int nz, double dx, const doub
 int lsf_phi0(double* phi, int nx, int ny, int nz, double dx, const double xLo[3], const double minX[3],
              const double maxX[3], const double* surfX, int nSurfNode, const int32_t* surfElem, int nSurfElem)
 {
+    Trace trace_("lsf_phi0");
     int rc = ensure_device();
     if (rc) return rc;
     if ((rc = check_dims(nx, ny, nz))) return rc;
@@ -1081,6 +1103,7 @@ int lsf_phi0(double* phi, int nx, int ny, int nz, double dx, const double xLo[3]
 int lsf_advect_nodes_device(const double* d_phi, const int32_t* d_phiSB, int nx, int ny, int nz, double dx,
                             const double xLo[3], double* surfXX, int nSurfNode, int iters, void* stream)
 {
+    Trace trace_("lsf_advect_nodes_device");
     int rc = ensure_device();
     if (rc) return rc;
     if ((rc = check_dims(nx, ny, nz))) return rc;
@@ -1115,6 +1138,7 @@ int lsf_advect_nodes_device(const double* d_phi, const int32_t* d_phiSB, int nx,
 int lsf_advect_nodes(const double* phi, const int32_t* phiSB, int nx, int ny, int nz, double dx, const double xLo[3],
                      double* surfXX, int nSurfNode, int iters)
 {
+    Trace trace_("lsf_advect_nodes");
     int rc = ensure_device();
     if (rc) return rc;
     if ((rc = check_dims(nx, ny, nz))) return rc;

@@ -35,8 +35,11 @@ __device__ __forceinline__ double wave_sum(double v)
 #endif
 constexpr int JAC_BX = 64, JAC_BY = LSF_JAC_BY, JAC_KC = LSF_JAC_KC;
 
+#ifndef LSF_JAC_WAVES
+#define LSF_JAC_WAVES 1
+#endif
 template <bool STRICT>
-__global__ __launch_bounds__(JAC_BX* JAC_BY) void k_reinit_jacobi(const double* __restrict__ A,
+__global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi(const double* __restrict__ A,
                                                                    double* __restrict__ Bout,
                                                                    const double* __restrict__ phiS, Box bx,
                                                                    int lo0, int lo1, int lo2, int hi0, int hi1,

@@ -98,7 +98,7 @@ def ref_reinit(phi0, nx, ny, nz, it, dx, h):
     with tempfile.TemporaryDirectory() as td:
         a, b = os.path.join(td, "in.npy"), os.path.join(td, "out.npy")
         np.save(a, np.asfortranarray(phi0))
-        p = subprocess.run([sys.executable, __file__, "--worker", a, b, str(nx), str(ny), str(nz), str(it), repr(dx), repr(h)],
+        p = subprocess.run([sys.executable, __file__, "--worker", a, b, str(nx), str(ny), str(nz), str(it), repr(float(dx)), repr(float(h))],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         tr = np.array([float(x) for x in RMS_RE.findall(p.stdout)])
         out = np.load(b) if os.path.exists(b) else None

@@ -43,3 +43,63 @@ def test_cube40_as_shipped_through_the_fortran_host(tmp_path, cube40):
     adv = np.load(os.path.join(GOLDEN, "cube40_advect.npz"))["surfXX"]
     assert nodes.shape == adv.shape == (9140, 3)
     assert np.allclose(nodes, adv, rtol=1e-15, atol=0)  # list-directed output prints 17 significant digits
+
+
+def _run_dropin(tmp_path, stl_name, surf_key, env_extra):
+    import stl_io
+
+    s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    stl_io.stl_write(tmp_path / stl_name, s[surf_key + "_surfX"], s[surf_key + "_surfElem"])
+    env = dict(os.environ, LSF_ARITH="strict", **env_extra)
+    p = subprocess.run(f"ulimit -s unlimited; cd {tmp_path}; {EXE} {stl_name}", shell=True, env=env, text=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800)
+    assert p.returncode == 0, p.stdout[-3000:]
+    return p.stdout
+
+
+def _sha_file_payload(path, shape):
+    import hashlib
+
+    import stl_io
+
+    a = stl_io.vti_read_phi(path, shape)
+    return hashlib.sha256(np.ascontiguousarray(a.ravel(order="F")).tobytes()).hexdigest(), a
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="drop-in executable not built")
+def test_baseline_config2_cube40_256(tmp_path):
+    """BASELINE config 2: cube40.stl, 256^3 fp64, reinit only (min/max cap 0), through the Fortran host with the
+    run-time overrides of INTEGRATION.md E4.  Fixed 8 sweeps: the field written to signedDistanceFunction.vti must
+    equal, bit for bit, what the reference's own reinit produced from the same phi0 (tests/golden/make_golden_c2.py)."""
+    fx = os.path.join(GOLDEN, "cube40_256.npz")
+    if not os.path.exists(fx):
+        pytest.skip("cube40_256.npz not generated")
+    g = np.load(fx)
+    out = _run_dropin(tmp_path, "cube40.stl", "cube40",
+                      dict(LSF_DX=repr(float(g["dx"])), LSF_REINIT_ITER=str(int(g["sweeps"]) - 1), LSF_MINMAX_ITER="0",
+                           LSF_REINIT2_ITER="0"))
+    assert "Grid Size: nx = 255 , ny = 255 ,nz = 255" in out
+    got_sha, a = _sha_file_payload(tmp_path / "signedDistanceFunction.vti", (256, 256, 256))
+    assert np.array_equal(a[::8, ::8, ::8], g["sample"])
+    assert got_sha == str(g["sha"])
+    rms = [float(x) for x in re.findall(r"RMS Error:\\s+(\\S+)", out)][: int(g["sweeps"])]
+    assert np.allclose(rms, g["rms"], rtol=1e-8, atol=0)
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="drop-in executable not built")
+def test_baseline_config3_twocube10_512(tmp_path):
+    """BASELINE config 3: twoCube10.stl at the 512-point resolution (512 x 63 x 63 with the host's uniform padding),
+    128 reinit sweeps (the surface diverges later in the reference itself) + 200 min/max-flow iterations."""
+    fx = os.path.join(GOLDEN, "twocube10_512.npz")
+    if not os.path.exists(fx):
+        pytest.skip("twocube10_512.npz not generated")
+    g = np.load(fx)
+    out = _run_dropin(tmp_path, "twoCube10.stl", "twocube10",
+                      dict(LSF_DX=repr(float(g["dx"])), LSF_REINIT_ITER=str(int(g["sweeps"]) - 1),
+                           LSF_MINMAX_ITER=str(200), LSF_REINIT2_ITER="0"))
+    assert "Grid Size: nx = 511 , ny = 62 ,nz = 62" in out
+    shape = tuple(int(v) + 1 for v in g["n"])
+    sha1, a1 = _sha_file_payload(tmp_path / "signedDistanceFunction.vti", shape)
+    assert np.array_equal(a1[::8, ::4, ::4], g["reinit_sample"]) and sha1 == str(g["reinit_sha"])
+    sha2, a2 = _sha_file_payload(tmp_path / "smoothedDistanceFunction.vti", shape)
+    assert np.array_equal(a2[::8, ::4, ::4], g["minmax_sample"]) and sha2 == str(g["minmax_sha"])
