@@ -82,7 +82,7 @@ def test_baseline_config2_cube40_256(tmp_path):
     got_sha, a = _sha_file_payload(tmp_path / "signedDistanceFunction.vti", (256, 256, 256))
     assert np.array_equal(a[::8, ::8, ::8], g["sample"])
     assert got_sha == str(g["sha"])
-    rms = [float(x) for x in re.findall(r"RMS Error:\\s+(\\S+)", out)][: int(g["sweeps"])]
+    rms = [float(x) for x in re.findall(r"RMS Error:\s+(\S+)", out)][: int(g["sweeps"])]
     assert np.allclose(rms, g["rms"], rtol=1e-8, atol=0)
 
 
