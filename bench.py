@@ -180,10 +180,13 @@ def main() -> None:
     else:
         order = args.mode
         nx = ny = nz = N - 1
-        phi0_np, dx = fields.two_sphere_phi0((N, N, N))
+        if N > 640:  # numpy temporaries of a 1024^3 field do not belong in host memory: build it in HBM
+            phi0, dx = fields.two_sphere_phi0_device((N, N, N), dev)
+        else:
+            phi0_np, dx = fields.two_sphere_phi0((N, N, N))
+            phi0 = torch.from_numpy(phi0_np.reshape(-1, order="F")).to(dev)
+            del phi0_np
         h = fields.reinit_step(dx)
-        phi0 = torch.from_numpy(phi0_np.reshape(-1, order="F")).to(dev)
-        del phi0_np
         phiS = phi0.clone()
         phi = phi0.clone()
 

@@ -75,7 +75,7 @@ struct TileList {
     std::vector<int> off; // plane offsets, size nplanes+1
 };
 
-enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_FLAGS, S_FLOWCTL, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_NSLOTS };
+enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_FLAGS, S_FLOWCTL, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_NSLOTS };
 
 struct Ctx {
     Buf slot[S_NSLOTS];
@@ -691,7 +691,7 @@ int narrowband_core(const double* d_phi, int32_t* d_nb, int32_t* d_sb, size_t n,
     return LSF_OK;
 }
 
-constexpr int MM_MAX_FIX = 8; // fix passes per min/max iteration before the fixed point counts as uncertified
+constexpr int MM_MAX_FIX = 32; // fix passes per min/max iteration before the fixed point counts as uncertified
 
 int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int nz, int iter, double dx,
                      double h1, double tol, int mode, int* iters_done, double* rms_trace, int trace_cap,
@@ -717,15 +717,19 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     long n_part;
     const bool fixed_point = order == LSF_ORDER_GS && !use_tiles;
     const long fp_blocks = (long)((n + MM_CH - 1) / MM_CH);
-    int *bflag = nullptr, *chg = nullptr;
+    int *bflag = nullptr, *chg = nullptr, *stamp = nullptr;
+    constexpr size_t CHG_BYTES = (MM_MAX_FIX + 1) * sizeof(int);
     double* part2 = nullptr;
     if (fixed_point) {
         n_part = fp_blocks;
         if ((rc = ws(c.slot[S_BFLAG], (size_t)fp_blocks * sizeof(int)))) return rc;
-        if ((rc = ws(c.slot[S_CHG], 64))) return rc;
+        if ((rc = ws(c.slot[S_CHG], CHG_BYTES))) return rc;
+        if ((rc = ws(c.slot[S_STAMP], (size_t)fp_blocks * sizeof(int)))) return rc;
         if ((rc = ws(c.slot[S_PART2], 256 * sizeof(double)))) return rc;
         bflag = (int*)c.slot[S_BFLAG].p;
         chg = (int*)c.slot[S_CHG].p;
+        stamp = (int*)c.slot[S_STAMP].p;
+        HIPCHK(hipMemsetAsync(stamp, 0, (size_t)fp_blocks * sizeof(int), st));
         part2 = (double*)c.slot[S_PART2].p;
     } else if (order == LSF_ORDER_GS) {
         nTi = cdiv(nx + 1, MM_TA), nTj = cdiv(ny + 1, 8), nTk = cdiv(nz + 1, 8);
@@ -741,20 +745,25 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
 
     double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
     int host_ctl[4] = {0, 0, 0, 0};
+    const char* tfp = getenv("LSF_TRACE_MINMAX");
+    const bool trace_fp = tfp && atoi(tfp) != 0;
     for (int it = 0; it < iter; ++it) { // DO n = 1,iter (set3d.f90:394)
         const double* A = bufs[it & 1];
         double* B = bufs[(it + 1) & 1];
         const int32_t* mask = it == 0 ? d_nb : nullptr;
         if (fixed_point) {
-            HIPCHK(hipMemsetAsync(chg, 0, 64, st));
-            const dim3 g((unsigned)fp_blocks), gs((unsigned)std::min<long>(fp_blocks, 4096)), b(256);
-            hipLaunchKernelGGL((k_minmax_fp<0>), g, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, fp_blocks,
+            HIPCHK(hipMemsetAsync(chg, 0, CHG_BYTES, st));
+            const dim3 g((unsigned)fp_blocks), b(256);
+            const dim3 gwide((unsigned)std::min<long>(cdiv(fp_blocks, 64), 4096)), gthin((unsigned)std::min<long>(cdiv(fp_blocks, 64), 1024));
+            const int epoch0 = it * (MM_MAX_FIX + 1) + 1; // stamps of this iteration: epoch0+1 .. epoch0+MM_MAX_FIX
+            hipLaunchKernelGGL((k_minmax_fp<0>), g, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, stamp, fp_blocks, 0, 0,
                                (const int*)nullptr, (int*)nullptr, part, ctl);
             for (int f = 0; f < MM_MAX_FIX; ++f)
-                hipLaunchKernelGGL((k_minmax_fp<1>), gs, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, fp_blocks,
+                hipLaunchKernelGGL((k_minmax_fp<1>), f < 3 ? gwide : gthin, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag,
+                                   stamp, fp_blocks, epoch0 + f, f == 0 ? 1 : 0,
                                    f == 0 ? (const int*)nullptr : (const int*)(chg + f - 1), chg + f, part, ctl);
-            hipLaunchKernelGGL((k_minmax_fp<2>), gs, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, fp_blocks,
-                               (const int*)(chg + MM_MAX_FIX - 1), (int*)nullptr, part, ctl);
+            hipLaunchKernelGGL((k_minmax_fp<2>), gwide, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, stamp, fp_blocks, 0,
+                               0, (const int*)(chg + MM_MAX_FIX - 1), (int*)nullptr, part, ctl);
             hipLaunchKernelGGL(k_reduce_slices, dim3(256), dim3(256), 0, st, (const double*)part, fp_blocks, part2);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, (const double*)part2, 256L, den, tol, d_trace,
                                std::max(iter, 1), ctl);
@@ -773,6 +782,14 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
         if (!fixed_point)
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, n_part, den, tol, d_trace, std::max(iter, 1),
                                ctl);
+        if (fixed_point && trace_fp) {
+            int hc[MM_MAX_FIX + 1] = {0};
+            HIPCHK(hipMemcpyAsync(hc, chg, sizeof hc, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            fprintf(stderr, "[lsf] min/max iteration %d: chunks changed per fix pass:", it + 1);
+            for (int f = 0; f < MM_MAX_FIX; ++f) fprintf(stderr, " %d", hc[f]);
+            fprintf(stderr, "\n");
+        }
         if ((it + 1) % CHECK_EVERY == 0 && it + 1 < iter) {
             HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -782,6 +799,14 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (fixed_point && getenv("LSF_TRACE")) {
+        int hc[MM_MAX_FIX + 1] = {0};
+        HIPCHK(hipMemcpy(hc, chg, sizeof hc, hipMemcpyDeviceToHost));
+        int used = 0;
+        for (int f = 0; f < MM_MAX_FIX; ++f) used += hc[f] != 0;
+        fprintf(stderr, "[lsf] min/max fixed point: last iteration needed %d fix passes that changed cells (cap %d)%s\n", used,
+                MM_MAX_FIX, host_ctl[3] ? "; NOT certified -> tile wavefront rerun" : "");
+    }
     if (inexact) *inexact = host_ctl[3] != 0;
     if (host_ctl[3]) return LSF_OK; // caller restores the input and reruns with the tile wavefront
     const int nit = host_ctl[1];

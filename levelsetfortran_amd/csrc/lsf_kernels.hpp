@@ -269,83 +269,116 @@ __global__ __launch_bounds__(256) void k_minmax_jacobi(const double* __restrict_
 // with the current X of its three upstream neighbours until a whole pass changes nothing.  A cell is
 // final one pass after its upstream cells are final, whatever mixture of old/new values a racing
 // read observes, so the passes may update in place; "no cell changed" certifies the fixed point.
-// Sign flips need |pAve| ~ h1*|curv|, i.e. a handful of cells hugging phi = 0: 2-3 passes in practice.
+// Sign flips need |pAve| ~ h1*|curv|: a handful of cells hugging phi = 0 at first (2-3 passes), but the
+// flow itself breeds such cells (1024^3 two-sphere case: 45 000 chunks change in pass 1 of iteration 12 and
+// the count falls ~4x per pass), so passes after the first visit only the chunks downstream of a change.
 // Fixed point-to-block map (MM_CH points per block) -> per-block band flags and deterministic RMS.
 // ---------------------------------------------------------------------------------------------
 constexpr int MM_CH = 2048;
 
-template <int PASS> // 0: scan (copy + Jacobi update + band flags), 1: fix pass, 2: RMS partials
+// PASS 0: scan (copy + Jacobi update + band flags), one chunk per block.
+// PASS 1: fix pass `epoch` of this call.  The first fix pass of an iteration (first != 0) re-evaluates every
+//         band chunk; later ones only the chunks a change of the previous pass can reach: a cell that changes
+//         stamps the chunks of its three downstream neighbours with epoch+1, and pass epoch+1 visits the
+//         chunks whose stamp is >= epoch+1 (stamps only grow inside a call, so nothing is ever cleared).
+// PASS 2: RMS partials of the band chunks.
+// Passes 1 and 2 find their chunks 64 at a time (one flag per lane of wave 0 + ballot) instead of walking
+// the flag array serially.
+template <int PASS>
 __global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A, double* __restrict__ B,
                                                    const int32_t* __restrict__ nbmask, int nx, int ny, int nz,
-                                                   double dx, double h1, int* __restrict__ blockflag, long nchunks,
+                                                   double dx, double h1, int* __restrict__ blockflag,
+                                                   int* __restrict__ stamp, long nchunks, int epoch, int first,
                                                    const int* __restrict__ changed_prev,
                                                    int* __restrict__ changed_cur, double* __restrict__ partials,
                                                    int* __restrict__ ctl)
 {
     __shared__ double red[4];
     __shared__ int flag;
+    __shared__ unsigned long long todo;
     if (ctl[0]) return;
     if (PASS == 1 && changed_prev && *changed_prev == 0) return;
     const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1), n = sxy * (nz + 1);
     const double dxx = 1. / (dx * dx);
-    // chunks of MM_CH consecutive points; the grid strides over them so that the (mostly empty) fix and
-    // RMS passes cost a few thousand blocks instead of one block per chunk
-    for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        if (PASS != 0 && !blockflag[chunk]) {
-            if (PASS == 2 && threadIdx.x == 0) partials[chunk] = 0.0;
-            continue;
+    const long round = PASS == 0 ? (long)gridDim.x : 64L * gridDim.x;
+    for (long base = 0; base < nchunks; base += round) {
+        unsigned long long m = 1ull;
+        if (PASS != 0) {
+            if (threadIdx.x < 64) {
+                const long ch = base + blockIdx.x + (long)threadIdx.x * gridDim.x;
+                bool need = ch < nchunks && blockflag[ch] != 0;
+                if (PASS == 1 && !first) need = need && stamp[ch] >= epoch;
+                const unsigned long long b = __ballot(need);
+                if (threadIdx.x == 0) todo = b;
+            }
+            __syncthreads();
+            m = todo;
         }
-        if (threadIdx.x == 0) flag = 0;
-        __syncthreads();
-        double acc = 0.0;
-        int mine = 0;
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const long chunk = base + blockIdx.x + (long)l * gridDim.x;
+            if (PASS == 0 && chunk >= nchunks) break;
+            if (threadIdx.x == 0) flag = 0;
+            __syncthreads();
+            double acc = 0.0;
+            int mine = 0;
 #pragma unroll
-        for (int t = 0; t < MM_CH / 256; ++t) {
-            const long p = chunk * MM_CH + t * 256 + threadIdx.x;
-            if (p >= n) break;
-            const int i = p % sx, j = (p / sx) % (ny + 1), k = p / sxy;
-            const double c = A[p];
-            const bool interior = i >= 1 && i <= nx - 1 && j >= 1 && j <= ny - 1 && k >= 1 && k <= nz - 1;
-            const bool band = interior && in_band(nbmask, p, c, dx);
-            if (PASS == 0) {
-                double out = c;
-                if (band) {
-                    const double xm = A[p - 1], xp = A[p + 1], ym = A[p - sx], yp = A[p + sx], zm = A[p - sxy],
-                                 zp = A[p + sxy];
-                    out = minmax_update(c, xm, xp, yp, ym, zp, zm, minmax_curv(c, xp, xm, yp, ym, zp, zm, dxx), h1);
-                    mine = 1;
-                }
-                B[p] = out;
-            } else if (band) {
-                if (PASS == 1) {
-                    const double xm = A[p - 1], xp = A[p + 1], ym = A[p - sx], yp = A[p + sx], zm = A[p - sxy],
-                                 zp = A[p + sxy];
-                    const double curv = minmax_curv(c, xp, xm, yp, ym, zp, zm, dxx);
-                    // upstream neighbours from the evolving field (B holds A wherever nothing was updated)
-                    const double nv = minmax_update(c, B[p - 1], xp, yp, B[p - sx], zp, B[p - sxy], curv, h1);
-                    const double cur = B[p];
-                    if (!(nv == cur)) {
-                        B[p] = nv;
+            for (int t = 0; t < MM_CH / 256; ++t) {
+                const long p = chunk * MM_CH + t * 256 + threadIdx.x;
+                if (p >= n) break;
+                const int i = p % sx, j = (p / sx) % (ny + 1), k = p / sxy;
+                const double c = A[p];
+                const bool interior = i >= 1 && i <= nx - 1 && j >= 1 && j <= ny - 1 && k >= 1 && k <= nz - 1;
+                const bool band = interior && in_band(nbmask, p, c, dx);
+                if (PASS == 0) {
+                    double out = c;
+                    if (band) {
+                        const double xm = A[p - 1], xp = A[p + 1], ym = A[p - sx], yp = A[p + sx], zm = A[p - sxy],
+                                     zp = A[p + sxy];
+                        out = minmax_update(c, xm, xp, yp, ym, zp, zm, minmax_curv(c, xp, xm, yp, ym, zp, zm, dxx), h1);
                         mine = 1;
                     }
-                } else {
-                    const double d = B[p] - c;
-                    acc += d * d;
+                    B[p] = out;
+                } else if (band) {
+                    if (PASS == 1) {
+                        const double xm = A[p - 1], xp = A[p + 1], ym = A[p - sx], yp = A[p + sx], zm = A[p - sxy],
+                                     zp = A[p + sxy];
+                        const double curv = minmax_curv(c, xp, xm, yp, ym, zp, zm, dxx);
+                        // upstream neighbours from the evolving field (B holds A wherever nothing was updated)
+                        const double nv = minmax_update(c, B[p - 1], xp, yp, B[p - sx], zp, B[p - sxy], curv, h1);
+                        const double cur = B[p];
+                        if (!(nv == cur)) {
+                            B[p] = nv;
+                            mine = 1;
+                            // the three cells that read this one: interior, hence inside the array
+                            stamp[(p + 1) / MM_CH] = epoch + 1;
+                            stamp[(p + sx) / MM_CH] = epoch + 1;
+                            stamp[(p + sxy) / MM_CH] = epoch + 1;
+                        }
+                    } else {
+                        const double d = B[p] - c;
+                        acc += d * d;
+                    }
                 }
             }
-        }
-        if (PASS == 2) {
-            acc = wave_sum(acc);
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-            __syncthreads();
-            if (threadIdx.x == 0) partials[chunk] = red[0] + red[1] + red[2] + red[3];
-        } else {
-            if (mine) flag = 1;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                if (PASS == 0) blockflag[chunk] = flag;
-                else if (flag) *changed_cur = 1;
+            if (PASS == 2) {
+                acc = wave_sum(acc);
+                if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+                __syncthreads();
+                if (threadIdx.x == 0) partials[chunk] = red[0] + red[1] + red[2] + red[3];
+            } else {
+                if (mine) flag = 1;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    if (PASS == 0) {
+                        blockflag[chunk] = flag;
+                        partials[chunk] = 0.0; // pass 2 overwrites the band chunks
+                    } else if (flag)
+                        atomicAdd(changed_cur, 1); // number of chunks this pass still changed
+                }
             }
+            __syncthreads();
         }
         __syncthreads();
     }

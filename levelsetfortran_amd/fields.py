@@ -40,3 +40,21 @@ def two_sphere_phi0(npts, lo=-1.5, hi=1.5, ranges=None):
 def reinit_step(dx: float, extent=(2.0, 2.0, 2.0), cfl: float = 0.1) -> float:
     """h = CFL * dx / |bbox diagonal| (set3d.f90:301-305); extent (2,2,2) is cube40's bounding box."""
     return cfl * dx / float(np.sqrt(extent[0] ** 2 + extent[1] ** 2 + extent[2] ** 2))
+
+
+def two_sphere_phi0_device(npts, device, lo=-1.5, hi=1.5):
+    """Same field as two_sphere_phi0, generated directly in HBM with torch (for grids whose numpy temporaries
+    would not fit in host memory, e.g. 1024^3).  Returns (1-D float64 CUDA tensor, i fastest; dx)."""
+    import torch
+
+    nxp, nyp, nzp = npts
+    dx = (hi - lo) / (nxp - 1)
+    ax = [lo + dx * torch.arange(n, dtype=torch.float64, device=device) for n in (nxp, nyp, nzp)]
+    d = None
+    for c in ((-0.6, 0.0, 0.0), (0.6, 0.0, 0.0)):
+        r2 = (ax[2][:, None, None] - c[2]) ** 2 + (ax[1][None, :, None] - c[1]) ** 2 + (ax[0][None, None, :] - c[0]) ** 2
+        r2.sqrt_().sub_(0.5)
+        d = r2 if d is None else torch.minimum(d, r2)
+        del r2
+    phi = d / torch.sqrt(d * d + dx * dx)
+    return phi.reshape(-1), float(dx)
