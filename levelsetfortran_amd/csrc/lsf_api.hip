@@ -75,7 +75,7 @@ struct TileList {
     std::vector<int> off; // plane offsets, size nplanes+1
 };
 
-enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_FLAGS, S_FLOWCTL, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_NSLOTS };
+enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_FLAGS, S_FLOWCTL, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_NSLOTS };
 
 struct Ctx {
     Buf slot[S_NSLOTS];
@@ -455,6 +455,7 @@ int reinit_flow_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         FlowArgs fa;
         fa.buf[0] = d_phi;
         fa.buf[1] = (double*)c.slot[S_PONG].p;
+        fa.nbuf = 2;
         fa.phiS = d_phiS;
         fa.nx = nx, fa.ny = ny, fa.nz = nz, fa.nTi = nTi, fa.nTj = nTj, fa.nTk = nTk;
         fa.dx = dx, fa.h = h;
@@ -553,6 +554,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
     const int max_sweeps = iter + 1;
     if ((rc = ws(c.slot[S_PONG], n * sizeof(double)))) return rc;
+    if ((rc = ws(c.slot[S_PONG2], n * sizeof(double)))) return rc;
     const double* d_phiS = d_phiS_in;
     if (!d_phiS) {
         if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
@@ -568,14 +570,18 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     if ((rc = get_tiles(nTi, nTj, nTk, &tl))) return rc;
     if ((rc = ws(c.slot[S_CTL], 64))) return rc;
     if ((rc = ws(c.slot[S_TRACE], (size_t)max_sweeps * sizeof(double)))) return rc;
-    if ((rc = ws(c.slot[S_COLSUM], (size_t)2 * nTj * nTk * sizeof(double)))) return rc;
+    if ((rc = ws(c.slot[S_COLSUM], (size_t)3 * nTj * nTk * sizeof(double)))) return rc;
     int* ctl = (int*)c.slot[S_CTL].p;
     HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
 
+    // Three field buffers in rotation: sweep g overwrites the result of sweep g-3, so it has to wait for the
+    // stop verdict of sweep g-3 only, and consecutive sweeps are spaced by the raster-flip rule alone.
     FlowArgs fa;
     std::memset(&fa, 0, sizeof fa);
     fa.buf[0] = d_phi;
     fa.buf[1] = (double*)c.slot[S_PONG].p;
+    fa.buf[2] = (double*)c.slot[S_PONG2].p;
+    fa.nbuf = 3;
     fa.phiS = d_phiS;
     fa.nx = nx, fa.ny = ny, fa.nz = nz, fa.nTi = nTi, fa.nTj = nTj, fa.nTk = nTk;
     fa.dx = dx, fa.h = h;
@@ -598,7 +604,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             for (int ax = 0; ax < 3; ++ax)
                 if (da[ax] != db[ax]) H += nT[ax] - 1;
             long s0 = start[q - 1] + H;
-            if (q >= 2) s0 = std::max(s0, start[q - 2] + np + 1);
+            if (q >= 3) s0 = std::max(s0, start[q - 3] + np + 1);
             if (!overlap) s0 = start[q - 1] + np;
             start.push_back(s0);
         }
@@ -612,8 +618,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     int epilogues = 0;     // sweeps whose last hyperplane has been launched
     bool stop = false;
     for (long slot = 0; !stop && lo < max_sweeps; ++slot) {
-        int nseg = 0;
-        fa.seg_count[0] = fa.seg_count[1] = 0;
+        int nseg = 0, grid = 0;
         // timing experiment only (results are wrong): every tile of a sweep in ONE launch = the pure work term
         static const bool nodeps = getenv("LSF_GS_NODEPS_EXPERIMENT") != nullptr;
         for (int g = lo; g < max_sweeps && start_of(g) <= slot; ++g) {
@@ -622,16 +627,17 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             int cnt = tl->off[P + 1] - tl->off[P];
             if (nodeps) cnt = P == 0 ? tl->off[np] : 0;
             if (cnt <= 0) continue;
-            if (nseg == 2) return fail(LSF_ERR_HIP, "internal: more than two sweeps in flight");
+            if (nseg == 4) return fail(LSF_ERR_HIP, "internal: more than four sweeps in flight");
             fa.seg_tiles[nseg] = tl->d + tl->off[P];
-            fa.seg_count[nseg] = cnt;
+            grid += cnt;
+            fa.seg_end[nseg] = grid;
             fa.seg_g[nseg] = g;
             for (int ax = 0; ax < 3; ++ax) fa.seg_sign[nseg][ax] = RASTER_SIGN[(first_raster + g) & 7][ax];
             ++nseg;
             if (P == np - 1) ++epilogues;
         }
         while (lo < max_sweeps && start_of(lo) + np <= slot + 1) ++lo;
-        const int grid = fa.seg_count[0] + fa.seg_count[1];
+        for (int q = nseg; q < 4; ++q) fa.seg_end[q] = grid;
         if (grid > 0) {
 #define LSF_LAUNCH_SLOT(TA_, NY_, ST_) \
     hipLaunchKernelGGL((k_reinit_gs_flow<TA_, NY_, ST_, true>), dim3(grid), dim3(64), 0, st, fa)
@@ -671,9 +677,8 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         g_prof.sweeps = nsw;
         g_prof.sweep_launches = launches;
     }
-    double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
-    if (bufs[nsw & 1] != d_phi)
-        HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (fa.buf[nsw % 3] != d_phi)
+        HIPCHK(hipMemcpyAsync(d_phi, fa.buf[nsw % 3], n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (rms_trace && trace_cap > 0 && nsw > 0)
         HIPCHK(hipMemcpyAsync(rms_trace, c.slot[S_TRACE].p, sizeof(double) * (size_t)std::min(nsw, trace_cap),
                               hipMemcpyDeviceToHost, st));

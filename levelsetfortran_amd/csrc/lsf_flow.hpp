@@ -39,7 +39,8 @@
 namespace lsf {
 
 struct FlowArgs {
-    double* buf[2];
+    double* buf[3];     // sweep g reads buf[g % nbuf] and writes buf[(g + 1) % nbuf]
+    int nbuf;           // 2 (flow) or 3 (slots: three sweeps in flight, see reinit_slot_core)
     const double* phiS;
     int nx, ny, nz, nTi, nTj, nTk;
     double dx, h;
@@ -52,18 +53,20 @@ struct FlowArgs {
     int* ticket;        // task counter
     int* tiles_done;    // [8] per local sweep
     int* verdict;       // number of sweeps with a verdict
-    double* colsum;     // [2][nTj*nTk]
+    double* colsum;     // [nbuf][nTj*nTk]
     double* trace;
     int trace_cap;
     double den, tol;
     int* ctl;           // [0] done, [1] sweeps completed, [2] status (1 NaN, 2 timeout), [3] unused
     long nTiles;
-    // SLOT mode (one launch per time slot, dependencies resolved by launch order): up to two tile-plane
-    // segments, one per sweep in flight; blockIdx.x < seg_count[0] belongs to segment 0
-    const uint32_t* seg_tiles[2];
-    int seg_count[2];
-    int seg_g[2];       // global sweep index of each segment
-    int seg_sign[2][3];
+    // SLOT mode (one launch per time slot, dependencies resolved by launch order): up to FLOW_MAXSEG
+    // tile-plane segments, one per sweep in flight; seg_end[] = running block count (segment q holds the
+    // blocks seg_end[q-1] <= blockIdx.x < seg_end[q])
+    const uint32_t* seg_tiles[4];
+    int seg_end[4];
+    int seg_g[4];       // global sweep index of each segment
+    int seg_sign[4][3];
+    uint32_t last_packed; // skewed tiles (lsf_skew.hpp): the tile that runs the sweep epilogue
     unsigned long long* dbg; // optional phase timers (s_memrealtime ticks): wait, load, march, publish, tasks
     int knobs;          // experiment bits: 1 no acquire fence, 2 plain (non-sc1) loads, 4 long sleep, 8 plain stores
 };
@@ -135,8 +138,9 @@ __global__ __launch_bounds__(64) void k_reinit_gs_flow(FlowArgs a)
         int s, g, si, sj, sk;
         uint32_t packed;
         if constexpr (SLOT) {
-            const int seg = (int)blockIdx.x < a.seg_count[0] ? 0 : 1;
-            const int q = (int)blockIdx.x - (seg ? a.seg_count[0] : 0);
+            const int bx = (int)blockIdx.x;
+            const int seg = (bx >= a.seg_end[0]) + (bx >= a.seg_end[1]) + (bx >= a.seg_end[2]);
+            const int q = bx - (seg ? a.seg_end[seg - 1] : 0);
             packed = a.seg_tiles[seg][q];
             g = a.seg_g[seg], s = 0;
             si = a.seg_sign[seg][0], sj = a.seg_sign[seg][1], sk = a.seg_sign[seg][2];
@@ -205,8 +209,9 @@ __global__ __launch_bounds__(64) void k_reinit_gs_flow(FlowArgs a)
         if constexpr (!SLOT)
             if (!(a.knobs & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
-        const double* in = a.buf[g & 1];
-        double* out = a.buf[(g + 1) & 1];
+        const int gb = g % a.nbuf;
+        const double* in = a.buf[gb];
+        double* out = a.buf[gb + 1 == a.nbuf ? 0 : gb + 1];
         const long dOI = out - in; // element offset that turns an `in` address into an `out` address
         const int i_lo = 1 + ti * TA, j_lo = 1 + tj * NY, k_lo = 1 + tk * 4;
         const int ni = min(TA, nx - i_lo), nj = min(NY, ny - j_lo), nk = min(4, nz - k_lo);
@@ -397,14 +402,14 @@ __global__ __launch_bounds__(64) void k_reinit_gs_flow(FlowArgs a)
             // the column's previous tile ran in an earlier launch; the far-corner tile (alone on the last
             // hyperplane of its sweep) runs the sweep epilogue, every other tile of the sweep is already done
             if (lane == 0) {
-                double* slot = a.colsum + (long)(g & 1) * ncol + (tj + (long)a.nTj * tk);
+                double* slot = a.colsum + (long)gb * ncol + (tj + (long)a.nTj * tk);
                 *slot = ((fA == 0) ? 0.0 : *slot) + acc;
             }
             last = fA == a.nTi - 1 && fB == a.nTj - 1 && fC == a.nTk - 1;
             __syncthreads();
         } else {
             if (lane == 0) {
-                double* slot = a.colsum + (long)(g & 1) * ncol + (tj + (long)a.nTj * tk);
+                double* slot = a.colsum + (long)gb * ncol + (tj + (long)a.nTj * tk);
                 const double prev = (fA == 0) ? 0.0 : ld_sc1(slot);
                 st_sc1(slot, prev + acc);
             }
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(64) void k_reinit_gs_flow(FlowArgs a)
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
-            const double* cs = a.colsum + (long)(g & 1) * ncol;
+            const double* cs = a.colsum + (long)gb * ncol;
             double t = 0.0;
             for (int p = lane; p < ncol; p += 64) t += SLOT ? cs[p] : ld_sc1(cs + p);
             t = wave_sum(t);
