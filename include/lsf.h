@@ -70,6 +70,9 @@ int lsf_release_workspace(void);
 int lsf_profile(int enable);
 int lsf_profile_get(double *sweep_kernel_ms, double *bc_ms, double *finish_ms,
                     long long *sweep_kernel_launches, int *sweeps);
+/* name of the sweep kernel the last profiled call launched (the exact ordering picks its tile shape by
+ * grid size); "" before the first profiled call.  The string is static. */
+const char *lsf_profile_kernel(void);
 
 /* ---- seam 1: reinit ----------------------------------------------------------------------
  * Replaces SUBROUTINE reinit(phi,gradPhi,gradPhiMag,nx,ny,nz,iter,dx,h), subs.f90:717-931.

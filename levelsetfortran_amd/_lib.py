@@ -45,6 +45,7 @@ SIGNATURES = {
     "lsf_set_device": (c_int, [c_int]),
     "lsf_release_workspace": (c_int, []),
     "lsf_profile": (c_int, [c_int]),
+    "lsf_profile_kernel": (ctypes.c_char_p, []),
     "lsf_profile_get": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_double),
                                 POINTER(ctypes.c_longlong), POINTER(c_int)]),
     "lsf_reinit": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_int,

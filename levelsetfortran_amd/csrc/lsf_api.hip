@@ -15,6 +15,7 @@
 #include "../../include/lsf.h"
 #include "lsf_kernels.hpp"
 #include "lsf_flow.hpp"
+#include "lsf_skew.hpp"
 
 using namespace lsf;
 
@@ -73,6 +74,7 @@ struct Buf {
 struct TileList {
     uint32_t* d = nullptr;
     std::vector<int> off; // plane offsets, size nplanes+1
+    uint32_t last = 0;    // skewed lists: the only tile of the last plane
 };
 
 enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_FLAGS, S_FLOWCTL, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_NSLOTS };
@@ -81,6 +83,7 @@ struct Ctx {
     Buf slot[S_NSLOTS];
     std::map<hipStream_t, Buf> part_by_stream;
     std::map<uint64_t, TileList> tiles;
+    std::map<uint64_t, TileList> skew_tiles;
     bool checked = false;
 };
 
@@ -93,6 +96,7 @@ struct Profile {
     double sweep_ms = 0, bc_ms = 0, finish_ms = 0;
     long sweep_launches = 0;
     int sweeps = 0;
+    const char* kernel = ""; // name of the sweep kernel of the last profiled call
     std::vector<hipEvent_t> ev; // 4 per timed sweep
 };
 thread_local Profile g_prof;
@@ -200,6 +204,83 @@ int get_tiles(int nA, int nB, int nC, TileList** out)
     return LSF_OK;
 }
 
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Skewed tiles (lsf_skew.hpp): (m, fB, fC) with TA m <= Fx + Fy + Fz < TA m + TA for some cell of row bundle
+// (fB, fC); the m range assumes full bundles (NY x 4 rows), a superset for the partial bundles at the far walls
+// (such a tile simply finds no cell to work on).  Sorted by hyperplane m + fB + fC.
+int get_skew_tiles(int nxi, int nTj, int nTk, int ta, int nyc, TileList** out)
+{
+    const int m_max = (nxi - 1 + nyc * nTj - 1 + 4 * nTk - 1) / ta;
+    if (m_max > 1023 || nTj > 1023 || nTk > 1023) return fail(LSF_ERR_INVALID, "grid too large for tile index packing");
+    const uint64_t key = ((uint64_t)nxi << 40) | ((uint64_t)nTj << 20) | (uint64_t)nTk;
+    Ctx& c = ctx();
+    auto it = c.skew_tiles.find(key);
+    if (it == c.skew_tiles.end()) {
+        const int nplanes = m_max + nTj + nTk - 1;
+        std::vector<int> cnt(nplanes + 1, 0);
+        auto m_lo = [&](int B, int C) { return (nyc * B + 4 * C) / ta; };
+        auto m_hi = [&](int B, int C) { return (nyc * B + nyc - 1 + 4 * C + 3 + nxi - 1) / ta; };
+        for (int C = 0; C < nTk; ++C)
+            for (int B = 0; B < nTj; ++B)
+                for (int m = m_lo(B, C); m <= m_hi(B, C); ++m) ++cnt[m + B + C];
+        TileList tl;
+        tl.off.assign(nplanes + 1, 0);
+        for (int P = 0; P < nplanes; ++P) tl.off[P + 1] = tl.off[P] + cnt[P];
+        std::vector<uint32_t> h((size_t)tl.off[nplanes]);
+        std::vector<int> fill(tl.off.begin(), tl.off.end() - 1);
+        // bundles of one plane in (C, B) order: neighbouring blocks share halo rows
+        for (int C = 0; C < nTk; ++C)
+            for (int B = 0; B < nTj; ++B)
+                for (int m = m_lo(B, C); m <= m_hi(B, C); ++m)
+                    h[(size_t)fill[m + B + C]++] = (uint32_t)m | ((uint32_t)B << 10) | ((uint32_t)C << 20);
+        tl.last = (uint32_t)m_hi(nTj - 1, nTk - 1) | ((uint32_t)(nTj - 1) << 10) | ((uint32_t)(nTk - 1) << 20);
+        if (tl.off[nplanes] - tl.off[nplanes - 1] != 1 || h.back() != tl.last)
+            return fail(LSF_ERR_HIP, "internal: skewed tile list does not end in a single tile");
+        HIPCHK(hipMalloc((void**)&tl.d, h.size() * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(tl.d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        it = c.skew_tiles.emplace(key, std::move(tl)).first;
+    }
+    *out = &it->second;
+    return LSF_OK;
+}
+
+// Spacing of two consecutive sweeps on skewed tiles: sweep g+1 (signs db) may run hyperplane P' of its tiles in
+// slot start[g+1] + P' only after every sweep-g tile (signs da) that holds a cell within stencil reach (the cell
+// itself or up to 3 cells along one axis) has run:  H > P_g(v) - P_{g+1}(u)  for all such pairs.  With
+// P = floor((Fx + Fy + Fz) / TA) + fB + fC and floor(p) - floor(q) <= floor(p - q) + 1 the maximum separates into
+// one 1-D scan per axis (exact up to one slot).
+long skew_spacing(const int* da, const int* db, int nx, int ny, int nz, int ta, int nyc)
+{
+    const int nq[3] = {nx, ny, nz}, ts[3] = {0, nyc, 4};
+    long m0[3], md[3];
+    for (int ax = 0; ax < 3; ++ax) {
+        const int n = nq[ax], TS = ts[ax], nT = TS ? cdiv(n - 1, TS) : 0;
+        // frame index + TA * bundle index of interior coordinate g (1..n-1) for direction sgn
+        auto w = [&](int g, int sgn) -> long {
+            if (!TS) return sgn > 0 ? g - 1 : n - 1 - g;
+            const int t = (g - 1) / TS, y = (g - 1) - t * TS, cntt = std::min(TS, n - 1 - t * TS);
+            const int fT = sgn > 0 ? t : nT - 1 - t, b = sgn > 0 ? y : cntt - 1 - y;
+            return (long)TS * fT + b + (long)ta * fT;
+        };
+        m0[ax] = md[ax] = -(1L << 40);
+        for (int g = 1; g <= n - 1; ++g) {
+            const long wu = w(g, db[ax]);
+            for (int d = -3; d <= 3; ++d) {
+                if (g + d < 1 || g + d > n - 1) continue;
+                const long v = w(g + d, da[ax]) - wu;
+                if (d == 0) m0[ax] = std::max(m0[ax], v);
+                else md[ax] = std::max(md[ax], v);
+            }
+        }
+        if (md[ax] < m0[ax]) md[ax] = m0[ax]; // an axis with a single interior cell has no neighbour
+    }
+    long tot = m0[0] + m0[1] + m0[2];
+    for (int ax = 0; ax < 3; ++ax) tot = std::max(tot, m0[0] + m0[1] + m0[2] - m0[ax] + md[ax]);
+    const long q = tot >= 0 ? tot / ta : -((-tot + ta - 1) / ta);
+    return q + 2;
+}
+
 double rms_denominator(int nx, int ny, int nz)
 {
     // INTEGER*4 product nx*ny*nz, subs.f90:914 / set3d.f90:447 (wraps like the reference)
@@ -208,8 +289,6 @@ double rms_denominator(int nx, int ny, int nz)
 
 const int RASTER_SIGN[8][3] = {{+1, +1, +1}, {+1, +1, -1}, {+1, -1, -1}, {-1, -1, -1},
                                {-1, +1, -1}, {-1, -1, +1}, {-1, +1, +1}, {+1, -1, +1}};
-
-inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 dim3 bc_grid(int e0, int e1, int e2)
 {
@@ -311,6 +390,7 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     const int nsw = host_ctl[1];
     prof_end(nsw);
     g_prof.sweep_launches = launches_per_sweep * g_prof.sweeps;
+    g_prof.kernel = "k_reinit_jacobi";
     if (bufs[nsw & 1] != d_phi)
         HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (rms_trace && trace_cap > 0 && nsw > 0)
@@ -401,7 +481,9 @@ int gs_schedule()
     const char* e = getenv("LSF_GS_SCHEDULE");
     if (e && std::strcmp(e, "planes") == 0) return 0;
     if (e && std::strcmp(e, "flow") == 0) return 2;
-    return 1;
+    if (e && std::strcmp(e, "skew") == 0) return 3;
+    if (e && std::strcmp(e, "slots") == 0) return 1;
+    return -1; // unset: slots on box tiles for small grids, on skewed tiles for large ones
 }
 
 int reinit_flow_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
@@ -562,12 +644,21 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         d_phiS = (const double*)c.slot[S_PHIS].p;
     }
     const int ta = gs_ta(), nyc = gs_ny();
-    const bool overlap = gs_schedule() == 1; // "planes": one sweep at a time (start[g+1] = start[g] + nPlanes)
+    int sched = gs_schedule();
+    // Box tiles keep 70 % of their lanes busy but need fewer time slots per sweep; skewed tiles (lsf_skew.hpp) do
+    // 19 % less work per sweep in 25 % more slots.  Measured break-even near 256^3 (1.75 vs 1.77 ms), skewed tiles
+    // win above it (512^3: 7.12 -> 6.56 ms, 1024^3: 38.0 -> 32.8 ms per sweep).
+    if (sched < 0) sched = (double)(nx - 1) * (ny - 1) * (nz - 1) >= 3.0e7 ? 3 : 1;
+    // skewed tiles need TA = 16, NY = 5 and at least two interior cells per axis
+    const bool skew = sched == 3 && ta == 16 && nyc == 5 && nx >= 3 && ny >= 3 && nz >= 3;
+    const bool overlap = sched != 0; // "planes": one sweep at a time (start[g+1] = start[g] + nPlanes)
     const int nTi = cdiv(nx - 1, ta), nTj = cdiv(ny - 1, nyc), nTk = cdiv(nz - 1, 4);
     const int nT[3] = {nTi, nTj, nTk};
-    const int np = nTi + nTj + nTk - 2;
     TileList* tl = nullptr;
-    if ((rc = get_tiles(nTi, nTj, nTk, &tl))) return rc;
+    if (skew) rc = get_skew_tiles(nx - 1, nTj, nTk, ta, nyc, &tl);
+    else rc = get_tiles(nTi, nTj, nTk, &tl);
+    if (rc) return rc;
+    const int np = (int)tl->off.size() - 1;
     if ((rc = ws(c.slot[S_CTL], 64))) return rc;
     if ((rc = ws(c.slot[S_TRACE], (size_t)max_sweeps * sizeof(double)))) return rc;
     if ((rc = ws(c.slot[S_COLSUM], (size_t)3 * nTj * nTk * sizeof(double)))) return rc;
@@ -592,6 +683,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     fa.tol = tol;
     fa.ctl = ctl;
     fa.nTiles = (long)nTi * nTj * nTk;
+    fa.last_packed = tl->last;
 
     // start slot of sweep g, generated on demand
     std::vector<long> start{0};
@@ -603,6 +695,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             long H = 2;
             for (int ax = 0; ax < 3; ++ax)
                 if (da[ax] != db[ax]) H += nT[ax] - 1;
+            if (skew) H = skew_spacing(da, db, nx, ny, nz, ta, nyc);
             long s0 = start[q - 1] + H;
             if (q >= 3) s0 = std::max(s0, start[q - 3] + np + 1);
             if (!overlap) s0 = start[q - 1] + np;
@@ -614,6 +707,29 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     prof_begin();
     prof_mark(st);
     long launches = 0;
+    auto launch_tiles = [&](int grid, hipStream_t s_) {
+        if (skew) {
+            if (strict) hipLaunchKernelGGL((k_reinit_gs_skew<16, 5, true>), dim3(grid), dim3(64), 0, s_, fa);
+            else hipLaunchKernelGGL((k_reinit_gs_skew<16, 5, false>), dim3(grid), dim3(64), 0, s_, fa);
+            return;
+        }
+#define LSF_LAUNCH_SLOT(TA_, NY_, ST_) \
+    hipLaunchKernelGGL((k_reinit_gs_flow<TA_, NY_, ST_, true>), dim3(grid), dim3(64), 0, s_, fa)
+#define LSF_LAUNCH_SLOT_NY(TA_, ST_)           \
+    do {                                       \
+        if (nyc == 5) LSF_LAUNCH_SLOT(TA_, 5, ST_); \
+        else LSF_LAUNCH_SLOT(TA_, 4, ST_);     \
+    } while (0)
+        if (strict) {
+            if (ta == 16) LSF_LAUNCH_SLOT_NY(16, true);
+            else LSF_LAUNCH_SLOT_NY(32, true);
+        } else {
+            if (ta == 16) LSF_LAUNCH_SLOT_NY(16, false);
+            else LSF_LAUNCH_SLOT_NY(32, false);
+        }
+#undef LSF_LAUNCH_SLOT_NY
+#undef LSF_LAUNCH_SLOT
+    };
     int lo = 0;            // first sweep that still has hyperplanes to launch
     int epilogues = 0;     // sweeps whose last hyperplane has been launched
     bool stop = false;
@@ -639,22 +755,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         while (lo < max_sweeps && start_of(lo) + np <= slot + 1) ++lo;
         for (int q = nseg; q < 4; ++q) fa.seg_end[q] = grid;
         if (grid > 0) {
-#define LSF_LAUNCH_SLOT(TA_, NY_, ST_) \
-    hipLaunchKernelGGL((k_reinit_gs_flow<TA_, NY_, ST_, true>), dim3(grid), dim3(64), 0, st, fa)
-#define LSF_LAUNCH_SLOT_NY(TA_, ST_)           \
-    do {                                       \
-        if (nyc == 5) LSF_LAUNCH_SLOT(TA_, 5, ST_); \
-        else LSF_LAUNCH_SLOT(TA_, 4, ST_);     \
-    } while (0)
-            if (strict) {
-                if (ta == 16) LSF_LAUNCH_SLOT_NY(16, true);
-                else LSF_LAUNCH_SLOT_NY(32, true);
-            } else {
-                if (ta == 16) LSF_LAUNCH_SLOT_NY(16, false);
-                else LSF_LAUNCH_SLOT_NY(32, false);
-            }
-#undef LSF_LAUNCH_SLOT_NY
-#undef LSF_LAUNCH_SLOT
+            launch_tiles(grid, st);
             ++launches;
         }
         if (epilogues >= CHECK_EVERY && lo < max_sweeps) {
@@ -676,6 +777,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         g_prof.bc_ms = g_prof.finish_ms = 0;
         g_prof.sweeps = nsw;
         g_prof.sweep_launches = launches;
+        g_prof.kernel = skew ? "k_reinit_gs_skew" : "k_reinit_gs_flow";
     }
     if (fa.buf[nsw % 3] != d_phi)
         HIPCHK(hipMemcpyAsync(d_phi, fa.buf[nsw % 3], n * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -696,11 +798,14 @@ int narrowband_core(const double* d_phi, int32_t* d_nb, int32_t* d_sb, size_t n,
     return LSF_OK;
 }
 
-constexpr int MM_MAX_FIX = 32; // fix passes per min/max iteration before the fixed point counts as uncertified
+constexpr int MM_MAX_FIX = 32;   // most fix passes ever enqueued per min/max iteration
+constexpr int MM_FIX_START = 12; // adaptive mode: passes enqueued per iteration until the first host check
+// how the exact ordering of the min/max flow is produced
+enum MinmaxExact { MM_TILES = 0, MM_FP_ADAPTIVE = 1, MM_FP_FULL = 2 };
 
 int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int nz, int iter, double dx,
                      double h1, double tol, int mode, int* iters_done, double* rms_trace, int trace_cap,
-                     hipStream_t st, bool use_tiles, bool* inexact)
+                     hipStream_t st, int exact_mode, bool* inexact)
 {
     int rc = check_dims(nx, ny, nz);
     if (rc) return rc;
@@ -720,7 +825,7 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     TileList* tl = nullptr;
     int nTi = 0, nTj = 0, nTk = 0, jblocks = 0;
     long n_part;
-    const bool fixed_point = order == LSF_ORDER_GS && !use_tiles;
+    const bool fixed_point = order == LSF_ORDER_GS && exact_mode != MM_TILES;
     const long fp_blocks = (long)((n + MM_CH - 1) / MM_CH);
     int *bflag = nullptr, *chg = nullptr, *stamp = nullptr;
     constexpr size_t CHG_BYTES = (MM_MAX_FIX + 1) * sizeof(int);
@@ -749,9 +854,14 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     const double den = rms_denominator(nx, ny, nz);
 
     double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
-    int host_ctl[4] = {0, 0, 0, 0};
+    int host_ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const char* tfp = getenv("LSF_TRACE_MINMAX");
     const bool trace_fp = tfp && atoi(tfp) != 0;
+    // Fix passes enqueued per iteration.  A pass that finds the fixed point certified returns at once, but an empty
+    // launch still costs ~6 us, so the count follows what the field needs (ctl[4] = most passes that changed cells,
+    // read with the stop flag every CHECK_EVERY iterations): twice that plus two.  Too few -> ctl[3], the caller
+    // repeats the call with MM_MAX_FIX passes.
+    int cap = exact_mode == MM_FP_FULL ? MM_MAX_FIX : MM_FIX_START;
     for (int it = 0; it < iter; ++it) { // DO n = 1,iter (set3d.f90:394)
         const double* A = bufs[it & 1];
         double* B = bufs[(it + 1) & 1];
@@ -763,12 +873,13 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
             const int epoch0 = it * (MM_MAX_FIX + 1) + 1; // stamps of this iteration: epoch0+1 .. epoch0+MM_MAX_FIX
             hipLaunchKernelGGL((k_minmax_fp<0>), g, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, stamp, fp_blocks, 0, 0,
                                (const int*)nullptr, (int*)nullptr, part, ctl);
-            for (int f = 0; f < MM_MAX_FIX; ++f)
+            for (int f = 0; f < cap; ++f)
                 hipLaunchKernelGGL((k_minmax_fp<1>), f < 3 ? gwide : gthin, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag,
                                    stamp, fp_blocks, epoch0 + f, f == 0 ? 1 : 0,
                                    f == 0 ? (const int*)nullptr : (const int*)(chg + f - 1), chg + f, part, ctl);
+            // pass 2 also records how many fix passes changed cells (first = cap) and flags an uncertified iteration
             hipLaunchKernelGGL((k_minmax_fp<2>), gwide, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, stamp, fp_blocks, 0,
-                               0, (const int*)(chg + MM_MAX_FIX - 1), (int*)nullptr, part, ctl);
+                               cap, (const int*)(chg + cap - 1), (int*)nullptr, part, ctl);
             hipLaunchKernelGGL(k_reduce_slices, dim3(256), dim3(256), 0, st, (const double*)part, fp_blocks, part2);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, (const double*)part2, 256L, den, tol, d_trace,
                                std::max(iter, 1), ctl);
@@ -799,6 +910,7 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
             HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             if (host_ctl[0] || host_ctl[3]) break;
+            if (exact_mode == MM_FP_ADAPTIVE) cap = std::min(MM_MAX_FIX, std::max(6, 2 * host_ctl[4] + 2));
         }
     }
     HIPCHK(hipGetLastError());
@@ -809,8 +921,8 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
         HIPCHK(hipMemcpy(hc, chg, sizeof hc, hipMemcpyDeviceToHost));
         int used = 0;
         for (int f = 0; f < MM_MAX_FIX; ++f) used += hc[f] != 0;
-        fprintf(stderr, "[lsf] min/max fixed point: last iteration needed %d fix passes that changed cells (cap %d)%s\n", used,
-                MM_MAX_FIX, host_ctl[3] ? "; NOT certified -> tile wavefront rerun" : "");
+        fprintf(stderr, "[lsf] min/max fixed point: last iteration needed %d fix passes that changed cells (%d enqueued)%s\n",
+                used, cap, host_ctl[3] ? "; NOT certified -> rerun" : "");
     }
     if (inexact) *inexact = host_ctl[3] != 0;
     if (host_ctl[3]) return LSF_OK; // caller restores the input and reruns with the tile wavefront
@@ -834,8 +946,9 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     return LSF_OK;
 }
 
-// Exact ordering: fixed-point passes (fast); if a fixed point is ever not certified within MM_MAX_FIX passes
-// (never observed), restore the input and redo the call with the tile-hyperplane wavefront.
+// Exact ordering: fixed-point passes (fast), as many per iteration as the field has needed so far; if a fixed point is
+// ever not certified, restore the input and redo the call with MM_MAX_FIX passes per iteration, and if that is still
+// not enough (never observed) with the tile-hyperplane wavefront.
 int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int nz, int iter, double dx,
                 double h1, double tol, int mode, int* iters_done, double* rms_trace, int trace_cap,
                 hipStream_t st)
@@ -845,7 +958,7 @@ int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int
     if ((mode & LSF_ORDER_MASK) != LSF_ORDER_GS || force_tiles || !d_phi || !d_nb || !d_sb || iter <= 0 ||
         check_dims(nx, ny, nz))
         return minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace,
-                                trace_cap, st, true, nullptr);
+                                trace_cap, st, MM_TILES, nullptr);
     Ctx& c = ctx();
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
     int rc = ws(c.slot[S_BACKUP], n * (sizeof(double) + 2 * sizeof(int32_t)));
@@ -855,16 +968,18 @@ int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int
     HIPCHK(hipMemcpyAsync(bk + n * sizeof(double), d_nb, n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(bk + n * (sizeof(double) + sizeof(int32_t)), d_sb, n * sizeof(int32_t),
                           hipMemcpyDeviceToDevice, st));
-    bool inexact = false;
-    rc = minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap, st,
-                          false, &inexact);
-    if (rc != LSF_OK || !inexact) return rc;
-    HIPCHK(hipMemcpyAsync(d_phi, bk, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_nb, bk + n * sizeof(double), n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_sb, bk + n * (sizeof(double) + sizeof(int32_t)), n * sizeof(int32_t),
-                          hipMemcpyDeviceToDevice, st));
+    for (int exact_mode : {MM_FP_ADAPTIVE, MM_FP_FULL}) {
+        bool inexact = false;
+        rc = minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap,
+                              st, exact_mode, &inexact);
+        if (rc != LSF_OK || !inexact) return rc;
+        HIPCHK(hipMemcpyAsync(d_phi, bk, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_nb, bk + n * sizeof(double), n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_sb, bk + n * (sizeof(double) + sizeof(int32_t)), n * sizeof(int32_t),
+                              hipMemcpyDeviceToDevice, st));
+    }
     return minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap,
-                            st, true, nullptr);
+                            st, MM_TILES, nullptr);
 }
 
 int box_ok(const lsf_box* b, const int lo[3], const int hi[3])
@@ -930,6 +1045,8 @@ int lsf_profile_get(double* sweep_kernel_ms, double* bc_ms, double* finish_ms, l
     if (sweeps) *sweeps = g_prof.sweeps;
     return LSF_OK;
 }
+
+const char* lsf_profile_kernel(void) { return g_prof.kernel; }
 
 int lsf_release_workspace(void)
 {

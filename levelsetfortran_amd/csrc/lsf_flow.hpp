@@ -1,13 +1,11 @@
-// lsf_flow.hpp -- exact Gauss-Seidel reinit as ONE persistent dataflow launch per batch of sweeps.
+// lsf_flow.hpp -- exact Gauss-Seidel reinit on box tiles: the slot-synchronous tile kernel (SLOT = true, the
+// product path for grids below ~310^3; larger grids use the skewed tiles of lsf_skew.hpp) and the experimental
+// persistent dataflow variant (SLOT = false, LSF_GS_SCHEDULE=flow), which share the loader, the march and the fused BC.
 //
-// The plane-by-plane schedule (k_reinit_gs_quad, one launch per tile hyperplane) costs
-//     T = n_planes x L_tile  +  tiles / X_saturated        (286 x 17 us + 4.6 ms at 512^3)
-// i.e. half of the time is the latency of 286 dependent launches during which the chip is mostly idle.
-// Here every tile is a task; a block takes tasks from a global ticket counter in an order that is a
-// topological order of the dependency graph, waits for its predecessors' completion flags, computes the
-// tile exactly like the quad kernel, publishes its results and its flag.  Consecutive sweeps (different
-// raster directions) overlap: a tile of sweep g+1 may start as soon as the tile and its six face
-// neighbours are done in sweep g, so the ramp-down of one sweep fills up with the ramp-up of the next.
+// The dataflow variant: every tile is a task; a block takes tasks from a global ticket counter in an order that is a
+// topological order of the dependency graph, waits for its predecessors' completion flags, computes the tile,
+// publishes its results and its flag.  Correct and tested, but 5-9 times slower than one launch per time slot
+// (DESIGN.md section 4.1): thousands of polling waves stretch the memory phases of the working tiles.
 //
 // Dependencies of tile T in (global) sweep g, reading buf[g&1] ("old") and writing buf[(g+1)&1]:
 //   a. T and its 6 face neighbours finished sweep g-1        (their old values; nobody still reads what T

@@ -382,8 +382,15 @@ __global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A,
         }
         __syncthreads();
     }
-    // the last allowed fix pass still changed something: the fixed point is not certified
-    if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0 && changed_prev && *changed_prev != 0) ctl[3] = 1;
+    if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0 && changed_prev) {
+        // `first` = number of fix passes that were enqueued, changed_prev = the counter of the last of them
+        const int* c0 = changed_prev - (first - 1);
+        int used = 0;
+        for (int f = 0; f < first; ++f) used += c0[f] != 0;
+        atomicMax(ctl + 4, used);
+        // the last allowed fix pass still changed something: the fixed point is not certified
+        if (*changed_prev != 0) ctl[3] = 1;
+    }
 }
 
 // deterministic two-stage reduction of many partials: block b sums its contiguous slice

@@ -24,14 +24,20 @@
 
 namespace lsf {
 
+// LDS rows (each RA = TA + 6 entries), grouped so that every 4-row load instruction is uniformly "old" or "new":
+//   [0, 20)  bundle rows, r = c * NY + b
+//   [20, 32) upstream y halo,   r = 20 + c * 3 + (b' + 3),       b' = -3..-1
+//   [32, 48) upstream z halo,   r = 32 + (c' + 3) * NY + b,      c' = -3..-1   (15 rows + 1 pad)
+//   [48, 60) downstream y halo, r = 48 + c * 3 + (b' - nj),      b' = nj..nj+2
+//   [60, 76) downstream z halo, r = 60 + (c' - nk) * NY + b,     c' = nk..nk+2 (15 rows + 1 pad)
 template <int TA, int NY>
 struct SkTile {
+    static_assert(NY == 5, "row groups below are laid out for 5 x 4 bundles");
     static constexpr int NZ = 4;
     static constexpr int RA = TA + 6;
-    static constexpr int NCORE = NZ * NY;  // bundle rows, r = c * NY + b
-    static constexpr int NYH = 6 * NZ;     // y-halo rows, q = c * 6 + hy  (b' = hy - 3 or nj + hy - 3)
-    static constexpr int NZH = 6 * NY;     // z-halo rows, q = hz * NY + b (c' = hz - 3 or nk + hz - 3)
-    static constexpr int YH0 = NCORE * RA, ZH0 = (NCORE + NYH) * RA, PS0 = (NCORE + NYH + NZH) * RA;
+    static constexpr int NCORE = NZ * NY;
+    static constexpr int YU0 = 20, ZU0 = 32, YD0 = 48, ZD0 = 60, NR = 76;
+    static constexpr int PS0 = NR * RA;       // phiS of the bundle cells, [NCORE][TA]
     static constexpr int TOTAL = PS0 + NCORE * TA;
 };
 
@@ -42,6 +48,7 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
     using T = SkTile<TA, NY>;
     constexpr int RA = T::RA;
     __shared__ double lds[T::TOTAL];
+    __shared__ int2 rowtab[T::NR];
     const int lane = threadIdx.x;
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1);
@@ -65,74 +72,91 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
     const int gb = g % a.nbuf;
     const double* in = a.buf[gb];
     double* out = a.buf[gb + 1 == a.nbuf ? 0 : gb + 1];
-    const long dOI = out - in;
 
-    // frame row (b', c') entry k -> global address; `fresh` = computed earlier in this sweep
-    auto cell_ptr = [&](int bq, int cq, int k, bool fresh) -> const double* {
-        const int fx = X0 - bq - cq + k - 3;
-        const int gi_r = si > 0 ? 1 + fx : nx - 1 - fx;
-        const int gj_r = j_lo + (sj > 0 ? bq : nj - 1 - bq);
-        const int gk_r = k_lo + (sk > 0 ? cq : nk - 1 - cq);
-        const bool interior = gi_r >= 1 && gi_r <= nx - 1 && gj_r >= 1 && gj_r <= ny - 1 && gk_r >= 1 && gk_r <= nz - 1;
-        const int gi = min(max(gi_r, 0), nx), gj = min(max(gj_r, 0), ny), gk = min(max(gk_r, 0), nz);
-        return in + (gi + sx * gj + sxy * gk) + ((fresh && interior) ? dOI : 0);
-    };
+    // ---- row table ------------------------------------------------------------------------------------------
+    // rowtab[r].x = (element offset of the row's i = 0 point from the tile origin) * 4 + flags
+    //                 flag 1: entries 3..18 hold values of this sweep (upstream halo row inside the interior)
+    //                 flag 2: entries 0..2 do (bundle row, or upstream halo row, inside the interior)
+    // rowtab[r].y = global i of the row's entry 3 (may lie outside [0, nx]: clamped on use)
+    // Offsets are tile-relative so that 32 bits suffice whatever the field size.
+    const int org_j = max(j_lo - 3, 0), org_k = max(k_lo - 3, 0);
+    const long org = sx * org_j + sxy * org_k;
+    const double* in_t = in + org;
+    double* out_t = out + org;
+    const double* ps_t = a.phiS + org;
+    const int gi0 = si > 0 ? 1 + X0 : nx - 1 - X0; // global i of frame position Fx = X0
+    for (int r = lane; r < T::NR; r += 64) {
+        int bq, cq, up = 0, core = 0;
+        // rows beyond a partial bundle (nj < NY or nk < 4) are never consumed: they alias a valid row
+        if (r < T::YU0) {
+            cq = r / NY, bq = r - NY * cq, core = 1;
+            bq = min(bq, nj - 1), cq = min(cq, nk - 1);
+        } else if (r < T::ZU0) {
+            const int q = r - T::YU0;
+            cq = q / 3, bq = q - 3 * cq - 3, up = 1;
+            cq = min(cq, nk - 1);
+        } else if (r < T::YD0) {
+            const int q = min(r - T::ZU0, 14), hz = q / NY;
+            bq = min(q - NY * hz, nj - 1), cq = hz - 3, up = 1;
+        } else if (r < T::ZD0) {
+            const int q = r - T::YD0;
+            cq = q / 3, bq = nj + q - 3 * cq;
+            cq = min(cq, nk - 1);
+        } else {
+            const int q = min(r - T::ZD0, 14), hz = q / NY;
+            bq = min(q - NY * hz, nj - 1), cq = nk + hz;
+        }
+        const int gj_r = j_lo + (sj > 0 ? bq : nj - 1 - bq), gk_r = k_lo + (sk > 0 ? cq : nk - 1 - cq);
+        const int rin = (int)((unsigned)(gj_r - 1) <= (unsigned)(ny - 2)) & (int)((unsigned)(gk_r - 1) <= (unsigned)(nz - 2));
+        const int gj = min(max(gj_r, 0), ny), gk = min(max(gk_r, 0), nz);
+        const int o = (gj - org_j) * (int)sx + (gk - org_k) * (int)sxy; // a 10-plane slab of any admissible field fits 29 bits
+        rowtab[r] = make_int2(o * 4 + (rin & up) + 2 * (rin & (up | core)), si > 0 ? gi0 - (bq + cq) : gi0 + (bq + cq));
+    }
+    __syncthreads();
 
     // ---- load: all global loads in flight before the first LDS write ------------------------------------
     {
-        constexpr int U0 = T::NCORE / 4, U1 = T::NYH / 4, U2 = (T::NZH + 3) / 4; // 16 main entries of 4 rows per instruction
-        constexpr int H0 = (6 * T::NCORE + 63) / 64, H1 = (6 * T::NYH + 63) / 64, H2 = (6 * T::NZH + 63) / 64;
-        constexpr int NV = U0 + U1 + U2 + U0 + H0 + H1 + H2;
-        static_assert(T::NCORE % 4 == 0 && T::NYH % 4 == 0, "row groups");
+        constexpr int UM = T::NR / 4;                 // entries 3..18 of 4 rows per instruction
+        constexpr int UH = (6 * T::NR + 63) / 64;     // entries 0..2 and 19..21 of every row
+        constexpr int UP = T::NCORE / 4;              // phiS of the bundle rows
+        constexpr int NV = UM + UH + UP;
         double v[NV];
         int dst[NV];
         const int xx = lane & 15, rsub = lane >> 4;
+        const int sxx = si > 0 ? xx : -xx;
         int n_ = 0;
 #pragma unroll
-        for (int u = 0; u < U0; ++u, ++n_) { // bundle rows, entries 3..18: old
-            const int r = 4 * u + rsub, c = r / NY, b = r - NY * c;
+        for (int u = 0; u < UM; ++u, ++n_) {
+            const int r = 4 * u + rsub;
+            const int2 e = rowtab[r];
+            const int gi_r = e.y + sxx;
+            const unsigned o = (unsigned)(e.x >> 2) + (unsigned)min(max(gi_r, 0), nx);
             dst[n_] = r * RA + 3 + xx;
-            v[n_] = *cell_ptr(b, c, 3 + xx, false);
+            if (4 * u >= T::YU0 && 4 * u < T::YD0) { // upstream halo rows: this sweep's values, except wall points
+                const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 1);
+                v[n_] = (fresh ? (const double*)out_t : in_t)[o];
+            } else {
+                v[n_] = in_t[o];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < U1; ++u, ++n_) { // y halo
-            const int q = 4 * u + rsub, c = q / 6, hy = q - 6 * c;
-            dst[n_] = T::YH0 + q * RA + 3 + xx;
-            v[n_] = *cell_ptr(hy < 3 ? hy - 3 : nj + hy - 3, c, 3 + xx, hy < 3);
+        for (int u = 0; u < UH; ++u, ++n_) {
+            const int idx = min(lane + 64 * u, 6 * T::NR - 1), r = idx / 6, ee = idx - 6 * r;
+            const int kk = ee < 3 ? ee - 3 : TA + ee - 3; // entry k = kk + 3
+            const int2 e = rowtab[r];
+            const int gi_r = e.y + (si > 0 ? kk : -kk);
+            const unsigned o = (unsigned)(e.x >> 2) + (unsigned)min(max(gi_r, 0), nx);
+            const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 2) & (ee < 3);
+            dst[n_] = r * RA + 3 + kk;
+            v[n_] = (fresh ? (const double*)out_t : in_t)[o];
         }
 #pragma unroll
-        for (int u = 0; u < U2; ++u, ++n_) { // z halo
-            const int q = min(4 * u + rsub, T::NZH - 1), hz = q / NY, b = q - NY * hz;
-            dst[n_] = T::ZH0 + q * RA + 3 + xx;
-            v[n_] = *cell_ptr(b, hz < 3 ? hz - 3 : nk + hz - 3, 3 + xx, hz < 3);
-        }
-#pragma unroll
-        for (int u = 0; u < U0; ++u, ++n_) { // phiS of the bundle cells
-            const int r = 4 * u + rsub, c = r / NY, b = r - NY * c;
+        for (int u = 0; u < UP; ++u, ++n_) {
+            const int r = 4 * u + rsub;
+            const int2 e = rowtab[r];
+            const unsigned o = (unsigned)(e.x >> 2) + (unsigned)min(max(e.y + sxx, 0), nx);
             dst[n_] = T::PS0 + r * TA + xx;
-            v[n_] = *(a.phiS + (cell_ptr(b, c, 3 + xx, false) - in));
-        }
-        // the 6 window-halo entries of every row: k = 0..2 (earlier tile of the row: fresh for bundle rows) and 19..21
-#pragma unroll
-        for (int u = 0; u < H0; ++u, ++n_) {
-            const int idx = min(lane + 64 * u, 6 * T::NCORE - 1), r = idx / 6, ee = idx - 6 * r;
-            const int c = r / NY, b = r - NY * c, k = ee < 3 ? ee : TA + ee;
-            dst[n_] = r * RA + k;
-            v[n_] = *cell_ptr(b, c, k, ee < 3);
-        }
-#pragma unroll
-        for (int u = 0; u < H1; ++u, ++n_) {
-            const int idx = min(lane + 64 * u, 6 * T::NYH - 1), q = idx / 6, ee = idx - 6 * q;
-            const int c = q / 6, hy = q - 6 * c, k = ee < 3 ? ee : TA + ee;
-            dst[n_] = T::YH0 + q * RA + k;
-            v[n_] = *cell_ptr(hy < 3 ? hy - 3 : nj + hy - 3, c, k, hy < 3);
-        }
-#pragma unroll
-        for (int u = 0; u < H2; ++u, ++n_) {
-            const int idx = min(lane + 64 * u, 6 * T::NZH - 1), q = idx / 6, ee = idx - 6 * q;
-            const int hz = q / NY, b = q - NY * hz, k = ee < 3 ? ee : TA + ee;
-            dst[n_] = T::ZH0 + q * RA + k;
-            v[n_] = *cell_ptr(b, hz < 3 ? hz - 3 : nk + hz - 3, k, hz < 3);
+            v[n_] = ps_t[o];
         }
 #pragma unroll
         for (int u = 0; u < NV; ++u) lds[dst[u]] = v[u]; // duplicates (clamped indices) rewrite the same value
@@ -157,10 +181,10 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
         int base = row_core - 3;
         if (axis == 1) {
             const int bq = bc + dF;
-            base = (bq >= 0 && bq < nj) ? (cc * NY + bq) * RA : T::YH0 + (cc * 6 + (bq < 0 ? bq + 3 : bq - nj + 3)) * RA;
+            base = ((bq >= 0 && bq < nj) ? cc * NY + bq : (bq < 0 ? T::YU0 + cc * 3 + bq + 3 : T::YD0 + cc * 3 + bq - nj)) * RA;
         } else if (axis == 2) {
             const int cq = cc + dF;
-            base = (cq >= 0 && cq < nk) ? (cq * NY + bc) * RA : T::ZH0 + ((cq < 0 ? cq + 3 : cq - nk + 3) * NY + bc) * RA;
+            base = ((cq >= 0 && cq < nk) ? cq * NY + bc : (cq < 0 ? T::ZU0 + (cq + 3) * NY + bc : T::ZD0 + (cq - nk) * NY + bc)) * RA;
         }
         off[mm] = base + 3 + dF;
     }
@@ -169,6 +193,7 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
     double acc = 0.0;
 
     // ---- march: TA steps, every lane busy ------------------------------------------------------------------
+#pragma unroll
     for (int t = 0; t < TA; ++t) {
         const int fx = fx0 + t;
         const bool active = row_ok && fx >= 0 && fx < nxi;
@@ -198,13 +223,13 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
 #pragma unroll
     for (int u = 0; u < T::NCORE / 4; ++u) {
         const int r = 4 * u + (lane >> 4), cq = r / NY, bq = r - NY * cq, t = lane & 15;
-        const int fx = X0 - bq - cq + t;
-        const bool mine = bq < nj && cq < nk && fx >= 0 && fx < nxi;
-        const int gi = si > 0 ? 1 + fx : nx - 1 - fx;
-        const int gj2 = j_lo + (sj > 0 ? bq : nj - 1 - bq), gk2 = k_lo + (sk > 0 ? cq : nk - 1 - cq);
+        const int2 e = rowtab[r];
+        const int gi = e.y + (si > 0 ? t : -t);
+        const bool mine = bq < nj && cq < nk && (unsigned)(gi - 1) <= (unsigned)(nx - 2);
         const double val0 = lds[r * RA + 3 + t];
-        if (mine) out[gi + sx * gj2 + sxy * gk2] = val0;
+        if (mine) out_t[(unsigned)(e.x >> 2) + (unsigned)gi] = val0;
         if (near_wall && mine) {
+            const int gj2 = j_lo + (sj > 0 ? bq : nj - 1 - bq), gk2 = k_lo + (sk > 0 ? cq : nk - 1 - cq);
             // wall points that clamp to this cell: move outward along any non-empty subset of its wall-adjacent axes
             const int ai = gi == 1 ? -1 : (gi == nx - 1 ? 1 : 0), aj = gj2 == 1 ? -1 : (gj2 == ny - 1 ? 1 : 0),
                       ak = gk2 == 1 ? -1 : (gk2 == nz - 1 ? 1 : 0);

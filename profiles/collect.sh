@@ -29,3 +29,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_cal" -- python3 "$OUT/cal.py" > /dev/null 2> "$OUT/pmc_${C}_cal.log"
 done
 python3 profiles/summarize.py "$OUT" "$TAG"
+bash profiles/sq_pass.sh "$TAG"
+# gpurun only carries gpurun_out/ back: stage the committed summaries there (copy them into profiles/ afterwards)
+mkdir -p "gpurun_out/profiles_$TAG"
+cp profiles/${TAG}_* profiles/traffic.json "gpurun_out/profiles_$TAG/"

@@ -16,13 +16,15 @@ python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
 res = {}
-for mode, kern in (("gs", "k_reinit_gs_flow"), ("jacobi", "k_reinit_jacobi")):
+for mode, kern in (("gs", "k_reinit_gs_"), ("jacobi", "k_reinit_jacobi")):
     tot = {}
     for p in ("p1", "p2"):
         for f in glob.glob(os.path.join(out, f"{p}_{mode}", "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 if kern in r["Kernel_Name"]:
                     tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    if tot.get("SQ_WAVES"):
+        tot["per_wave"] = {k: round(v / tot["SQ_WAVES"], 1) for k, v in tot.items() if k != "SQ_WAVES"}
     res[kern] = tot
 json.dump(res, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
 json.dump(res, open(os.path.join(out, "sq_counters.json"), "w"), indent=1)

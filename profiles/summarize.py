@@ -33,7 +33,17 @@ if stats:
 res = {"unit": "bytes per sweep", "N": 512, "note": "sum over the sweep-kernel dispatches of one sweep; counters are in KiB "
        "(rocprofv3 FETCH_SIZE/WRITE_SIZE); fetch_corrected = 2 x fetch_raw (gfx950 wide-read correction, upper bound)"}
 traffic = {}
-for mode, kern in (("gs", "k_reinit_gs_flow"), ("jacobi", "k_reinit_jacobi")):
+def gs_kernel_name():
+    # the exact ordering launches k_reinit_gs_skew (skewed tiles, large grids) or k_reinit_gs_flow (box tiles)
+    f = one("pmc_FETCH_SIZE_gs/**/*counter_collection.csv")
+    if f:
+        for r in csv.DictReader(open(f)):
+            if "k_reinit_gs_" in r["Kernel_Name"]:
+                return "k_reinit_gs_skew" if "gs_skew" in r["Kernel_Name"] else "k_reinit_gs_flow"
+    return "k_reinit_gs_flow"
+
+
+for mode, kern in (("gs", gs_kernel_name()), ("jacobi", "k_reinit_jacobi")):
     entry = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         f = one(f"pmc_{ctr}_{mode}/**/*counter_collection.csv")

@@ -305,7 +305,7 @@ def test_reinit_alternative_tile_geometries(lsf, oracle, synth, monkeypatch, geo
     assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("schedule", ["planes", "flow"])
+@pytest.mark.parametrize("schedule", ["planes", "flow", "skew"])
 def test_reinit_alternative_schedules(lsf, synth, cube40, monkeypatch, schedule):
     """The exact-GS tile graph has three executors (LSF_GS_SCHEDULE): overlapped slot launches (default, used by
     every other test), one launch per hyperplane, and the experimental persistent dataflow kernel.  All must be
