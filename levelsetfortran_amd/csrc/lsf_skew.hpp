@@ -24,21 +24,28 @@
 
 namespace lsf {
 
-// LDS rows (each RA = TA + 6 entries), grouped so that every 4-row load instruction is uniformly "old" or "new":
-//   [0, 20)  bundle rows, r = c * NY + b
-//   [20, 32) upstream y halo,   r = 20 + c * 3 + (b' + 3),       b' = -3..-1
-//   [32, 48) upstream z halo,   r = 32 + (c' + 3) * NY + b,      c' = -3..-1   (15 rows + 1 pad)
-//   [48, 60) downstream y halo, r = 48 + c * 3 + (b' - nj),      b' = nj..nj+2
-//   [60, 76) downstream z halo, r = 60 + (c' - nk) * NY + b,     c' = nk..nk+2 (15 rows + 1 pad)
+// LDS rows, grouped so that every 4-row load instruction is uniformly "old" or "new":
+//   [0, 20)  bundle rows, r = c * NY + b                                        entries 0..21 (RA = TA + 6)
+//   [20, 32) upstream y halo,   r = 20 + c * 3 + (b' + 3),       b' = -3..-1    entries 0..17 (the only ones a
+//   [32, 48) upstream z halo,   r = 32 + (c' + 3) * NY + b,      c' = -3..-1    stencil d = 1..3 rows away reaches)
+//   [48, 60) downstream y halo, r = 48 + c * 3 + (b' - nj),      b' = nj..nj+2  entries 4..21
+//   [60, 76) downstream z halo, r = 60 + (c' - nk) * NY + b,     c' = nk..nk+2  entries 4..21
+// (the z groups hold 15 rows + 1 pad).  phiS of the bundle cells is not staged: the lanes of a cell read their 16
+// values straight into registers.
 template <int TA, int NY>
 struct SkTile {
     static_assert(NY == 5, "row groups below are laid out for 5 x 4 bundles");
     static constexpr int NZ = 4;
     static constexpr int RA = TA + 6;
+    static constexpr int RH = TA + 2;         // entries kept of a halo row
     static constexpr int NCORE = NZ * NY;
     static constexpr int YU0 = 20, ZU0 = 32, YD0 = 48, ZD0 = 60, NR = 76;
-    static constexpr int PS0 = NR * RA;       // phiS of the bundle cells, [NCORE][TA]
-    static constexpr int TOTAL = PS0 + NCORE * TA;
+    static constexpr int TOTAL = NCORE * RA + (NR - NCORE) * RH;
+    // LDS index of entry k of row r (halo rows store entry 0 resp. 4 first)
+    __host__ __device__ static constexpr int at(int r, int k)
+    {
+        return r < NCORE ? r * RA + k : NCORE * RA + (r - NCORE) * RH + (r < YD0 ? k : k - 4);
+    }
 };
 
 template <int TA, int NY, bool STRICT>
@@ -115,24 +122,31 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
     __syncthreads();
 
     // ---- load: all global loads in flight before the first LDS write ------------------------------------
+    static_assert(NY == 5, "lane map: 5 cells x 3 axes per 16 lanes");
+    const int t16 = lane & 15;
+    const int b = t16 / 3, axis = t16 - 3 * b, c = lane >> 4; // t16 = 15: b = 5 >= nj, idle
+    const bool row_ok = b < nj && c < nk;
+    const int bc = row_ok ? b : 0, cc = row_ok ? c : 0;
+    double ps[TA]; // phiS of the 16 cells this lane's cell row holds (the x lane of a cell uses them)
     {
-        constexpr int UM = T::NR / 4;                 // entries 3..18 of 4 rows per instruction
-        constexpr int UH = (6 * T::NR + 63) / 64;     // entries 0..2 and 19..21 of every row
-        constexpr int UP = T::NCORE / 4;              // phiS of the bundle rows
-        constexpr int NV = UM + UH + UP;
+        constexpr int UM = T::NR / 4;                                   // 16 entries of 4 rows per instruction
+        constexpr int XC = 6 * T::NCORE, XH = 2 * (T::NR - T::NCORE);   // the remaining 6 (bundle) / 2 (halo) entries
+        constexpr int UX = (XC + XH + 63) / 64;
+        constexpr int NV = UM + UX;
         double v[NV];
         int dst[NV];
         const int xx = lane & 15, rsub = lane >> 4;
-        const int sxx = si > 0 ? xx : -xx;
         int n_ = 0;
 #pragma unroll
         for (int u = 0; u < UM; ++u, ++n_) {
             const int r = 4 * u + rsub;
             const int2 e = rowtab[r];
-            const int gi_r = e.y + sxx;
+            // bundle rows: entries 3..18 (old); upstream halo: 2..17 (this sweep's, except wall points); downstream: 4..19
+            const int k = (4 * u < T::YU0 ? 3 : (4 * u < T::YD0 ? 2 : 4)) + xx;
+            const int gi_r = e.y + (si > 0 ? k - 3 : 3 - k);
             const unsigned o = (unsigned)(e.x >> 2) + (unsigned)min(max(gi_r, 0), nx);
-            dst[n_] = r * RA + 3 + xx;
-            if (4 * u >= T::YU0 && 4 * u < T::YD0) { // upstream halo rows: this sweep's values, except wall points
+            dst[n_] = T::at(r, k);
+            if (4 * u >= T::YU0 && 4 * u < T::YD0) {
                 const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 1);
                 v[n_] = (fresh ? (const double*)out_t : in_t)[o];
             } else {
@@ -140,23 +154,30 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
             }
         }
 #pragma unroll
-        for (int u = 0; u < UH; ++u, ++n_) {
-            const int idx = min(lane + 64 * u, 6 * T::NR - 1), r = idx / 6, ee = idx - 6 * r;
-            const int kk = ee < 3 ? ee - 3 : TA + ee - 3; // entry k = kk + 3
+        for (int u = 0; u < UX; ++u, ++n_) {
+            const int idx = min(lane + 64 * u, XC + XH - 1);
+            int r, k;
+            if (idx < XC) { // bundle rows: entries 0..2 (previous tile of the row: this sweep's) and 19..21
+                r = idx / 6;
+                const int ee = idx - 6 * r;
+                k = ee < 3 ? ee : TA + ee;
+            } else { // halo rows: entries 0, 1 (upstream) or 20, 21 (downstream)
+                const int h = idx - XC;
+                r = T::NCORE + (h >> 1);
+                k = (r < T::YD0 ? 0 : TA + 4) + (h & 1);
+            }
             const int2 e = rowtab[r];
-            const int gi_r = e.y + (si > 0 ? kk : -kk);
+            const int gi_r = e.y + (si > 0 ? k - 3 : 3 - k);
             const unsigned o = (unsigned)(e.x >> 2) + (unsigned)min(max(gi_r, 0), nx);
-            const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 2) & (ee < 3);
-            dst[n_] = r * RA + 3 + kk;
+            const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 2) & (k < 3);
+            dst[n_] = T::at(r, k);
             v[n_] = (fresh ? (const double*)out_t : in_t)[o];
         }
+        {
+            const int2 e = rowtab[cc * NY + bc];
 #pragma unroll
-        for (int u = 0; u < UP; ++u, ++n_) {
-            const int r = 4 * u + rsub;
-            const int2 e = rowtab[r];
-            const unsigned o = (unsigned)(e.x >> 2) + (unsigned)min(max(e.y + sxx, 0), nx);
-            dst[n_] = T::PS0 + r * TA + xx;
-            v[n_] = ps_t[o];
+            for (int t = 0; t < TA; ++t)
+                ps[t] = ps_t[(unsigned)(e.x >> 2) + (unsigned)min(max(e.y + (si > 0 ? t : -t), 0), nx)];
         }
 #pragma unroll
         for (int u = 0; u < NV; ++u) lds[dst[u]] = v[u]; // duplicates (clamped indices) rewrite the same value
@@ -164,15 +185,11 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
     __syncthreads();
 
     // ---- per-lane constants: 3 lanes per cell inside each 16-lane row (5 cells + 1 idle lane) -------------
-    static_assert(NY == 5, "lane map: 5 cells x 3 axes per 16 lanes");
-    const int t16 = lane & 15;
-    const int b = t16 / 3, axis = t16 - 3 * b, c = lane >> 4; // t16 = 15: b = 5 >= nj, idle
-    const bool row_ok = b < nj && c < nk;
-    const int bc = row_ok ? b : 0, cc = row_ok ? c : 0;
     const int gj = j_lo + (sj > 0 ? bc : nj - 1 - bc), gk = k_lo + (sk > 0 ? cc : nk - 1 - cc);
     const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
     const bool yquirk = axis == 1;
     const int row_core = (cc * NY + bc) * RA + 3;
+    auto row_at = [](int r) { return r < T::NCORE ? r * RA : T::NCORE * RA + (r - T::NCORE) * T::RH - (r < T::YD0 ? 0 : 4); };
     int off[7];
 #pragma unroll
     for (int mm = 0; mm < 7; ++mm) {
@@ -181,14 +198,13 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
         int base = row_core - 3;
         if (axis == 1) {
             const int bq = bc + dF;
-            base = ((bq >= 0 && bq < nj) ? cc * NY + bq : (bq < 0 ? T::YU0 + cc * 3 + bq + 3 : T::YD0 + cc * 3 + bq - nj)) * RA;
+            base = row_at((bq >= 0 && bq < nj) ? cc * NY + bq : (bq < 0 ? T::YU0 + cc * 3 + bq + 3 : T::YD0 + cc * 3 + bq - nj));
         } else if (axis == 2) {
             const int cq = cc + dF;
-            base = ((cq >= 0 && cq < nk) ? cq * NY + bc : (cq < 0 ? T::ZU0 + (cq + 3) * NY + bc : T::ZD0 + (cq - nk) * NY + bc)) * RA;
+            base = row_at((cq >= 0 && cq < nk) ? cq * NY + bc : (cq < 0 ? T::ZU0 + (cq + 3) * NY + bc : T::ZD0 + (cq - nk) * NY + bc));
         }
         off[mm] = base + 3 + dF;
     }
-    const int ps_row = T::PS0 + (cc * NY + bc) * TA;
     const int fx0 = X0 - bc - cc;
     double acc = 0.0;
 
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
         double q[7];
 #pragma unroll
         for (int mm = 0; mm < 7; ++mm) q[mm] = lds[off[mm] + t];
-        const double pS = lds[ps_row + t];
+        const double pS = ps[t];
         const int gi = si > 0 ? 1 + fx : nx - 1 - fx;
         const bool weno_ok = yz_weno && gi > 3 && gi < nx - 4;
         double dm, dp;
