@@ -58,6 +58,18 @@ int gs_ta()
     const char* e = getenv("LSF_GS_TA");
     return (e && atoi(e) == 32) ? 32 : 16;
 }
+// wavefronts per skewed tile (lsf_skew.hpp): WY x WZ adjacent 5 x 4 bundles marched in lock step, "WYxWZ" or "WY"
+void gs_skew_w(int* wy, int* wz)
+{
+    const char* e = getenv("LSF_GS_SKEW_W");
+    int y = 2, z = 2; // measured best at 256^3, 512^3 and 1024^3
+    if (e && sscanf(e, "%dx%d", &y, &z) < 1) y = z = 2;
+    if (e && !std::strchr(e, 'x')) z = 1;
+    static const int ok[][2] = {{1, 1}, {2, 1}, {4, 1}, {1, 2}, {2, 2}, {4, 2}, {2, 4}};
+    *wy = *wz = 2;
+    for (auto& s : ok)
+        if (s[0] == y && s[1] == z) *wy = y, *wz = z;
+}
 int gs_ny()
 {
     const char* e = getenv("LSF_GS_NY");
@@ -209,18 +221,18 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Skewed tiles (lsf_skew.hpp): (m, fB, fC) with TA m <= Fx + Fy + Fz < TA m + TA for some cell of row bundle
 // (fB, fC); the m range assumes full bundles (NY x 4 rows), a superset for the partial bundles at the far walls
 // (such a tile simply finds no cell to work on).  Sorted by hyperplane m + fB + fC.
-int get_skew_tiles(int nxi, int nTj, int nTk, int ta, int nyc, TileList** out)
+int get_skew_tiles(int nxi, int nTj, int nTk, int ta, int nyc, int nzc, TileList** out)
 {
-    const int m_max = (nxi - 1 + nyc * nTj - 1 + 4 * nTk - 1) / ta;
+    const int m_max = (nxi - 1 + nyc * nTj - 1 + nzc * nTk - 1) / ta;
     if (m_max > 1023 || nTj > 1023 || nTk > 1023) return fail(LSF_ERR_INVALID, "grid too large for tile index packing");
-    const uint64_t key = ((uint64_t)nxi << 40) | ((uint64_t)nTj << 20) | (uint64_t)nTk;
+    const uint64_t key = ((uint64_t)nxi << 44) | ((uint64_t)nTj << 28) | ((uint64_t)nTk << 12) | (uint64_t)(nyc << 6 | nzc);
     Ctx& c = ctx();
     auto it = c.skew_tiles.find(key);
     if (it == c.skew_tiles.end()) {
         const int nplanes = m_max + nTj + nTk - 1;
         std::vector<int> cnt(nplanes + 1, 0);
-        auto m_lo = [&](int B, int C) { return (nyc * B + 4 * C) / ta; };
-        auto m_hi = [&](int B, int C) { return (nyc * B + nyc - 1 + 4 * C + 3 + nxi - 1) / ta; };
+        auto m_lo = [&](int B, int C) { return (nyc * B + nzc * C) / ta; };
+        auto m_hi = [&](int B, int C) { return (nyc * B + nyc - 1 + nzc * C + nzc - 1 + nxi - 1) / ta; };
         for (int C = 0; C < nTk; ++C)
             for (int B = 0; B < nTj; ++B)
                 for (int m = m_lo(B, C); m <= m_hi(B, C); ++m) ++cnt[m + B + C];
@@ -250,9 +262,9 @@ int get_skew_tiles(int nxi, int nTj, int nTk, int ta, int nyc, TileList** out)
 // itself or up to 3 cells along one axis) has run:  H > P_g(v) - P_{g+1}(u)  for all such pairs.  With
 // P = floor((Fx + Fy + Fz) / TA) + fB + fC and floor(p) - floor(q) <= floor(p - q) + 1 the maximum separates into
 // one 1-D scan per axis (exact up to one slot).
-long skew_spacing(const int* da, const int* db, int nx, int ny, int nz, int ta, int nyc)
+long skew_spacing(const int* da, const int* db, int nx, int ny, int nz, int ta, int nyc, int nzc)
 {
-    const int nq[3] = {nx, ny, nz}, ts[3] = {0, nyc, 4};
+    const int nq[3] = {nx, ny, nz}, ts[3] = {0, nyc, nzc};
     long m0[3], md[3];
     for (int ax = 0; ax < 3; ++ax) {
         const int n = nq[ax], TS = ts[ax], nT = TS ? cdiv(n - 1, TS) : 0;
@@ -483,7 +495,7 @@ int gs_schedule()
     if (e && std::strcmp(e, "flow") == 0) return 2;
     if (e && std::strcmp(e, "skew") == 0) return 3;
     if (e && std::strcmp(e, "slots") == 0) return 1;
-    return -1; // unset: slots on box tiles for small grids, on skewed tiles for large ones
+    return -1; // unset: slots on skewed tiles
 }
 
 int reinit_flow_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
@@ -643,19 +655,24 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st));
         d_phiS = (const double*)c.slot[S_PHIS].p;
     }
-    const int ta = gs_ta(), nyc = gs_ny();
+    const int ta = gs_ta();
+    int nyc = gs_ny();
     int sched = gs_schedule();
-    // Box tiles keep 70 % of their lanes busy but need fewer time slots per sweep; skewed tiles (lsf_skew.hpp) do
-    // 19 % less work per sweep in 25 % more slots.  Measured break-even near 256^3 (1.75 vs 1.77 ms), skewed tiles
-    // win above it (512^3: 7.12 -> 6.56 ms, 1024^3: 38.0 -> 32.8 ms per sweep).
-    if (sched < 0) sched = (double)(nx - 1) * (ny - 1) * (nz - 1) >= 3.0e7 ? 3 : 1;
+    // Default: skewed tiles (lsf_skew.hpp), 2 x 2 wavefronts each.  Measured against the box tiles of lsf_flow.hpp
+    // (`slots`): 32^3 0.16 vs 0.20 ms, 256^3 1.33 vs 1.75, 512^3 4.81 vs 6.83, 1024^3 25.5 vs 38.0 ms per sweep.
+    if (sched < 0) sched = 3;
     // skewed tiles need TA = 16, NY = 5 and at least two interior cells per axis
     const bool skew = sched == 3 && ta == 16 && nyc == 5 && nx >= 3 && ny >= 3 && nz >= 3;
+    int wy = 1, wz = 1, nzc = 4;
+    if (skew) {
+        gs_skew_w(&wy, &wz);
+        nyc = 5 * wy, nzc = 4 * wz; // rows of a tile in y and z
+    }
     const bool overlap = sched != 0; // "planes": one sweep at a time (start[g+1] = start[g] + nPlanes)
-    const int nTi = cdiv(nx - 1, ta), nTj = cdiv(ny - 1, nyc), nTk = cdiv(nz - 1, 4);
+    const int nTi = cdiv(nx - 1, ta), nTj = cdiv(ny - 1, nyc), nTk = cdiv(nz - 1, nzc);
     const int nT[3] = {nTi, nTj, nTk};
     TileList* tl = nullptr;
-    if (skew) rc = get_skew_tiles(nx - 1, nTj, nTk, ta, nyc, &tl);
+    if (skew) rc = get_skew_tiles(nx - 1, nTj, nTk, ta, nyc, nzc, &tl);
     else rc = get_tiles(nTi, nTj, nTk, &tl);
     if (rc) return rc;
     const int np = (int)tl->off.size() - 1;
@@ -695,7 +712,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             long H = 2;
             for (int ax = 0; ax < 3; ++ax)
                 if (da[ax] != db[ax]) H += nT[ax] - 1;
-            if (skew) H = skew_spacing(da, db, nx, ny, nz, ta, nyc);
+            if (skew) H = skew_spacing(da, db, nx, ny, nz, ta, nyc, nzc);
             long s0 = start[q - 1] + H;
             if (q >= 3) s0 = std::max(s0, start[q - 3] + np + 1);
             if (!overlap) s0 = start[q - 1] + np;
@@ -709,8 +726,22 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     long launches = 0;
     auto launch_tiles = [&](int grid, hipStream_t s_) {
         if (skew) {
-            if (strict) hipLaunchKernelGGL((k_reinit_gs_skew<16, 5, true>), dim3(grid), dim3(64), 0, s_, fa);
-            else hipLaunchKernelGGL((k_reinit_gs_skew<16, 5, false>), dim3(grid), dim3(64), 0, s_, fa);
+#define LSF_LAUNCH_SKEW(WY_, WZ_)                                                                                          \
+    do {                                                                                                                   \
+        if (strict)                                                                                                        \
+            hipLaunchKernelGGL((k_reinit_gs_skew<16, WY_, WZ_, true>), dim3(grid), dim3(64 * WY_ * WZ_), 0, s_, fa);       \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_reinit_gs_skew<16, WY_, WZ_, false>), dim3(grid), dim3(64 * WY_ * WZ_), 0, s_, fa);      \
+    } while (0)
+            const int shape = wy * 16 + wz;
+            if (shape == 0x11) LSF_LAUNCH_SKEW(1, 1);
+            else if (shape == 0x21) LSF_LAUNCH_SKEW(2, 1);
+            else if (shape == 0x41) LSF_LAUNCH_SKEW(4, 1);
+            else if (shape == 0x12) LSF_LAUNCH_SKEW(1, 2);
+            else if (shape == 0x42) LSF_LAUNCH_SKEW(4, 2);
+            else if (shape == 0x24) LSF_LAUNCH_SKEW(2, 4);
+            else LSF_LAUNCH_SKEW(2, 2);
+#undef LSF_LAUNCH_SKEW
             return;
         }
 #define LSF_LAUNCH_SLOT(TA_, NY_, ST_) \
@@ -1061,9 +1092,11 @@ int lsf_release_workspace(void)
     for (auto& kv : c.part_by_stream)
         if (kv.second.p) HIPCHK(hipFree(kv.second.p));
     c.part_by_stream.clear();
-    for (auto& kv : c.tiles)
-        if (kv.second.d) HIPCHK(hipFree(kv.second.d));
-    c.tiles.clear();
+    for (auto* lists : {&c.tiles, &c.skew_tiles}) {
+        for (auto& kv : *lists)
+            if (kv.second.d) HIPCHK(hipFree(kv.second.d));
+        lists->clear();
+    }
     return LSF_OK;
 }
 

@@ -24,22 +24,32 @@
 
 namespace lsf {
 
-// LDS rows, grouped so that every 4-row load instruction is uniformly "old" or "new":
-//   [0, 20)  bundle rows, r = c * NY + b                                        entries 0..21 (RA = TA + 6)
-//   [20, 32) upstream y halo,   r = 20 + c * 3 + (b' + 3),       b' = -3..-1    entries 0..17 (the only ones a
-//   [32, 48) upstream z halo,   r = 32 + (c' + 3) * NY + b,      c' = -3..-1    stencil d = 1..3 rows away reaches)
-//   [48, 60) downstream y halo, r = 48 + c * 3 + (b' - nj),      b' = nj..nj+2  entries 4..21
-//   [60, 76) downstream z halo, r = 60 + (c' - nk) * NY + b,     c' = nk..nk+2  entries 4..21
-// (the z groups hold 15 rows + 1 pad).  phiS of the bundle cells is not staged: the lanes of a cell read their 16
-// values straight into registers.
-template <int TA, int NY>
+// A tile is WY x WZ adjacent 5 x 4 bundles (one wavefront each), marched in lock step: NYT = 5 WY by NZT = 4 WZ
+// rows share one LDS image, the halo between the bundles of a tile is internal, and the sweep needs fewer, fatter time
+// slots (a flip of the raster direction along y costs n/16 + (number of tiles in y) slots, the cycle flips y six
+// times out of eight and z twice).
+//
+// LDS rows, grouped so that every 4-row load instruction is uniformly "old" or "new" (1 x 1: 76 rows):
+//   [0, NCORE)    bundle rows, r = c * NYT + b                                   entries 0..21 (RA = TA + 6)
+//   [YU0, ZU0)    upstream y halo,   r = YU0 + c * 3 + (b' + 3),    b' = -3..-1   entries 0..17 (the only ones a
+//   [ZU0, YD0)    upstream z halo,   r = ZU0 + (c' + 3) * NYT + b,  c' = -3..-1   stencil d = 1..3 rows away reaches)
+//   [YD0, ZD0)    downstream y halo, r = YD0 + c * 3 + (b' - nj),   b' = nj..nj+2 entries 4..21
+//   [ZD0, NR)     downstream z halo, r = ZD0 + (c' - nk) * NYT + b, c' = nk..nk+2 entries 4..21
+// (z groups padded to whole load instructions).  phiS of the bundle cells is not staged: the lanes of a cell read
+// their 16 values straight into registers.
+template <int TA, int WY, int WZ>
 struct SkTile {
-    static_assert(NY == 5, "row groups below are laid out for 5 x 4 bundles");
-    static constexpr int NZ = 4;
+    static constexpr int W = WY * WZ;         // wavefronts per tile
+    static_assert(W >= 1 && W <= 16, "1 to 16 wavefronts per tile");
+    static constexpr int NYT = 5 * WY, NZT = 4 * WZ; // rows of a tile in y and z
     static constexpr int RA = TA + 6;
     static constexpr int RH = TA + 2;         // entries kept of a halo row
-    static constexpr int NCORE = NZ * NY;
-    static constexpr int YU0 = 20, ZU0 = 32, YD0 = 48, ZD0 = 60, NR = 76;
+    static constexpr int NCORE = NZT * NYT;
+    static constexpr int YH = 3 * NZT;
+    static constexpr int ZP = (3 * NYT + 3) / 4 * 4;
+    static constexpr int YU0 = NCORE, ZU0 = YU0 + YH, YD0 = ZU0 + ZP, ZD0 = YD0 + YH;
+    static constexpr int NR = (ZD0 + ZP + 4 * W - 1) / (4 * W) * (4 * W);
+    static_assert(NCORE % (4 * W) == 0, "whole store instructions");
     static constexpr int TOTAL = NCORE * RA + (NR - NCORE) * RH;
     // LDS index of entry k of row r (halo rows store entry 0 resp. 4 first)
     __host__ __device__ static constexpr int at(int r, int k)
@@ -48,15 +58,16 @@ struct SkTile {
     }
 };
 
-template <int TA, int NY, bool STRICT>
-__global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
+template <int TA, int WY, int WZ, bool STRICT>
+__global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
 {
     static_assert(TA == 16, "row-per-16-lanes loader");
-    using T = SkTile<TA, NY>;
-    constexpr int RA = T::RA;
+    using T = SkTile<TA, WY, WZ>;
+    constexpr int RA = T::RA, NYT = T::NYT, NZT = T::NZT, W = T::W, NT = 64 * W;
     __shared__ double lds[T::TOTAL];
     __shared__ int2 rowtab[T::NR];
-    const int lane = threadIdx.x;
+    __shared__ double wsum[W];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1);
     const double dx = a.dx, h = a.h;
@@ -72,10 +83,10 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
 
     const int m = packed & 0x3ff, fB = (packed >> 10) & 0x3ff, fC = (packed >> 20) & 0x3ff;
     const int tj = sj > 0 ? fB : a.nTj - 1 - fB, tk = sk > 0 ? fC : a.nTk - 1 - fC;
-    const int j_lo = 1 + tj * NY, k_lo = 1 + tk * 4;
-    const int nj = min(NY, ny - j_lo), nk = min(4, nz - k_lo);
+    const int j_lo = 1 + tj * NYT, k_lo = 1 + tk * NZT;
+    const int nj = min(NYT, ny - j_lo), nk = min(NZT, nz - k_lo);
     const int nxi = nx - 1;                       // interior cells along x
-    const int X0 = TA * m - NY * fB - 4 * fC;     // Fx of row (0,0) at step 0
+    const int X0 = TA * m - NYT * fB - NZT * fC;  // Fx of row (0,0) at step 0
     const int gb = g % a.nbuf;
     const double* in = a.buf[gb];
     double* out = a.buf[gb + 1 == a.nbuf ? 0 : gb + 1];
@@ -92,61 +103,63 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
     double* out_t = out + org;
     const double* ps_t = a.phiS + org;
     const int gi0 = si > 0 ? 1 + X0 : nx - 1 - X0; // global i of frame position Fx = X0
-    for (int r = lane; r < T::NR; r += 64) {
+    for (int r = tid; r < T::NR; r += NT) {
         int bq, cq, up = 0, core = 0;
-        // rows beyond a partial bundle (nj < NY or nk < 4) are never consumed: they alias a valid row
+        // rows beyond a partial tile (nj < NYT or nk < NZT) are never consumed: they alias a valid row
         if (r < T::YU0) {
-            cq = r / NY, bq = r - NY * cq, core = 1;
+            cq = r / NYT, bq = r - NYT * cq, core = 1;
             bq = min(bq, nj - 1), cq = min(cq, nk - 1);
         } else if (r < T::ZU0) {
             const int q = r - T::YU0;
             cq = q / 3, bq = q - 3 * cq - 3, up = 1;
             cq = min(cq, nk - 1);
         } else if (r < T::YD0) {
-            const int q = min(r - T::ZU0, 14), hz = q / NY;
-            bq = min(q - NY * hz, nj - 1), cq = hz - 3, up = 1;
+            const int q = min(r - T::ZU0, 3 * NYT - 1), hz = q / NYT;
+            bq = min(q - NYT * hz, nj - 1), cq = hz - 3, up = 1;
         } else if (r < T::ZD0) {
             const int q = r - T::YD0;
             cq = q / 3, bq = nj + q - 3 * cq;
             cq = min(cq, nk - 1);
         } else {
-            const int q = min(r - T::ZD0, 14), hz = q / NY;
-            bq = min(q - NY * hz, nj - 1), cq = nk + hz;
+            const int q = min(r - T::ZD0, 3 * NYT - 1), hz = q / NYT;
+            bq = min(q - NYT * hz, nj - 1), cq = nk + hz;
         }
         const int gj_r = j_lo + (sj > 0 ? bq : nj - 1 - bq), gk_r = k_lo + (sk > 0 ? cq : nk - 1 - cq);
         const int rin = (int)((unsigned)(gj_r - 1) <= (unsigned)(ny - 2)) & (int)((unsigned)(gk_r - 1) <= (unsigned)(nz - 2));
         const int gj = min(max(gj_r, 0), ny), gk = min(max(gk_r, 0), nz);
-        const int o = (gj - org_j) * (int)sx + (gk - org_k) * (int)sxy; // a 10-plane slab of any admissible field fits 29 bits
+        const int o = (gj - org_j) * (int)sx + (gk - org_k) * (int)sxy; // a slab of NZT + 6 planes of any admissible field fits 29 bits
         rowtab[r] = make_int2(o * 4 + (rin & up) + 2 * (rin & (up | core)), si > 0 ? gi0 - (bq + cq) : gi0 + (bq + cq));
     }
     __syncthreads();
 
     // ---- load: all global loads in flight before the first LDS write ------------------------------------
-    static_assert(NY == 5, "lane map: 5 cells x 3 axes per 16 lanes");
+    // lane map of a wavefront: 3 lanes per cell inside each 16-lane row (5 cells + 1 idle lane), 4 rows = 4 c;
+    // wavefront (wy, wz) of the tile owns rows b = 5 wy .. 5 wy + 4, c = 4 wz .. 4 wz + 3
     const int t16 = lane & 15;
-    const int b = t16 / 3, axis = t16 - 3 * b, c = lane >> 4; // t16 = 15: b = 5 >= nj, idle
-    const bool row_ok = b < nj && c < nk;
+    const int bl = t16 / 3, axis = t16 - 3 * bl; // t16 = 15: bl = 5, idle
+    const int b = 5 * (wave % WY) + bl, c = 4 * (wave / WY) + (lane >> 4);
+    const bool row_ok = bl < 5 && b < nj && c < nk;
     const int bc = row_ok ? b : 0, cc = row_ok ? c : 0;
     double ps[TA]; // phiS of the 16 cells this lane's cell row holds (the x lane of a cell uses them)
     {
-        constexpr int UM = T::NR / 4;                                   // 16 entries of 4 rows per instruction
+        constexpr int UM = T::NR / (4 * W);                             // 16 entries of 4 rows per wave instruction
         constexpr int XC = 6 * T::NCORE, XH = 2 * (T::NR - T::NCORE);   // the remaining 6 (bundle) / 2 (halo) entries
-        constexpr int UX = (XC + XH + 63) / 64;
+        constexpr int UX = (XC + XH + NT - 1) / NT;
         constexpr int NV = UM + UX;
         double v[NV];
         int dst[NV];
-        const int xx = lane & 15, rsub = lane >> 4;
+        const int xx = tid & 15, rsub = tid >> 4;
         int n_ = 0;
 #pragma unroll
         for (int u = 0; u < UM; ++u, ++n_) {
-            const int r = 4 * u + rsub;
+            const int r0 = 4 * W * u + 4 * wave, r = 4 * W * u + rsub; // r0: first row of this wave's group (uniform)
             const int2 e = rowtab[r];
             // bundle rows: entries 3..18 (old); upstream halo: 2..17 (this sweep's, except wall points); downstream: 4..19
-            const int k = (4 * u < T::YU0 ? 3 : (4 * u < T::YD0 ? 2 : 4)) + xx;
+            const int k = (r0 < T::YU0 ? 3 : (r0 < T::YD0 ? 2 : 4)) + xx;
             const int gi_r = e.y + (si > 0 ? k - 3 : 3 - k);
             const unsigned o = (unsigned)(e.x >> 2) + (unsigned)min(max(gi_r, 0), nx);
             dst[n_] = T::at(r, k);
-            if (4 * u >= T::YU0 && 4 * u < T::YD0) {
+            if (r0 >= T::YU0 && r0 < T::YD0) {
                 const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 1);
                 v[n_] = (fresh ? (const double*)out_t : in_t)[o];
             } else {
@@ -155,16 +168,16 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
         }
 #pragma unroll
         for (int u = 0; u < UX; ++u, ++n_) {
-            const int idx = min(lane + 64 * u, XC + XH - 1);
+            const int idx = min(tid + NT * u, XC + XH - 1);
             int r, k;
             if (idx < XC) { // bundle rows: entries 0..2 (previous tile of the row: this sweep's) and 19..21
                 r = idx / 6;
                 const int ee = idx - 6 * r;
                 k = ee < 3 ? ee : TA + ee;
             } else { // halo rows: entries 0, 1 (upstream) or 20, 21 (downstream)
-                const int h = idx - XC;
-                r = T::NCORE + (h >> 1);
-                k = (r < T::YD0 ? 0 : TA + 4) + (h & 1);
+                const int hh = idx - XC;
+                r = T::NCORE + (hh >> 1);
+                k = (r < T::YD0 ? 0 : TA + 4) + (hh & 1);
             }
             const int2 e = rowtab[r];
             const int gi_r = e.y + (si > 0 ? k - 3 : 3 - k);
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
             v[n_] = (fresh ? (const double*)out_t : in_t)[o];
         }
         {
-            const int2 e = rowtab[cc * NY + bc];
+            const int2 e = rowtab[cc * NYT + bc];
 #pragma unroll
             for (int t = 0; t < TA; ++t)
                 ps[t] = ps_t[(unsigned)(e.x >> 2) + (unsigned)min(max(e.y + (si > 0 ? t : -t), 0), nx)];
@@ -184,11 +197,11 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
     }
     __syncthreads();
 
-    // ---- per-lane constants: 3 lanes per cell inside each 16-lane row (5 cells + 1 idle lane) -------------
+    // ---- per-lane constants ---------------------------------------------------------------------------------
     const int gj = j_lo + (sj > 0 ? bc : nj - 1 - bc), gk = k_lo + (sk > 0 ? cc : nk - 1 - cc);
     const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
     const bool yquirk = axis == 1;
-    const int row_core = (cc * NY + bc) * RA + 3;
+    const int row_core = (cc * NYT + bc) * RA + 3;
     auto row_at = [](int r) { return r < T::NCORE ? r * RA : T::NCORE * RA + (r - T::NCORE) * T::RH - (r < T::YD0 ? 0 : 4); };
     int off[7];
 #pragma unroll
@@ -198,17 +211,17 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
         int base = row_core - 3;
         if (axis == 1) {
             const int bq = bc + dF;
-            base = row_at((bq >= 0 && bq < nj) ? cc * NY + bq : (bq < 0 ? T::YU0 + cc * 3 + bq + 3 : T::YD0 + cc * 3 + bq - nj));
+            base = row_at((bq >= 0 && bq < nj) ? cc * NYT + bq : (bq < 0 ? T::YU0 + cc * 3 + bq + 3 : T::YD0 + cc * 3 + bq - nj));
         } else if (axis == 2) {
             const int cq = cc + dF;
-            base = row_at((cq >= 0 && cq < nk) ? cq * NY + bc : (cq < 0 ? T::ZU0 + (cq + 3) * NY + bc : T::ZD0 + (cq - nk) * NY + bc));
+            base = row_at((cq >= 0 && cq < nk) ? cq * NYT + bc : (cq < 0 ? T::ZU0 + (cq + 3) * NYT + bc : T::ZD0 + (cq - nk) * NYT + bc));
         }
         off[mm] = base + 3 + dF;
     }
     const int fx0 = X0 - bc - cc;
     double acc = 0.0;
 
-    // ---- march: TA steps, every lane busy ------------------------------------------------------------------
+    // ---- march: TA steps, every lane busy; the wavefronts of a tile meet after every step ---------------------
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
         const int fx = fx0 + t;
@@ -237,8 +250,8 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
     const bool near_wall = j_lo == 1 || j_lo + nj == ny || k_lo == 1 || k_lo + nk == nz ||
                            (fx_min <= 0 && fx_max >= 0) || (fx_min <= nxi - 1 && fx_max >= nxi - 1);
 #pragma unroll
-    for (int u = 0; u < T::NCORE / 4; ++u) {
-        const int r = 4 * u + (lane >> 4), cq = r / NY, bq = r - NY * cq, t = lane & 15;
+    for (int u = 0; u < T::NCORE / (4 * W); ++u) {
+        const int r = 4 * W * u + (tid >> 4), cq = r / NYT, bq = r - NYT * cq, t = tid & 15;
         const int2 e = rowtab[r];
         const int gi = e.y + (si > 0 ? t : -t);
         const bool mine = bq < nj && cq < nk && (unsigned)(gi - 1) <= (unsigned)(nx - 2);
@@ -270,15 +283,22 @@ __global__ __launch_bounds__(64) void k_reinit_gs_skew(FlowArgs a)
         }
     }
     acc = wave_sum(acc);
+    if (W > 1) { // fixed-order sum over the wavefronts of the tile
+        if (lane == 0) wsum[wave] = acc;
+        __syncthreads();
+        acc = wsum[0];
+        for (int w = 1; w < W; ++w) acc += wsum[w];
+    }
 
-    // ---- RMS: per-bundle running sum along m (deterministic), epilogue by the last tile of the sweep --------
-    if (lane == 0) {
+    // ---- RMS: per-tile-column running sum along m (deterministic), epilogue by the last tile of the sweep ----
+    if (tid == 0) {
         double* slot = a.colsum + (long)gb * ncol + (tj + (long)a.nTj * tk);
-        const int m_lo = (NY * fB + 4 * fC) / TA;
+        const int m_lo = (NYT * fB + NZT * fC) / TA;
         *slot = ((m == m_lo) ? 0.0 : *slot) + acc;
     }
     if (packed != a.last_packed) return;
     __syncthreads();
+    if (wave != 0) return;
     const double* cs = a.colsum + (long)gb * ncol;
     double tsum = 0.0;
     for (int p = lane; p < ncol; p += 64) tsum += cs[p];

@@ -3,8 +3,8 @@
 
 The reference sweeps the grid in place in raster order (subs.f90:743-852, eight cyclic directions): a cell needs
 this sweep's values of the three cells before it on every axis and last sweep's values of the three cells after it.
-The GPU executor cuts every (5 x 4)-row bundle into tiles along the skew coordinate s = Fx + Fy + Fz and launches
-them by hyperplanes m + fB + fC.  These tests check, on small grids and without a GPU, the properties the
+The GPU executor cuts every (5 WY x 4 WZ)-row bundle (WY x WZ wavefronts per tile) into tiles along the skew
+coordinate s = Fx + Fy + Fz and launches them by hyperplanes m + fB + fC.  These tests check, on small grids and without a GPU, the properties the
 bit-for-bit GPU parity tests rely on:
   * every interior cell belongs to exactly one tile of a sweep and every address the loader forms lies in the array,
   * a cell's upstream stencil cells run in an earlier launch or on an earlier step of the same tile,
@@ -16,14 +16,30 @@ import itertools
 import numpy as np
 import pytest
 
-TA, NY, NZ = 16, 5, 4
-YU0, ZU0, YD0, ZD0, NR = 20, 32, 48, 60, 76
-RASTER = [(1, 1, 1), (1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1), (-1, -1, 1), (-1, 1, 1), (1, -1, 1)]
-GRIDS = [(24, 24, 24), (39, 32, 26), (7, 9, 5), (3, 3, 3), (16, 5, 4), (17, 6, 5), (33, 12, 10), (4, 20, 3)]
+TA = 16
 
 
 def cdiv(a, b):
     return -(-a // b)
+
+
+WAVES = ((1, 1), (2, 1), (4, 1), (8, 1), (2, 2), (4, 2), (4, 4))  # (WY, WZ) shapes the library instantiates
+
+
+def layout(w):
+    """SkTile<16, WY, WZ>: rows of a tile in y and z, first row of each LDS row group, number of rows"""
+    wy, wz = w
+    nyt, nzt = 5 * wy, 4 * wz
+    ncore, yh, zp = nzt * nyt, 3 * nzt, (3 * nyt + 3) // 4 * 4
+    yu0, zu0 = ncore, ncore + yh
+    yd0 = zu0 + zp
+    zd0 = yd0 + yh
+    nr = cdiv(zd0 + zp, 4 * wy * wz) * (4 * wy * wz)
+    return nyt, nzt, yu0, zu0, yd0, zd0, nr
+
+
+RASTER = [(1, 1, 1), (1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1), (-1, -1, 1), (-1, 1, 1), (1, -1, 1)]
+GRIDS = [(24, 24, 24), (39, 32, 26), (7, 9, 5), (3, 3, 3), (16, 5, 4), (17, 6, 5), (33, 12, 10), (4, 20, 3)]
 
 
 def frame(g, n, ts, sgn):
@@ -39,8 +55,9 @@ def frame(g, n, ts, sgn):
     return ts * f_t + b, f_t
 
 
-def row_of(r, nj, nk):
+def row_of(r, nj, nk, w):
     """LDS row r -> frame-local (b', c') exactly as the kernel's row table decodes it"""
+    NY, _, YU0, ZU0, YD0, ZD0, _ = layout(w)
     if r < YU0:
         cq, bq = divmod(r, NY)
         return min(bq, nj - 1), min(cq, nk - 1)
@@ -48,18 +65,20 @@ def row_of(r, nj, nk):
         cq, hy = divmod(r - YU0, 3)
         return hy - 3, min(cq, nk - 1)
     if r < YD0:
-        hz, bq = divmod(min(r - ZU0, 14), NY)
+        hz, bq = divmod(min(r - ZU0, 3 * NY - 1), NY)
         return min(bq, nj - 1), hz - 3
     if r < ZD0:
         cq, hy = divmod(r - YD0, 3)
         return nj + hy, min(cq, nk - 1)
-    hz, bq = divmod(min(r - ZD0, 14), NY)
+    hz, bq = divmod(min(r - ZD0, 3 * NY - 1), NY)
     return min(bq, nj - 1), nk + hz
 
 
+@pytest.mark.parametrize("w", WAVES)
 @pytest.mark.parametrize("dims", GRIDS)
-def test_tiles_cover_every_cell_once_and_addresses_stay_inside(dims):
+def test_tiles_cover_every_cell_once_and_addresses_stay_inside(dims, w):
     nx, ny, nz = dims
+    NY, NZ, _, _, _, _, NR = layout(w)
     sx, sxy = nx + 1, (nx + 1) * (ny + 1)
     n = sxy * (nz + 1)
     n_tj, n_tk, nxi = cdiv(ny - 1, NY), cdiv(nz - 1, NZ), nx - 1
@@ -79,7 +98,7 @@ def test_tiles_cover_every_cell_once_and_addresses_stay_inside(dims):
                 gi0 = 1 + x0 if si > 0 else nx - 1 - x0
                 table = []
                 for r in range(NR):
-                    bq, cq = row_of(r, nj, nk)
+                    bq, cq = row_of(r, nj, nk, w)
                     gj = min(max(j_lo + (bq if sj > 0 else nj - 1 - bq), 0), ny)
                     gk = min(max(k_lo + (cq if sk > 0 else nk - 1 - cq), 0), nz)
                     o = (gj - org_j) * sx + (gk - org_k) * sxy
@@ -102,7 +121,7 @@ def test_tiles_cover_every_cell_once_and_addresses_stay_inside(dims):
         assert not c3.any()
 
 
-def plane_maps(nx, ny, nz, direction):
+def plane_maps(nx, ny, nz, direction, NY, NZ):
     si, sj, sk = direction
     fx = np.array([frame(g, nx, 0, si)[0] for g in range(1, nx)])
     fy = np.array([frame(g, ny, NY, sj) for g in range(1, ny)])
@@ -126,7 +145,7 @@ def shifted(a, axis, d, fill):
     return b
 
 
-def spacing_closed_form(da, db, nx, ny, nz):
+def spacing_closed_form(da, db, nx, ny, nz, NY, NZ):
     """skew_spacing() of lsf_api.hip"""
     m0, md = [0] * 3, [0] * 3
     for ax, (n, ts) in enumerate(((nx, 0), (ny, NY), (nz, NZ))):
@@ -151,10 +170,12 @@ def spacing_closed_form(da, db, nx, ny, nz):
     return tot // TA + 2
 
 
+@pytest.mark.parametrize("w", WAVES)
 @pytest.mark.parametrize("dims", GRIDS + [(64, 64, 64), (100, 37, 51)])
-def test_launch_order_respects_the_in_place_sweep(dims):
+def test_launch_order_respects_the_in_place_sweep(dims, w):
     nx, ny, nz = dims
-    maps = [plane_maps(nx, ny, nz, d) for d in RASTER]
+    NY, NZ = 5 * w[0], 4 * w[1]
+    maps = [plane_maps(nx, ny, nz, d, NY, NZ) for d in RASTER]
     for direction, (plane, step, tile) in zip(RASTER, maps):
         for axis, sgn in zip((2, 1, 0), direction):  # arrays are [k, j, i]
             for d in (1, 2, 3):
@@ -170,5 +191,5 @@ def test_launch_order_respects_the_in_place_sweep(dims):
         for axis in range(3):
             for d in (-3, -2, -1, 1, 2, 3):
                 need = max(need, (shifted(pa, axis, d, -10 ** 6) - pb).max())
-        got = spacing_closed_form(RASTER[q], RASTER[(q + 1) & 7], nx, ny, nz)
+        got = spacing_closed_form(RASTER[q], RASTER[(q + 1) & 7], nx, ny, nz, NY, NZ)
         assert need + 1 <= got <= need + 2
