@@ -307,10 +307,10 @@ def test_reinit_alternative_tile_geometries(lsf, oracle, synth, monkeypatch, geo
 
 @pytest.mark.parametrize("schedule", ["planes", "slots", "flow", "skew:1", "skew:2", "skew:4", "skew:1x2", "skew:2x2", "skew:4x2", "skew:2x4"])
 def test_reinit_alternative_schedules(lsf, synth, cube40, monkeypatch, schedule):
-    """The exact-GS tile graph has several executors (LSF_GS_SCHEDULE): overlapped slot launches on box tiles (the
-    default at these sizes, used by every other test), one launch per hyperplane, the experimental persistent
-    dataflow kernel, and slot launches on skewed tiles of 1, 2 or 4 wavefronts (LSF_GS_SKEW_W; the default above
-    3e7 cells).  All must be bit-identical to the reference."""
+    """The exact-GS tile graph has several executors (LSF_GS_SCHEDULE): slot launches on skewed tiles of WY x WZ
+    wavefronts (LSF_GS_SKEW_W; 2x2 is the default and what every other test runs), slot launches on box tiles, one
+    launch per box-tile hyperplane, and the experimental persistent dataflow kernel.  All must be bit-identical to the
+    reference."""
     schedule, _, waves = schedule.partition(":")
     monkeypatch.setenv("LSF_GS_SCHEDULE", schedule)
     if waves:
