@@ -857,20 +857,21 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     int nTi = 0, nTj = 0, nTk = 0, jblocks = 0;
     long n_part;
     const bool fixed_point = order == LSF_ORDER_GS && exact_mode != MM_TILES;
-    const long fp_blocks = (long)((n + MM_CH - 1) / MM_CH);
+    const long fp_blocks = (long)((n + MM_CH - 1) / MM_CH);  // blocks of the scan
+    const long fp_chunks = (long)((n + MM_SUB - 1) / MM_SUB); // chunks: flags, stamps, RMS partials
     int *bflag = nullptr, *chg = nullptr, *stamp = nullptr;
     constexpr size_t CHG_BYTES = (MM_MAX_FIX + 1) * sizeof(int);
     double* part2 = nullptr;
     if (fixed_point) {
-        n_part = fp_blocks;
-        if ((rc = ws(c.slot[S_BFLAG], (size_t)fp_blocks * sizeof(int)))) return rc;
+        n_part = fp_chunks;
+        if ((rc = ws(c.slot[S_BFLAG], (size_t)fp_chunks * sizeof(int)))) return rc;
         if ((rc = ws(c.slot[S_CHG], CHG_BYTES))) return rc;
-        if ((rc = ws(c.slot[S_STAMP], (size_t)fp_blocks * sizeof(int)))) return rc;
+        if ((rc = ws(c.slot[S_STAMP], (size_t)fp_chunks * sizeof(int)))) return rc;
         if ((rc = ws(c.slot[S_PART2], 256 * sizeof(double)))) return rc;
         bflag = (int*)c.slot[S_BFLAG].p;
         chg = (int*)c.slot[S_CHG].p;
         stamp = (int*)c.slot[S_STAMP].p;
-        HIPCHK(hipMemsetAsync(stamp, 0, (size_t)fp_blocks * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(stamp, 0, (size_t)fp_chunks * sizeof(int), st));
         part2 = (double*)c.slot[S_PART2].p;
     } else if (order == LSF_ORDER_GS) {
         nTi = cdiv(nx + 1, MM_TA), nTj = cdiv(ny + 1, 8), nTk = cdiv(nz + 1, 8);
@@ -893,6 +894,8 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     // read with the stop flag every CHECK_EVERY iterations): twice that plus two.  Too few -> ctl[3], the caller
     // repeats the call with MM_MAX_FIX passes.
     int cap = exact_mode == MM_FP_FULL ? MM_MAX_FIX : MM_FIX_START;
+    if (const char* e = getenv("LSF_MINMAX_FIX_START")) // test hook: start with too few passes to exercise the rerun
+        if (exact_mode == MM_FP_ADAPTIVE) cap = std::min(MM_MAX_FIX, std::max(1, atoi(e)));
     for (int it = 0; it < iter; ++it) { // DO n = 1,iter (set3d.f90:394)
         const double* A = bufs[it & 1];
         double* B = bufs[(it + 1) & 1];
@@ -900,18 +903,18 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
         if (fixed_point) {
             HIPCHK(hipMemsetAsync(chg, 0, CHG_BYTES, st));
             const dim3 g((unsigned)fp_blocks), b(256);
-            const dim3 gwide((unsigned)std::min<long>(cdiv(fp_blocks, 64), 4096)), gthin((unsigned)std::min<long>(cdiv(fp_blocks, 64), 1024));
+            const dim3 gwide((unsigned)std::min<long>(cdiv(fp_chunks, 64), 4096)), gthin((unsigned)std::min<long>(cdiv(fp_chunks, 64), 1024));
             const int epoch0 = it * (MM_MAX_FIX + 1) + 1; // stamps of this iteration: epoch0+1 .. epoch0+MM_MAX_FIX
             hipLaunchKernelGGL((k_minmax_fp<0>), g, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, stamp, fp_blocks, 0, 0,
                                (const int*)nullptr, (int*)nullptr, part, ctl);
             for (int f = 0; f < cap; ++f)
                 hipLaunchKernelGGL((k_minmax_fp<1>), f < 3 ? gwide : gthin, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag,
-                                   stamp, fp_blocks, epoch0 + f, f == 0 ? 1 : 0,
+                                   stamp, fp_chunks, epoch0 + f, f == 0 ? 1 : 0,
                                    f == 0 ? (const int*)nullptr : (const int*)(chg + f - 1), chg + f, part, ctl);
             // pass 2 also records how many fix passes changed cells (first = cap) and flags an uncertified iteration
-            hipLaunchKernelGGL((k_minmax_fp<2>), gwide, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, stamp, fp_blocks, 0,
+            hipLaunchKernelGGL((k_minmax_fp<2>), gwide, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, stamp, fp_chunks, 0,
                                cap, (const int*)(chg + cap - 1), (int*)nullptr, part, ctl);
-            hipLaunchKernelGGL(k_reduce_slices, dim3(256), dim3(256), 0, st, (const double*)part, fp_blocks, part2);
+            hipLaunchKernelGGL(k_reduce_slices, dim3(256), dim3(256), 0, st, (const double*)part, fp_chunks, part2);
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, (const double*)part2, 256L, den, tol, d_trace,
                                std::max(iter, 1), ctl);
         } else if (order == LSF_ORDER_GS) {
@@ -992,22 +995,17 @@ int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int
                                 trace_cap, st, MM_TILES, nullptr);
     Ctx& c = ctx();
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
-    int rc = ws(c.slot[S_BACKUP], n * (sizeof(double) + 2 * sizeof(int32_t)));
+    // an uncertified attempt returns before it touches the masks, so only phi needs a copy to start over from
+    int rc = ws(c.slot[S_BACKUP], n * sizeof(double));
     if (rc) return rc;
     char* bk = (char*)c.slot[S_BACKUP].p;
     HIPCHK(hipMemcpyAsync(bk, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(bk + n * sizeof(double), d_nb, n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(bk + n * (sizeof(double) + sizeof(int32_t)), d_sb, n * sizeof(int32_t),
-                          hipMemcpyDeviceToDevice, st));
     for (int exact_mode : {MM_FP_ADAPTIVE, MM_FP_FULL}) {
         bool inexact = false;
         rc = minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap,
                               st, exact_mode, &inexact);
         if (rc != LSF_OK || !inexact) return rc;
         HIPCHK(hipMemcpyAsync(d_phi, bk, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(d_nb, bk + n * sizeof(double), n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(d_sb, bk + n * (sizeof(double) + sizeof(int32_t)), n * sizeof(int32_t),
-                              hipMemcpyDeviceToDevice, st));
     }
     return minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap,
                             st, MM_TILES, nullptr);

@@ -272,11 +272,12 @@ __global__ __launch_bounds__(256) void k_minmax_jacobi(const double* __restrict_
 // Sign flips need |pAve| ~ h1*|curv|: a handful of cells hugging phi = 0 at first (2-3 passes), but the
 // flow itself breeds such cells (1024^3 two-sphere case: 45 000 chunks change in pass 1 of iteration 12 and
 // the count falls ~4x per pass), so passes after the first visit only the chunks downstream of a change.
-// Fixed point-to-block map (MM_CH points per block) -> per-block band flags and deterministic RMS.
+// Fixed point-to-chunk map (MM_SUB consecutive points per chunk) -> per-chunk band flags, stamps and RMS
+// partials (deterministic).  The scan handles MM_CH points (4 chunks) per block.
 // ---------------------------------------------------------------------------------------------
-constexpr int MM_CH = 2048;
+constexpr int MM_CH = 2048, MM_SUB = 512;
 
-// PASS 0: scan (copy + Jacobi update + band flags), one chunk per block.
+// PASS 0: scan (copy + Jacobi update + band flags), MM_CH points per block (nchunks counts those blocks).
 // PASS 1: fix pass `epoch` of this call.  The first fix pass of an iteration (first != 0) re-evaluates every
 //         band chunk; later ones only the chunks a change of the previous pass can reach: a cell that changes
 //         stamps the chunks of its three downstream neighbours with epoch+1, and pass epoch+1 visits the
@@ -294,8 +295,9 @@ __global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A,
                                                    int* __restrict__ ctl)
 {
     __shared__ double red[4];
-    __shared__ int flag;
+    __shared__ int flag, flag4[MM_CH / MM_SUB];
     __shared__ unsigned long long todo;
+    constexpr int CH = PASS == 0 ? MM_CH : MM_SUB; // points one trip of the loop below covers
     if (ctl[0]) return;
     if (PASS == 1 && changed_prev && *changed_prev == 0) return;
     const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1), n = sxy * (nz + 1);
@@ -320,12 +322,13 @@ __global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A,
             const long chunk = base + blockIdx.x + (long)l * gridDim.x;
             if (PASS == 0 && chunk >= nchunks) break;
             if (threadIdx.x == 0) flag = 0;
+            if (PASS == 0 && threadIdx.x < MM_CH / MM_SUB) flag4[threadIdx.x] = 0;
             __syncthreads();
             double acc = 0.0;
             int mine = 0;
 #pragma unroll
-            for (int t = 0; t < MM_CH / 256; ++t) {
-                const long p = chunk * MM_CH + t * 256 + threadIdx.x;
+            for (int t = 0; t < CH / 256; ++t) {
+                const long p = chunk * CH + t * 256 + threadIdx.x;
                 if (p >= n) break;
                 const int i = p % sx, j = (p / sx) % (ny + 1), k = p / sxy;
                 const double c = A[p];
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A,
                         const double xm = A[p - 1], xp = A[p + 1], ym = A[p - sx], yp = A[p + sx], zm = A[p - sxy],
                                      zp = A[p + sxy];
                         out = minmax_update(c, xm, xp, yp, ym, zp, zm, minmax_curv(c, xp, xm, yp, ym, zp, zm, dxx), h1);
-                        mine = 1;
+                        mine |= 1 << (t * 256 / MM_SUB);
                     }
                     B[p] = out;
                 } else if (band) {
@@ -352,9 +355,9 @@ __global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A,
                             B[p] = nv;
                             mine = 1;
                             // the three cells that read this one: interior, hence inside the array
-                            stamp[(p + 1) / MM_CH] = epoch + 1;
-                            stamp[(p + sx) / MM_CH] = epoch + 1;
-                            stamp[(p + sxy) / MM_CH] = epoch + 1;
+                            stamp[(p + 1) / MM_SUB] = epoch + 1;
+                            stamp[(p + sx) / MM_SUB] = epoch + 1;
+                            stamp[(p + sxy) / MM_SUB] = epoch + 1;
                         }
                     } else {
                         const double d = B[p] - c;
@@ -367,16 +370,20 @@ __global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A,
                 if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
                 __syncthreads();
                 if (threadIdx.x == 0) partials[chunk] = red[0] + red[1] + red[2] + red[3];
+            } else if (PASS == 0) {
+#pragma unroll
+                for (int sb = 0; sb < MM_CH / MM_SUB; ++sb)
+                    if (mine & (1 << sb)) flag4[sb] = 1;
+                __syncthreads();
+                const long sub = chunk * (MM_CH / MM_SUB) + threadIdx.x;
+                if (threadIdx.x < MM_CH / MM_SUB && sub * MM_SUB < n) {
+                    blockflag[sub] = flag4[threadIdx.x];
+                    partials[sub] = 0.0; // pass 2 overwrites the band chunks
+                }
             } else {
                 if (mine) flag = 1;
                 __syncthreads();
-                if (threadIdx.x == 0) {
-                    if (PASS == 0) {
-                        blockflag[chunk] = flag;
-                        partials[chunk] = 0.0; // pass 2 overwrites the band chunks
-                    } else if (flag)
-                        atomicAdd(changed_cur, 1); // number of chunks this pass still changed
-                }
+                if (threadIdx.x == 0 && flag) atomicAdd(changed_cur, 1); // number of chunks this pass still changed
             }
             __syncthreads();
         }

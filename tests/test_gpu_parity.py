@@ -284,6 +284,21 @@ def test_minmax_tile_wavefront_path(lsf, oracle, cube40, monkeypatch):
     test_minmax_vs_oracle_other_shapes(lsf, oracle)
 
 
+def test_minmax_uncertified_fixed_point_is_repeated(lsf, oracle, cube40, monkeypatch, capfd):
+    """The fixed-point passes are enqueued without a host round trip; when an iteration needs more passes than were
+    enqueued, the call starts over with the full count.  One pass is never enough here (the first fix pass always
+    changes cells), so this runs the second rung of the ladder; the result must not change."""
+    monkeypatch.setenv("LSF_MINMAX_FIX_START", "1")
+    monkeypatch.setenv("LSF_TRACE", "1")
+    nx, ny, nz = _n(cube40)
+    phi, nb, sb = F(cube40["phi_reinit"]), F(cube40["NB0"].astype(np.int32)), F(cube40["SB0"].astype(np.int32))
+    rep = lsf.minmaxFlow(phi, nb, sb, nx, ny, nz, 10, float(cube40["dx"]), float(cube40["h1"]))
+    assert rep.count == 10 and sha(phi) == str(cube40["mm10_sha"])
+    assert "NOT certified -> rerun" in capfd.readouterr().err
+    monkeypatch.delenv("LSF_TRACE")
+    test_minmax_vs_oracle_other_shapes(lsf, oracle)
+
+
 @pytest.mark.parametrize("geometry", [("4", "16"), ("5", "32"), ("4", "32")])
 def test_reinit_alternative_tile_geometries(lsf, oracle, synth, monkeypatch, geometry):
     """Default tiles are 16 x 5 x 4 cells with three lanes per cell; 4-lane cells and 32-long tiles are kept."""
