@@ -180,7 +180,7 @@ def main() -> None:
     else:
         order = args.mode
         nx = ny = nz = N - 1
-        if N > 640:  # numpy temporaries of a 1024^3 field do not belong in host memory: build it in HBM
+        if N > 640 or world > 1:  # numpy temporaries (several fields per rank) do not belong in host memory: build it in HBM
             phi0, dx = fields.two_sphere_phi0_device((N, N, N), dev)
         else:
             phi0_np, dx = fields.two_sphere_phi0((N, N, N))
