@@ -830,7 +830,7 @@ int narrowband_core(const double* d_phi, int32_t* d_nb, int32_t* d_sb, size_t n,
 }
 
 constexpr int MM_MAX_FIX = 32;   // most fix passes ever enqueued per min/max iteration
-constexpr int MM_FIX_START = 12; // adaptive mode: passes enqueued per iteration until the first host check
+constexpr int MM_FIX_START = 16; // adaptive mode: passes enqueued per iteration until the first host check
 // how the exact ordering of the min/max flow is produced
 enum MinmaxExact { MM_TILES = 0, MM_FP_ADAPTIVE = 1, MM_FP_FULL = 2 };
 
@@ -891,8 +891,10 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     const bool trace_fp = tfp && atoi(tfp) != 0;
     // Fix passes enqueued per iteration.  A pass that finds the fixed point certified returns at once, but an empty
     // launch still costs ~6 us, so the count follows what the field needs (ctl[4] = most passes that changed cells,
-    // read with the stop flag every CHECK_EVERY iterations): twice that plus two.  Too few -> ctl[3], the caller
-    // repeats the call with MM_MAX_FIX passes.
+    // read with the stop flag every CHECK_EVERY iterations): three times that plus four.  Too few -> ctl[3], the
+    // caller repeats the call with MM_MAX_FIX passes.  Large grids skip the adaptation (minmax_core): their chains of
+    // sign flips grow fast (1024^3 two spheres: 4, 7, 9, 16 passes in iterations 4..8 of a call) and 32 launches are
+    // 4 % of an iteration there.
     int cap = exact_mode == MM_FP_FULL ? MM_MAX_FIX : MM_FIX_START;
     if (const char* e = getenv("LSF_MINMAX_FIX_START")) // test hook: start with too few passes to exercise the rerun
         if (exact_mode == MM_FP_ADAPTIVE) cap = std::min(MM_MAX_FIX, std::max(1, atoi(e)));
@@ -940,11 +942,13 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
             for (int f = 0; f < MM_MAX_FIX; ++f) fprintf(stderr, " %d", hc[f]);
             fprintf(stderr, "\n");
         }
-        if ((it + 1) % CHECK_EVERY == 0 && it + 1 < iter) {
+        // the adaptive pass count looks at the device early (after iterations 1, 2 and 4), then with the stop flag
+        const bool early = fixed_point && exact_mode == MM_FP_ADAPTIVE && (it == 0 || it == 1 || it == 3);
+        if (((it + 1) % CHECK_EVERY == 0 || early) && it + 1 < iter) {
             HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             if (host_ctl[0] || host_ctl[3]) break;
-            if (exact_mode == MM_FP_ADAPTIVE) cap = std::min(MM_MAX_FIX, std::max(6, 2 * host_ctl[4] + 2));
+            if (exact_mode == MM_FP_ADAPTIVE) cap = std::min(MM_MAX_FIX, std::max(8, 3 * host_ctl[4] + 4));
         }
     }
     HIPCHK(hipGetLastError());
@@ -1001,6 +1005,7 @@ int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int
     char* bk = (char*)c.slot[S_BACKUP].p;
     HIPCHK(hipMemcpyAsync(bk, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st));
     for (int exact_mode : {MM_FP_ADAPTIVE, MM_FP_FULL}) {
+        if (exact_mode == MM_FP_ADAPTIVE && n >= (size_t)200000000) continue; // >= ~585^3: always the full count
         bool inexact = false;
         rc = minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap,
                               st, exact_mode, &inexact);
