@@ -140,7 +140,13 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
     const int b = 5 * (wave % WY) + bl, c = 4 * (wave / WY) + (lane >> 4);
     const bool row_ok = bl < 5 && b < nj && c < nk;
     const int bc = row_ok ? b : 0, cc = row_ok ? c : 0;
-    double ps[TA]; // phiS of the 16 cells this lane's cell row holds (the x lane of a cell uses them)
+    // phiS of the 16 cells this lane's cell row holds (the x lane of a cell uses them): 8 registers, refilled for
+    // step t + 8 as soon as step t has used its value
+    double ps[TA / 2];
+    const int2 e_ps = rowtab[cc * NYT + bc];
+    auto ps_load = [&](int t) {
+        return ps_t[(unsigned)(e_ps.x >> 2) + (unsigned)min(max(e_ps.y + (si > 0 ? t : -t), 0), nx)];
+    };
     {
         constexpr int UM = T::NR / (4 * W);                             // 16 entries of 4 rows per wave instruction
         constexpr int XC = 6 * T::NCORE, XH = 2 * (T::NR - T::NCORE);   // the remaining 6 (bundle) / 2 (halo) entries
@@ -186,12 +192,8 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
             dst[n_] = T::at(r, k);
             v[n_] = (fresh ? (const double*)out_t : in_t)[o];
         }
-        {
-            const int2 e = rowtab[cc * NYT + bc];
 #pragma unroll
-            for (int t = 0; t < TA; ++t)
-                ps[t] = ps_t[(unsigned)(e.x >> 2) + (unsigned)min(max(e.y + (si > 0 ? t : -t), 0), nx)];
-        }
+        for (int t = 0; t < TA / 2; ++t) ps[t] = ps_load(t);
 #pragma unroll
         for (int u = 0; u < NV; ++u) lds[dst[u]] = v[u]; // duplicates (clamped indices) rewrite the same value
     }
@@ -229,7 +231,8 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
         double q[7];
 #pragma unroll
         for (int mm = 0; mm < 7; ++mm) q[mm] = lds[off[mm] + t];
-        const double pS = ps[t];
+        const double pS = ps[t & (TA / 2 - 1)];
+        if (t + TA / 2 < TA) ps[t & (TA / 2 - 1)] = ps_load(t + TA / 2);
         const int gi = si > 0 ? 1 + fx : nx - 1 - fx;
         const bool weno_ok = yz_weno && gi > 3 && gi < nx - 4;
         double dm, dp;
