@@ -258,7 +258,7 @@ def main() -> None:
 
     per_gpu_cells_per_sweep = cells_total / K / world
     out = {
-        "metric": "cell-updates/s (WENO5 reinit, 512^3 fp64)",
+        "metric": f"cell-updates/s (WENO5 reinit, {N}^3 fp64)",
         "value": cells_total / seconds,
         "unit": "cell-updates/s",
         "n_gpus": world,
