@@ -320,6 +320,26 @@ def test_reinit_alternative_tile_geometries(lsf, oracle, synth, monkeypatch, geo
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("waves", ["2x2", "1", "4x2"])
+def test_reinit_odd_grid_shapes(lsf, oracle, monkeypatch, waves):
+    """Grids whose extents are not multiples of the tile size (partial tiles at either end, extents below one tile,
+    two interior cells per axis): every sweep direction once, bit-identical to the oracle."""
+    from levelsetfortran_amd import fields
+
+    monkeypatch.setenv("LSF_GS_SKEW_W", waves)
+    for npts in ((4, 4, 4), (6, 10, 8), (18, 7, 6), (34, 13, 11), (10, 42, 14), (65, 8, 30), (23, 23, 5), (5, 5, 47)):
+        phi0, dx = fields.two_sphere_phi0(npts)
+        nx, ny, nz = (v - 1 for v in npts)
+        h = fields.reinit_step(dx)
+        ref = phi0.copy(order="F")
+        _, n_ref, tr_ref = oracle.reinit(ref, nx, ny, nz, 8, dx, h, tol=0.0)
+        got = phi0.copy(order="F")
+        rep = lsf.reinit(got, None, None, nx, ny, nz, 8, dx, h, tol=0.0, arith="strict")
+        assert rep.count == n_ref == 9, npts
+        assert np.array_equal(got, ref), npts
+        assert np.allclose(rep.rms, tr_ref[:9], rtol=1e-9, atol=0), npts
+
+
 @pytest.mark.parametrize("schedule", ["planes", "slots", "flow", "skew:1", "skew:2", "skew:4", "skew:1x2", "skew:2x2", "skew:4x2", "skew:2x4"])
 def test_reinit_alternative_schedules(lsf, synth, cube40, monkeypatch, schedule):
     """The exact-GS tile graph has several executors (LSF_GS_SCHEDULE): slot launches on skewed tiles of WY x WZ
