@@ -249,11 +249,13 @@ def main() -> None:
                 traffic = None
         return {
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": kernel, "launches_per_sweep": lps,
+            "traffic": traffic / lps if traffic else None, "kernel": kernel, "launches_per_sweep": lps,
             "avg_launch_us": per_sweep_s / lps * 1e6,
             "algorithmic_bytes_per_launch": cells_per_sweep * BYTES_PER_CELL_UPDATE / lps,
+            "traffic_per_sweep": traffic, "algorithmic_bytes_per_sweep": cells_per_sweep * BYTES_PER_CELL_UPDATE,
             "note": "achieved = 24 B x (N-2)^3 cells / HIP-event time of the sweep kernel launch(es) of one sweep; "
-                    "traffic = measured HBM bytes per sweep from rocprofv3 PMC passes (profiles/), null if not collected",
+                    "traffic = measured HBM bytes per launch (per sweep / launches per sweep) from the rocprofv3 PMC "
+                    "passes summarised in profiles/, null if not collected for this size",
         }
 
     per_gpu_cells_per_sweep = cells_total / K / world
