@@ -1360,17 +1360,25 @@ int lsf_jacobi_sweep_box(const double* d_in, double* d_out, const double* d_phiS
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(cdiv(hi[0] - lo[0], JAC_BX), cdiv(hi[1] - lo[1], JAC_BY), cdiv(hi[2] - lo[2], JAC_KC));
+    // regions a few cells wide in x (the x rim of a decomposed sweep) run with the lanes along y
+    const bool thinx = hi[0] - lo[0] <= 8 && hi[1] - lo[1] >= 32;
+    const dim3 grid = thinx ? dim3(cdiv(hi[1] - lo[1], JAC_BX), cdiv(hi[0] - lo[0], JAC_BY), cdiv(hi[2] - lo[2], JAC_KC))
+                            : dim3(cdiv(hi[0] - lo[0], JAC_BX), cdiv(hi[1] - lo[1], JAC_BY), cdiv(hi[2] - lo[2], JAC_KC));
     const long np = (long)grid.x * grid.y * grid.z;
     double* part = nullptr;
     if ((rc = stream_partials(st, (size_t)np, &part))) return rc;
     const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
-    if (mode & LSF_ARITH_STRICT)
-        hipLaunchKernelGGL((k_reinit_jacobi<true>), grid, dim3(JAC_BX, JAC_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0],
-                           lo[1], lo[2], hi[0], hi[1], hi[2], dx, h, part, (const int*)nullptr);
-    else
-        hipLaunchKernelGGL((k_reinit_jacobi<false>), grid, dim3(JAC_BX, JAC_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0],
-                           lo[1], lo[2], hi[0], hi[1], hi[2], dx, h, part, (const int*)nullptr);
+#define LSF_LAUNCH_JAC(ST_, TX_)                                                                                      \
+    hipLaunchKernelGGL((k_reinit_jacobi<ST_, TX_>), grid, dim3(JAC_BX, JAC_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0], \
+                       lo[1], lo[2], hi[0], hi[1], hi[2], dx, h, part, (const int*)nullptr)
+    if (mode & LSF_ARITH_STRICT) {
+        if (thinx) LSF_LAUNCH_JAC(true, true);
+        else LSF_LAUNCH_JAC(true, false);
+    } else {
+        if (thinx) LSF_LAUNCH_JAC(false, true);
+        else LSF_LAUNCH_JAC(false, false);
+    }
+#undef LSF_LAUNCH_JAC
     hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(256), 0, st, part, np, d_sumsq);
     HIPCHK(hipGetLastError());
     return LSF_OK;

@@ -38,7 +38,9 @@ constexpr int JAC_BX = 64, JAC_BY = LSF_JAC_BY, JAC_KC = LSF_JAC_KC;
 #ifndef LSF_JAC_WAVES
 #define LSF_JAC_WAVES 1
 #endif
-template <bool STRICT>
+// THINX: for regions only a few cells wide in x (the x rim of a block-decomposed sweep, 3 cells) the lanes of a
+// wavefront run along y instead (blockIdx.y picks the x cell): strided loads, but 64 busy lanes instead of 3.
+template <bool STRICT, bool THINX = false>
 __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi(const double* __restrict__ A,
                                                                    double* __restrict__ Bout,
                                                                    const double* __restrict__ phiS, Box bx,
@@ -49,8 +51,8 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi
 {
     __shared__ double red[JAC_BX * JAC_BY / 64];
     if (done && *done) return;
-    const int li = lo0 + blockIdx.x * JAC_BX + threadIdx.x;
-    const int lj = lo1 + blockIdx.y * JAC_BY + threadIdx.y;
+    const int li = THINX ? lo0 + (int)(blockIdx.y * JAC_BY + threadIdx.y) : lo0 + (int)(blockIdx.x * JAC_BX + threadIdx.x);
+    const int lj = THINX ? lo1 + (int)(blockIdx.x * JAC_BX + threadIdx.x) : lo1 + (int)(blockIdx.y * JAC_BY + threadIdx.y);
     const int k0 = lo2 + blockIdx.z * JAC_KC;
     const int k1 = min(k0 + JAC_KC, hi2);
     const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
