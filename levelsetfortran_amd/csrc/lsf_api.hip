@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <map>
 #include <mutex>
 #include <string>
@@ -89,6 +90,13 @@ struct TileList {
     uint32_t last = 0;    // skewed lists: the only tile of the last plane
 };
 
+// dataflow schedule of the exact ordering: tiles of a batch of sweeps in slot order, per-sweep table, hyperplane sizes
+struct BatchPlan {
+    uint2* d_order = nullptr;
+    int* d_aux = nullptr; // [4 * 32] {sign i, j, k, spacing} per sweep, then [np] tiles per hyperplane
+    long total = 0;
+};
+
 enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_FLAGS, S_FLOWCTL, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_NSLOTS };
 
 struct Ctx {
@@ -96,6 +104,7 @@ struct Ctx {
     std::map<hipStream_t, Buf> part_by_stream;
     std::map<uint64_t, TileList> tiles;
     std::map<uint64_t, TileList> skew_tiles;
+    std::map<std::array<int, 6>, BatchPlan> plans; // dataflow schedule: batch plans per grid / raster phase / sweep count
     bool checked = false;
 };
 
@@ -495,7 +504,8 @@ int gs_schedule()
     if (e && std::strcmp(e, "flow") == 0) return 2;
     if (e && std::strcmp(e, "skew") == 0) return 3;
     if (e && std::strcmp(e, "slots") == 0) return 1;
-    return -1; // unset: slots on skewed tiles
+    if (e && std::strcmp(e, "dataflow") == 0) return 5;
+    return -1; // unset: dataflow on skewed tiles
 }
 
 int reinit_flow_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
@@ -658,9 +668,13 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     const int ta = gs_ta();
     int nyc = gs_ny();
     int sched = gs_schedule();
-    // Default: skewed tiles (lsf_skew.hpp), 2 x 2 wavefronts each.  Measured against the box tiles of lsf_flow.hpp
-    // (`slots`): 32^3 0.16 vs 0.20 ms, 256^3 1.33 vs 1.75, 512^3 4.81 vs 6.83, 1024^3 25.5 vs 38.0 ms per sweep.
-    if (sched < 0) sched = 3;
+    // Default: skewed tiles (lsf_skew.hpp), 2 x 2 wavefronts each, dependencies resolved in the kernel (`dataflow`,
+    // one launch per batch of sweeps).  Measured per sweep: dataflow / slot launches on skewed tiles (`skew`) / slot
+    // launches on the box tiles of lsf_flow.hpp (`slots`): 256^3 0.97 / 1.24 / 1.75 ms, 512^3 3.25 / 4.61 / 6.83 ms,
+    // 1024^3 24.7 / 25.2 / 38.0 ms.
+    if (sched < 0) sched = 5;
+    const bool persist = sched == 5; // k_reinit_gs_persist
+    if (persist) sched = 3;
     // skewed tiles need TA = 16, NY = 5 and at least two interior cells per axis
     const bool skew = sched == 3 && ta == 16 && nyc == 5 && nx >= 3 && ny >= 3 && nz >= 3;
     int wy = 1, wz = 1, nzc = 4;
@@ -724,6 +738,96 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     prof_begin();
     prof_mark(st);
     long launches = 0;
+    if (persist && skew && wy == 2 && wz == 2) {
+        // Dataflow schedule (k_reinit_gs_persist): one launch per batch of up to 32 sweeps, one block per tile,
+        // dependencies resolved in the kernel.  The batch plan (tiles in slot order, spacing table) depends on the grid,
+        // the raster phase of the batch's first sweep and the number of sweeps only, and is cached on the device.
+        const long ntiles = tl->off[np];
+        // sweeps per launch: 32 (the sweep index has 5 bits in the task word), fewer on very large grids so that the
+        // task list stays below 256 MB; a multiple of 8 keeps the raster phase, hence the cached plan, the same
+        const int BATCH = (int)std::max<long>(8, std::min<long>(32, (256L << 20) / (ntiles * 8) / 8 * 8));
+        const int nM = (nx - 2 + nyc * nTj - 1 + nzc * nTk - 1) / ta + 1; // m_max + 1 (get_skew_tiles)
+        const size_t tile_flags = (size_t)BATCH * nM * nTj * nTk;
+        if ((rc = ws(c.slot[S_FLAGS], ((size_t)BATCH * np + BATCH + 16) * sizeof(int)))) return rc;
+        if ((rc = ws(c.slot[S_BFLAG], tile_flags * sizeof(int)))) return rc;
+        int* d_cnt = (int*)c.slot[S_FLAGS].p;
+        int* d_done = d_cnt + (size_t)BATCH * np;
+        int* d_ticket = d_done + BATCH;
+        unsigned long long* d_dbg = nullptr;
+        if (getenv("LSF_TRACE")) {
+            if ((rc = ws(c.slot[S_FLOWCTL], 64))) return rc;
+            d_dbg = (unsigned long long*)c.slot[S_FLOWCTL].p;
+        }
+        for (int g0 = 0; g0 < max_sweeps; g0 += BATCH) {
+            const int ns = std::min(BATCH, max_sweeps - g0), phase = (first_raster + g0) & 7;
+            const std::array<int, 6> key{nx, ny, nz, phase, ns, 0x22};
+            auto it = c.plans.find(key);
+            if (it == c.plans.end()) {
+                BatchPlan bp;
+                std::vector<uint32_t> h_tiles((size_t)ntiles);
+                HIPCHK(hipMemcpy(h_tiles.data(), tl->d, (size_t)ntiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                std::vector<int> h_aux(4 * 32 + np, 0); // sweep table, then tiles per hyperplane
+                std::vector<long> st0(ns, 0);
+                for (int q = 0; q < ns; ++q) {
+                    const int* db = RASTER_SIGN[(phase + q) & 7];
+                    for (int ax = 0; ax < 3; ++ax) h_aux[4 * q + ax] = db[ax];
+                    if (q == 0) continue;
+                    const long H = skew_spacing(RASTER_SIGN[(phase + q - 1) & 7], db, nx, ny, nz, ta, nyc, nzc);
+                    h_aux[4 * q + 3] = (int)H;
+                    st0[q] = st0[q - 1] + H;
+                    if (q >= 3) st0[q] = std::max(st0[q], st0[q - 3] + np + 1); // list order respects condition (c)
+                }
+                for (int P = 0; P < np; ++P) h_aux[4 * 32 + P] = tl->off[P + 1] - tl->off[P];
+                // the entries of the batch in slot order (what the slot schedule would launch, launch after launch)
+                std::vector<uint2> order;
+                order.reserve((size_t)ns * ntiles);
+                int lo_s = 0;
+                for (long slot = 0; lo_s < ns; ++slot) {
+                    for (int q = lo_s; q < ns && st0[q] <= slot; ++q) {
+                        const long P = slot - st0[q];
+                        if (P >= np) continue;
+                        for (int i = tl->off[P]; i < tl->off[P + 1]; ++i)
+                            order.push_back(make_uint2(h_tiles[i], (unsigned)q | ((unsigned)P << 5)));
+                    }
+                    while (lo_s < ns && st0[lo_s] + np <= slot + 1) ++lo_s;
+                }
+                bp.total = (long)order.size();
+                HIPCHK(hipMalloc((void**)&bp.d_order, order.size() * sizeof(uint2)));
+                HIPCHK(hipMalloc((void**)&bp.d_aux, h_aux.size() * sizeof(int)));
+                HIPCHK(hipMemcpy(bp.d_order, order.data(), order.size() * sizeof(uint2), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(bp.d_aux, h_aux.data(), h_aux.size() * sizeof(int), hipMemcpyHostToDevice));
+                it = c.plans.emplace(key, bp).first;
+            }
+            const BatchPlan& bp = it->second;
+            HIPCHK(hipMemsetAsync(d_cnt, 0, ((size_t)BATCH * np + BATCH + 16) * sizeof(int), st)); // counters, ticket
+            HIPCHK(hipMemsetAsync(c.slot[S_BFLAG].p, 0, (size_t)ns * nM * nTj * nTk * sizeof(int), st));
+            if (d_dbg) HIPCHK(hipMemsetAsync(d_dbg, 0, 64, st));
+            fa.sweep_tab = bp.d_aux, fa.plane_size = bp.d_aux + 4 * 32;
+            fa.order = bp.d_order, fa.total = bp.total;
+            fa.nsweeps = ns, fa.g0 = g0, fa.np = np;
+            fa.plane_cnt = d_cnt, fa.planes_done = d_done, fa.ticket = d_ticket;
+            fa.tile_done = (int*)c.slot[S_BFLAG].p, fa.nM = nM;
+            fa.dbg = d_dbg;
+            // one block per tile; a block takes its tile from the ticket counter, so the grid only has to be large enough
+            // (2-D: gridDim.x * blockDim.x must stay below 2^32)
+            const dim3 grid((unsigned)std::min<long>(fa.total, 65536), (unsigned)((fa.total + 65535) / 65536));
+            if (strict) hipLaunchKernelGGL((k_reinit_gs_persist<16, 2, 2, true>), grid, dim3(256), 0, st, fa);
+            else hipLaunchKernelGGL((k_reinit_gs_persist<16, 2, 2, false>), grid, dim3(256), 0, st, fa);
+            ++launches;
+            if (g0 + BATCH < max_sweeps || d_dbg) { // stop flag between batches (later batches would exit at once anyway)
+                HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (d_dbg) {
+                    unsigned long long hd[3];
+                    HIPCHK(hipMemcpy(hd, d_dbg, sizeof hd, hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[lsf] dataflow batch of %d sweeps: %llu tiles, per tile: take+wait %.2f us, work+publish %.2f us\n", ns,
+                            hd[2], hd[2] ? hd[0] / 100.0 / hd[2] : 0.0, hd[2] ? hd[1] / 100.0 / hd[2] : 0.0);
+                }
+                if (host_ctl[0]) break;
+            }
+        }
+    }
+    const bool slots_loop = !(persist && skew && wy == 2 && wz == 2);
     auto launch_tiles = [&](int grid, hipStream_t s_) {
         if (skew) {
 #define LSF_LAUNCH_SKEW(WY_, WZ_)                                                                                          \
@@ -764,7 +868,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     int lo = 0;            // first sweep that still has hyperplanes to launch
     int epilogues = 0;     // sweeps whose last hyperplane has been launched
     bool stop = false;
-    for (long slot = 0; !stop && lo < max_sweeps; ++slot) {
+    for (long slot = 0; slots_loop && !stop && lo < max_sweeps; ++slot) {
         int nseg = 0, grid = 0;
         // timing experiment only (results are wrong): every tile of a sweep in ONE launch = the pure work term
         static const bool nodeps = getenv("LSF_GS_NODEPS_EXPERIMENT") != nullptr;
@@ -808,7 +912,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         g_prof.bc_ms = g_prof.finish_ms = 0;
         g_prof.sweeps = nsw;
         g_prof.sweep_launches = launches;
-        g_prof.kernel = skew ? "k_reinit_gs_skew" : "k_reinit_gs_flow";
+        g_prof.kernel = !slots_loop ? "k_reinit_gs_persist" : (skew ? "k_reinit_gs_skew" : "k_reinit_gs_flow");
     }
     if (fa.buf[nsw % 3] != d_phi)
         HIPCHK(hipMemcpyAsync(d_phi, fa.buf[nsw % 3], n * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -817,6 +921,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
                               hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (sweeps_done) *sweeps_done = nsw;
+    if (host_ctl[2] == 2) return fail(LSF_ERR_HIP, "exact-GS dataflow schedule timed out waiting for a tile");
     if (host_ctl[2] == 1) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, subs.f90:926)");
     return LSF_OK;
 }
@@ -1095,6 +1200,11 @@ int lsf_release_workspace(void)
     for (auto& kv : c.part_by_stream)
         if (kv.second.p) HIPCHK(hipFree(kv.second.p));
     c.part_by_stream.clear();
+    for (auto& kv : c.plans) {
+        if (kv.second.d_order) HIPCHK(hipFree(kv.second.d_order));
+        if (kv.second.d_aux) HIPCHK(hipFree(kv.second.d_aux));
+    }
+    c.plans.clear();
     for (auto* lists : {&c.tiles, &c.skew_tiles}) {
         for (auto& kv : *lists)
             if (kv.second.d) HIPCHK(hipFree(kv.second.d));

@@ -65,6 +65,14 @@ struct FlowArgs {
     int seg_g[4];       // global sweep index of each segment
     int seg_sign[4][3];
     uint32_t last_packed; // skewed tiles (lsf_skew.hpp): the tile that runs the sweep epilogue
+    // persistent schedule on skewed tiles (k_reinit_gs_persist): order[t] = {packed tile, s | P << 5}
+    int np;                 // hyperplanes per sweep
+    int* tile_done;         // [nsweeps][nM * nTj * nTk] 1 once tile (m, B, C) of the sweep is done
+    int nM;                 // row length of tile_done
+    int* plane_cnt;         // [nsweeps][np] tiles finished
+    int* planes_done;       // [nsweeps] leading hyperplanes complete; np + 1 once the epilogue has run
+    const int* plane_size;  // [np] tiles per hyperplane
+    const int* sweep_tab;   // [nsweeps][4] {sign i, sign j, sign k, spacing in hyperplanes behind sweep s - 1}
     unsigned long long* dbg; // optional phase timers (s_memrealtime ticks): wait, load, march, publish, tasks
     int knobs;          // experiment bits: 1 no acquire fence, 2 plain (non-sc1) loads, 4 long sleep, 8 plain stores
 };

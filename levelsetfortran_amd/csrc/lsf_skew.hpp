@@ -58,8 +58,13 @@ struct SkTile {
     }
 };
 
-template <int TA, int WY, int WZ, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
+// One tile.  SC1 = false: every value this tile reads was written by an earlier launch (slot schedule).
+// SC1 = true: producers may have run in this launch on another XCD (persistent schedule): results are stored
+// write-through and drained before the caller publishes the tile, phi is loaded past the non-coherent caches
+// (cdna_hip_programming.md G16).  Measured on the slot schedule: no cost (4.75 vs 4.82 ms per 512^3 sweep), whereas
+// an agent-scope acquire per tile (L2 invalidate) with plain loads made every tile 35 % slower.
+template <int TA, int WY, int WZ, bool STRICT, bool SC1>
+__device__ __forceinline__ void skew_tile(const FlowArgs& a, uint32_t packed, int g, int si, int sj, int sk)
 {
     static_assert(TA == 16, "row-per-16-lanes loader");
     using T = SkTile<TA, WY, WZ>;
@@ -74,12 +79,11 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
     const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
     const int ncol = a.nTj * a.nTk;
 
-    const int bx = (int)blockIdx.x;
-    const int seg = (bx >= a.seg_end[0]) + (bx >= a.seg_end[1]) + (bx >= a.seg_end[2]);
-    const uint32_t packed = a.seg_tiles[seg][bx - (seg ? a.seg_end[seg - 1] : 0)];
-    const int g = a.seg_g[seg];
-    const int si = a.seg_sign[seg][0], sj = a.seg_sign[seg][1], sk = a.seg_sign[seg][2];
-    if (ld_flag(a.ctl + 0) != 0) return; // converged or failed in an earlier launch
+    auto ldp = [](const double* p_) { return SC1 ? ld_sc1(p_) : *p_; };
+    auto stp = [](double* p_, double v_) {
+        if (SC1) st_sc1(p_, v_);
+        else *p_ = v_;
+    };
 
     const int m = packed & 0x3ff, fB = (packed >> 10) & 0x3ff, fC = (packed >> 20) & 0x3ff;
     const int tj = sj > 0 ? fB : a.nTj - 1 - fB, tk = sk > 0 ? fC : a.nTk - 1 - fC;
@@ -167,9 +171,9 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
             dst[n_] = T::at(r, k);
             if (r0 >= T::YU0 && r0 < T::YD0) {
                 const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 1);
-                v[n_] = (fresh ? (const double*)out_t : in_t)[o];
+                v[n_] = ldp((fresh ? (const double*)out_t : in_t) + o);
             } else {
-                v[n_] = in_t[o];
+                v[n_] = ldp(in_t + o);
             }
         }
 #pragma unroll
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
             const unsigned o = (unsigned)(e.x >> 2) + (unsigned)min(max(gi_r, 0), nx);
             const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 2) & (k < 3);
             dst[n_] = T::at(r, k);
-            v[n_] = (fresh ? (const double*)out_t : in_t)[o];
+            v[n_] = ldp((fresh ? (const double*)out_t : in_t) + o);
         }
 #pragma unroll
         for (int t = 0; t < TA / 2; ++t) ps[t] = ps_load(t);
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
         const int gi = e.y + (si > 0 ? t : -t);
         const bool mine = bq < nj && cq < nk && (unsigned)(gi - 1) <= (unsigned)(nx - 2);
         const double val0 = lds[r * RA + 3 + t];
-        if (mine) out_t[(unsigned)(e.x >> 2) + (unsigned)gi] = val0;
+        if (mine) stp(out_t + ((unsigned)(e.x >> 2) + (unsigned)gi), val0);
         if (near_wall && mine) {
             const int gj2 = j_lo + (sj > 0 ? bq : nj - 1 - bq), gk2 = k_lo + (sk > 0 ? cq : nk - 1 - cq);
             // wall points that clamp to this cell: move outward along any non-empty subset of its wall-adjacent axes
@@ -278,8 +282,8 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
                         for (int rr = 0; rr < mrep; ++rr) val = val + dx;
                     }
                     const long p = wi + sx * wj + sxy * wk;
-                    const double dlt = val - in[p];
-                    out[p] = val;
+                    const double dlt = val - ldp(in + p);
+                    stp(out + p, val);
                     acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
                 }
             }
@@ -297,14 +301,15 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
     if (tid == 0) {
         double* slot = a.colsum + (long)gb * ncol + (tj + (long)a.nTj * tk);
         const int m_lo = (NYT * fB + NZT * fC) / TA;
-        *slot = ((m == m_lo) ? 0.0 : *slot) + acc;
+        stp(slot, ((m == m_lo) ? 0.0 : ldp(slot)) + acc);
     }
+    if (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // results are at the memory side before anyone is told
     if (packed != a.last_packed) return;
     __syncthreads();
     if (wave != 0) return;
     const double* cs = a.colsum + (long)gb * ncol;
     double tsum = 0.0;
-    for (int p = lane; p < ncol; p += 64) tsum += cs[p];
+    for (int p = lane; p < ncol; p += 64) tsum += ldp(cs + p);
     tsum = wave_sum(tsum);
     if (lane == 0) {
         const double rms = __builtin_sqrt(tsum / a.den);
@@ -312,6 +317,126 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
         st_flag(a.ctl + 1, g + 1);
         if (rms < a.tol) st_flag(a.ctl + 0, 1);
         else if (rms != rms) { st_flag(a.ctl + 2, 1); st_flag(a.ctl + 0, 1); }
+    }
+}
+
+// Slot schedule: one launch per time slot, one block per tile of the slot (dependencies resolved by launch order).
+template <int TA, int WY, int WZ, bool STRICT>
+__global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
+{
+    const int bx = (int)blockIdx.x;
+    const int seg = (bx >= a.seg_end[0]) + (bx >= a.seg_end[1]) + (bx >= a.seg_end[2]);
+    const uint32_t packed = a.seg_tiles[seg][bx - (seg ? a.seg_end[seg - 1] : 0)];
+    if (ld_flag(a.ctl + 0) != 0) return; // converged or failed in an earlier launch
+    skew_tile<TA, WY, WZ, STRICT, false>(a, packed, a.seg_g[seg], a.seg_sign[seg][0], a.seg_sign[seg][1], a.seg_sign[seg][2]);
+}
+
+// Dataflow schedule: ONE launch per batch of sweeps, one block per tile.  The tiles of the batch form a list in slot
+// order (the order the slot schedule launches them in); a block takes the next entry from a ticket counter when it
+// starts (blocks are not assumed to start in index order) and waits until
+//   (a) its up to three upstream tiles of the same sweep are done                  tile_done[s][(m-1,B,C)], ...
+//   (b) sweep s-1 has completed the hyperplanes within stencil reach of this one   planes_done[s-1] >= min(P + H[s], np)
+//   (c) sweep s-3, whose result this sweep overwrites, has its stop verdict        planes_done[s-3] == np + 1
+// Every entry a block waits for precedes it in the list and was taken by a block that is running or done, so there
+// is no deadlock whatever the dispatch order or the number of resident blocks; every spin is bounded (ctl[2] = 2 on
+// time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
+// plane_cnt[s][P]; the last tile of a hyperplane publishes planes_done[s] = P + 1.
+template <int TA, int WY, int WZ, bool STRICT>
+__global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_persist(FlowArgs a)
+{
+    using T = SkTile<TA, WY, WZ>;
+    __shared__ int sh_task[8]; // packed tile, s | P << 5, go flag, raster signs of the sweep
+    const int tid = threadIdx.x;
+    const int np = a.np;
+    const int nM = a.nM;                       // tile_done[s] is indexed m + nM * (B + nTj * C)
+    const long per_sweep = (long)nM * a.nTj * a.nTk;
+    {
+        const unsigned long long tsA = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            const long t = (long)__hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int go = 0;
+            uint2 e = make_uint2(0u, 0u);
+            if (t < a.total) {
+                e = a.order[t];
+                const int s = (int)(e.y & 31u), P = (int)(e.y >> 5);
+                const int m = e.x & 0x3ff, B = (e.x >> 10) & 0x3ff, C = (e.x >> 20) & 0x3ff;
+                auto m_lo = [&](int B_, int C_) { return (T::NYT * B_ + T::NZT * C_) / TA; };
+                auto m_hi = [&](int B_, int C_) { return (T::NYT * B_ + T::NYT - 1 + T::NZT * C_ + T::NZT - 1 + a.nx - 2) / TA; };
+                const int* td = a.tile_done + s * per_sweep;
+                const int* w0 = m - 1 >= m_lo(B, C) ? td + (m - 1) + (long)nM * (B + (long)a.nTj * C) : nullptr;
+                const int* w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : nullptr;
+                const int* w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : nullptr;
+                const int* pd = a.planes_done;
+                const int need1 = s == 0 ? 0 : min(P + a.sweep_tab[4 * s + 3], np);
+                const int need3 = s < 3 ? 0 : np + 1;
+                // absent conditions point at a word that always passes (the stop flag's neighbour ctl[1] >= 0)
+                const int* always = a.ctl + 1;
+                const int* p0 = w0 ? w0 : nullptr;
+                const int* p3 = s == 0 ? always : pd + s - 1;
+                const int* p4 = s < 3 ? always : pd + s - 3;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                go = 1;
+                for (;;) {
+                    // five independent loads in flight at once, then one test
+                    const int vstop = ld_flag(a.ctl + 0);
+                    const int v0 = p0 ? ld_flag(p0) : 1, v1 = w1 ? ld_flag(w1) : 1, v2 = w2 ? ld_flag(w2) : 1;
+                    const int v3 = ld_flag(p3), v4 = ld_flag(p4);
+                    if (vstop != 0) { // converged, NaN or time-out elsewhere: skip, and let the blocks still to come leave at once
+                        go = 2;
+                        __hip_atomic_fetch_max(a.ticket, (int)a.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    const bool ok = (v0 != 0) & (v1 != 0) & (v2 != 0) & (v3 >= need1) & (v4 >= need3);
+                    if (ok) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > FLOW_TIMEOUT_TICKS) {
+                        st_flag(a.ctl + 2, 2);
+                        st_flag(a.ctl + 0, 1);
+                        go = 2;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(32);
+                }
+                sh_task[3] = a.sweep_tab[4 * s], sh_task[4] = a.sweep_tab[4 * s + 1], sh_task[5] = a.sweep_tab[4 * s + 2];
+            }
+            sh_task[0] = (int)e.x, sh_task[1] = (int)e.y, sh_task[2] = go;
+        }
+        __syncthreads();
+        // wave-uniform values: keep them in scalar registers (an LDS read alone would make them look divergent)
+        auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+        const uint32_t packed = (uint32_t)uni(sh_task[0]);
+        const int sP = uni(sh_task[1]), go = uni(sh_task[2]);
+        const int s = sP & 31, P = (int)((unsigned)sP >> 5);
+        if (go == 0) return;
+        const unsigned long long tsB = __builtin_amdgcn_s_memrealtime();
+        if (go == 1) {
+            skew_tile<TA, WY, WZ, STRICT, true>(a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads(); // every wave of the tile has drained its stores (and left the LDS image)
+        if (tid == 0 && go == 1) {
+            const int m = packed & 0x3ff, B = (packed >> 10) & 0x3ff, C = (packed >> 20) & 0x3ff;
+            st_flag(a.tile_done + s * per_sweep + m + (long)nM * (B + (long)a.nTj * C), 1);
+            const int done = __hip_atomic_fetch_add(a.plane_cnt + s * np + P, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            if (done == a.plane_size[P]) {
+                // Hyperplanes may complete out of order now; planes_done[s] counts the LEADING complete ones.  Whoever
+                // completes a hyperplane pushes the counter as far as it goes: a hyperplane completed while the counter
+                // was still behind it is picked up by the thread that moves the counter onto it (its tile count was
+                // final before that thread looks), so nothing is lost whichever of the two runs first.
+                for (;;) {
+                    int lead = ld_flag(a.planes_done + s);
+                    if (lead >= np || ld_flag(a.plane_cnt + s * np + lead) < a.plane_size[lead]) break;
+                    // the tile that completes the last hyperplane has run the sweep epilogue before counting itself
+                    __hip_atomic_compare_exchange_strong(a.planes_done + s, &lead, lead + 1 == np ? np + 1 : lead + 1,
+                                                         __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (a.dbg) {
+                const unsigned long long tsC = __builtin_amdgcn_s_memrealtime();
+                atomicAdd(a.dbg + 0, tsB - tsA);
+                atomicAdd(a.dbg + 1, tsC - tsB);
+                atomicAdd(a.dbg + 2, 1ull);
+            }
+        }
     }
 }
 

@@ -320,13 +320,16 @@ def test_reinit_alternative_tile_geometries(lsf, oracle, synth, monkeypatch, geo
     assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("waves", ["2x2", "1", "4x2"])
-def test_reinit_odd_grid_shapes(lsf, oracle, monkeypatch, waves):
+@pytest.mark.parametrize("waves,schedule", [("2x2", None), ("2x2", "skew"), ("1", None), ("4x2", None)])
+def test_reinit_odd_grid_shapes(lsf, oracle, monkeypatch, waves, schedule):
     """Grids whose extents are not multiples of the tile size (partial tiles at either end, extents below one tile,
-    two interior cells per axis): every sweep direction once, bit-identical to the oracle."""
+    two interior cells per axis): every sweep direction once, bit-identical to the oracle.  2x2 tiles run the
+    dataflow launch by default and slot launches with LSF_GS_SCHEDULE=skew; other shapes always use slot launches."""
     from levelsetfortran_amd import fields
 
     monkeypatch.setenv("LSF_GS_SKEW_W", waves)
+    if schedule:
+        monkeypatch.setenv("LSF_GS_SCHEDULE", schedule)
     for npts in ((4, 4, 4), (6, 10, 8), (18, 7, 6), (34, 13, 11), (10, 42, 14), (65, 8, 30), (23, 23, 5), (5, 5, 47)):
         phi0, dx = fields.two_sphere_phi0(npts)
         nx, ny, nz = (v - 1 for v in npts)
@@ -340,11 +343,12 @@ def test_reinit_odd_grid_shapes(lsf, oracle, monkeypatch, waves):
         assert np.allclose(rep.rms, tr_ref[:9], rtol=1e-9, atol=0), npts
 
 
-@pytest.mark.parametrize("schedule", ["planes", "slots", "flow", "skew:1", "skew:2", "skew:4", "skew:1x2", "skew:2x2", "skew:4x2", "skew:2x4"])
+@pytest.mark.parametrize("schedule", ["planes", "slots", "flow", "skew", "dataflow", "skew:1", "skew:2", "skew:4", "skew:1x2", "skew:2x2", "skew:4x2", "skew:2x4"])
 def test_reinit_alternative_schedules(lsf, synth, cube40, monkeypatch, schedule):
-    """The exact-GS tile graph has several executors (LSF_GS_SCHEDULE): slot launches on skewed tiles of WY x WZ
-    wavefronts (LSF_GS_SKEW_W; 2x2 is the default and what every other test runs), slot launches on box tiles, one
-    launch per box-tile hyperplane, and the experimental persistent dataflow kernel.  All must be bit-identical to the
+    """The exact-GS tile graph has several executors (LSF_GS_SCHEDULE): the dataflow launch on skewed 2x2-wavefront
+    tiles (one launch per batch of sweeps, dependencies resolved in the kernel; the default and what every other test
+    runs), slot launches on skewed tiles of WY x WZ wavefronts (LSF_GS_SKEW_W), slot launches on box tiles, one launch
+    per box-tile hyperplane, and the experimental persistent kernel on box tiles.  All must be bit-identical to the
     reference."""
     schedule, _, waves = schedule.partition(":")
     monkeypatch.setenv("LSF_GS_SCHEDULE", schedule)
