@@ -322,7 +322,7 @@ __device__ __forceinline__ void skew_tile(const FlowArgs& a, uint32_t packed, in
 
 // Slot schedule: one launch per time slot, one block per tile of the slot (dependencies resolved by launch order).
 template <int TA, int WY, int WZ, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY == 2 && WZ == 2 ? 5 : 1))) void k_reinit_gs_skew(FlowArgs a)
 {
     const int bx = (int)blockIdx.x;
     const int seg = (bx >= a.seg_end[0]) + (bx >= a.seg_end[1]) + (bx >= a.seg_end[2]);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_skew(FlowArgs a)
 // time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
 // plane_cnt[s][P]; the last tile of a hyperplane publishes planes_done[s] = P + 1.
 template <int TA, int WY, int WZ, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) void k_reinit_gs_persist(FlowArgs a)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(5))) void k_reinit_gs_persist(FlowArgs a)
 {
     using T = SkTile<TA, WY, WZ>;
     __shared__ int sh_task[8]; // packed tile, s | P << 5, go flag, raster signs of the sweep
