@@ -8,7 +8,7 @@ TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 for C in FETCH_SIZE WRITE_SIZE; do
   for M in gs jacobi; do
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_$M" -- python3 bench.py --steps 2 --warmup 0 --mode $M --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/pmc_${C}_$M.log"
