@@ -116,9 +116,10 @@ struct GsTile {
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    // bound_ctrl: lanes the shift leaves without a source read 0 (they are never the x lane of a cell), so the
+    // destination needs no copy of the source first
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 

@@ -226,19 +226,25 @@ __device__ __forceinline__ void skew_tile(const FlowArgs& a, uint32_t packed, in
     }
     const int fx0 = X0 - bc - cc;
     double acc = 0.0;
+    // per-lane bit t: the cell of step t exists (0 <= fx0 + t < nxi) / takes the WENO branch (3 < gi < nx - 4)
+    auto step_mask = [](int lo_t, int hi_t) { // bits lo_t .. hi_t - 1 of 16
+        lo_t = min(max(lo_t, 0), TA), hi_t = min(max(hi_t, lo_t), TA);
+        return ((1u << hi_t) - 1u) & ~((1u << lo_t) - 1u);
+    };
+    const unsigned act_bits = row_ok ? step_mask(-fx0, nxi - fx0) : 0u;
+    // 3 < gi < nx - 4 with gi = 1 + fx (si > 0: 2 < fx < nx - 5) or gi = nx - 1 - fx (si < 0: 3 < fx < nx - 4)
+    const unsigned weno_bits = yz_weno ? step_mask((si > 0 ? 3 : 4) - fx0, (si > 0 ? nx - 5 : nx - 4) - fx0) : 0u;
 
     // ---- march: TA steps, every lane busy; the wavefronts of a tile meet after every step ---------------------
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
-        const int fx = fx0 + t;
-        const bool active = row_ok && fx >= 0 && fx < nxi;
+        const bool active = (act_bits >> t) & 1u;
         double q[7];
 #pragma unroll
         for (int mm = 0; mm < 7; ++mm) q[mm] = lds[off[mm] + t];
         const double pS = ps[t & (TA / 2 - 1)];
         if (t + TA / 2 < TA) ps[t & (TA / 2 - 1)] = ps_load(t + TA / 2);
-        const int gi = si > 0 ? 1 + fx : nx - 1 - fx;
-        const bool weno_ok = yz_weno && gi > 3 && gi < nx - 4;
+        const bool weno_ok = (weno_bits >> t) & 1u;
         double dm, dp;
         axis_pair<STRICT>(q, weno_ok, yquirk, dx, floor2, dm, dp);
         const double gg = axis_godunov<STRICT>(q[3], dm, dp);
