@@ -738,7 +738,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     prof_begin();
     prof_mark(st);
     long launches = 0;
-    if (persist && skew && wy == 2 && wz == 2) {
+    if (persist && skew) {
         // Dataflow schedule (k_reinit_gs_persist): one launch per batch of up to 32 sweeps, one block per tile,
         // dependencies resolved in the kernel.  The batch plan (tiles in slot order, spacing table) depends on the grid,
         // the raster phase of the batch's first sweep and the number of sweeps only, and is cached on the device.
@@ -760,7 +760,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         }
         for (int g0 = 0; g0 < max_sweeps; g0 += BATCH) {
             const int ns = std::min(BATCH, max_sweeps - g0), phase = (first_raster + g0) & 7;
-            const std::array<int, 6> key{nx, ny, nz, phase, ns, 0x22};
+            const std::array<int, 6> key{nx, ny, nz, phase, ns, wy * 16 + wz};
             auto it = c.plans.find(key);
             if (it == c.plans.end()) {
                 BatchPlan bp;
@@ -811,8 +811,20 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             // one block per tile; a block takes its tile from the ticket counter, so the grid only has to be large enough
             // (2-D: gridDim.x * blockDim.x must stay below 2^32)
             const dim3 grid((unsigned)std::min<long>(fa.total, 65536), (unsigned)((fa.total + 65535) / 65536));
-            if (strict) hipLaunchKernelGGL((k_reinit_gs_persist<16, 2, 2, true>), grid, dim3(256), 0, st, fa);
-            else hipLaunchKernelGGL((k_reinit_gs_persist<16, 2, 2, false>), grid, dim3(256), 0, st, fa);
+#define LSF_LAUNCH_DF(WY_, WZ_)                                                                                  \
+    do {                                                                                                         \
+        if (strict) hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, true>), grid, dim3(64 * WY_ * WZ_), 0, st, fa); \
+        else hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, false>), grid, dim3(64 * WY_ * WZ_), 0, st, fa);       \
+    } while (0)
+            const int shape = wy * 16 + wz;
+            if (shape == 0x11) LSF_LAUNCH_DF(1, 1);
+            else if (shape == 0x21) LSF_LAUNCH_DF(2, 1);
+            else if (shape == 0x41) LSF_LAUNCH_DF(4, 1);
+            else if (shape == 0x12) LSF_LAUNCH_DF(1, 2);
+            else if (shape == 0x42) LSF_LAUNCH_DF(4, 2);
+            else if (shape == 0x24) LSF_LAUNCH_DF(2, 4);
+            else LSF_LAUNCH_DF(2, 2);
+#undef LSF_LAUNCH_DF
             ++launches;
             if (g0 + BATCH < max_sweeps || d_dbg) { // stop flag between batches (later batches would exit at once anyway)
                 HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
@@ -827,7 +839,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             }
         }
     }
-    const bool slots_loop = !(persist && skew && wy == 2 && wz == 2);
+    const bool slots_loop = !(persist && skew);
     auto launch_tiles = [&](int grid, hipStream_t s_) {
         if (skew) {
 #define LSF_LAUNCH_SKEW(WY_, WZ_)                                                                                          \

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
 // time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
 // plane_cnt[s][P]; the last tile of a hyperplane publishes planes_done[s] = P + 1.
 template <int TA, int WY, int WZ, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(5))) void k_reinit_gs_persist(FlowArgs a)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY == 2 && WZ == 2 ? 5 : 1))) void k_reinit_gs_persist(FlowArgs a)
 {
     using T = SkTile<TA, WY, WZ>;
     __shared__ int sh_task[8]; // packed tile, s | P << 5, go flag, raster signs of the sweep
