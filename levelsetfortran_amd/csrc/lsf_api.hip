@@ -497,8 +497,10 @@ int get_order(int nTi, int nTj, int nTk, int first_dir, int ns, TileList* tl, Or
 //   "planes"           one launch per tile hyperplane, one sweep at a time     reinit_slot_core (no overlap)
 //   "flow"             persistent dataflow kernel with flag polling (experimental: correct, but the polling
 //                      waves slow the memory system down -- measurements in DESIGN.md)  reinit_flow_core
+thread_local int g_schedule_override = -2; // set while a call is repeated on the slot schedule (see below)
 int gs_schedule()
 {
+    if (g_schedule_override != -2) return g_schedule_override;
     const char* e = getenv("LSF_GS_SCHEDULE");
     if (e && std::strcmp(e, "planes") == 0) return 0;
     if (e && std::strcmp(e, "flow") == 0) return 2;
@@ -808,6 +810,8 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             fa.plane_cnt = d_cnt, fa.planes_done = d_done, fa.ticket = d_ticket;
             fa.tile_done = (int*)c.slot[S_BFLAG].p, fa.nM = nM;
             fa.dbg = d_dbg;
+            fa.timeout_ticks = FLOW_TIMEOUT_TICKS;
+            if (const char* e = getenv("LSF_GS_TIMEOUT_TICKS")) fa.timeout_ticks = strtoull(e, nullptr, 10); // test hook
             // one block per tile; a block takes its tile from the ticket counter, so the grid only has to be large enough
             // (2-D: gridDim.x * blockDim.x must stay below 2^32)
             const dim3 grid((unsigned)std::min<long>(fa.total, 65536), (unsigned)((fa.total + 65535) / 65536));
@@ -933,7 +937,21 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
                               hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (sweeps_done) *sweeps_done = nsw;
-    if (host_ctl[2] == 2) return fail(LSF_ERR_HIP, "exact-GS dataflow schedule timed out waiting for a tile");
+    if (host_ctl[2] == 2) {
+        // A block of the dataflow launch waited 4 s for a predecessor: never observed, but the launch relies on
+        // nothing else going wrong with the device.  When the call's input is still around (phiS was copied from it
+        // on entry) repeat the call on the slot schedule, whose dependencies are launch boundaries.
+        if (!d_phiS_in && g_schedule_override == -2) {
+            fprintf(stderr, "[lsf] dataflow launch timed out; repeating the call with slot launches\n");
+            HIPCHK(hipMemcpyAsync(d_phi, c.slot[S_PHIS].p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            g_schedule_override = 3;
+            rc = reinit_slot_core(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done, rms_trace,
+                                  trace_cap, st);
+            g_schedule_override = -2;
+            return rc;
+        }
+        return fail(LSF_ERR_HIP, "exact-GS dataflow schedule timed out waiting for a tile");
+    }
     if (host_ctl[2] == 1) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, subs.f90:926)");
     return LSF_OK;
 }

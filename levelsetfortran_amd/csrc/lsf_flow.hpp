@@ -73,6 +73,7 @@ struct FlowArgs {
     int* planes_done;       // [nsweeps] leading hyperplanes complete; np + 1 once the epilogue has run
     const int* plane_size;  // [np] tiles per hyperplane
     const int* sweep_tab;   // [nsweeps][4] {sign i, sign j, sign k, spacing in hyperplanes behind sweep s - 1}
+    unsigned long long timeout_ticks; // bound of every spin of the dataflow launch (100 MHz ticks)
     unsigned long long* dbg; // optional phase timers (s_memrealtime ticks): wait, load, march, publish, tasks
     int knobs;          // experiment bits: 1 no acquire fence, 2 plain (non-sc1) loads, 4 long sleep, 8 plain stores
 };

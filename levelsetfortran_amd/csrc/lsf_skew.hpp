@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
                     }
                     const bool ok = (v0 != 0) & (v1 != 0) & (v2 != 0) & (v3 >= need1) & (v4 >= need3);
                     if (ok) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > FLOW_TIMEOUT_TICKS) {
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
                         st_flag(a.ctl + 2, 2);
                         st_flag(a.ctl + 0, 1);
                         go = 2;

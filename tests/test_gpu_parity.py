@@ -320,6 +320,17 @@ def test_reinit_alternative_tile_geometries(lsf, oracle, synth, monkeypatch, geo
     assert np.array_equal(got, ref)
 
 
+def test_dataflow_timeout_falls_back_to_slot_launches(lsf, synth, monkeypatch, capfd):
+    """Every spin of the dataflow launch is bounded; if one ever runs out the library repeats the call with slot
+    launches from the copy of the input it keeps as phiS.  A one-tick bound forces that path."""
+    monkeypatch.setenv("LSF_GS_TIMEOUT_TICKS", "1")
+    nx, ny, nz = _n(synth)
+    phi = F(synth["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, 15, float(synth["dx"]), float(synth["h"]), arith="strict")
+    assert rep.count == 16 and np.array_equal(phi, synth["phi_16"])
+    assert "repeating the call with slot launches" in capfd.readouterr().err
+
+
 @pytest.mark.parametrize("waves,schedule", [("2x2", None), ("2x2", "skew"), ("1", None), ("4x2", None)])
 def test_reinit_odd_grid_shapes(lsf, oracle, monkeypatch, waves, schedule):
     """Grids whose extents are not multiples of the tile size (partial tiles at either end, extents below one tile,
