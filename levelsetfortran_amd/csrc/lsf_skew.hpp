@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
                         go = 2;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(32);
+                    __builtin_amdgcn_s_sleep(16); // ~0.5 us between looks; 8..64 measured within 2 % of each other
                 }
                 sh_task[3] = a.sweep_tab[4 * s], sh_task[4] = a.sweep_tab[4 * s + 1], sh_task[5] = a.sweep_tab[4 * s + 2];
             }
