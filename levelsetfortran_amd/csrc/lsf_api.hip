@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <array>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -35,13 +36,19 @@ int fail(int code, const std::string& msg)
 struct Trace {
     const char* name;
     bool on;
+    std::chrono::steady_clock::time_point t0;
     explicit Trace(const char* n) : name(n), on(getenv("LSF_TRACE") != nullptr)
     {
-        if (on) fprintf(stderr, "[lsf] -> %s\n", name);
+        if (on) {
+            fprintf(stderr, "[lsf] -> %s\n", name);
+            t0 = std::chrono::steady_clock::now();
+        }
     }
     ~Trace()
     {
-        if (on) fprintf(stderr, "[lsf] <- %s\n", name);
+        if (on)
+            fprintf(stderr, "[lsf] <- %s (%.1f ms)\n", name,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
 };
 
