@@ -127,3 +127,28 @@ def test_full_size_field_equals_the_reference_itself(n):
     assert np.array_equal(got.reshape((n, n, n), order="F")[::16, ::16, ::16], g[f"n{n}_sample"])
     # the reference sums 1.3e8 squares sequentially (rounding ~ n*eps ~ 1e-8); the device sum is a tree
     assert np.allclose(rep.rms, g[f"n{n}_rms"], rtol=1e-7, atol=0)
+
+
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+def test_dataflow_launch_equals_slot_launches_over_many_sweeps(arith, monkeypatch):
+    """70 sweeps on a 300 x 250 x 200 grid (partial tiles on every axis, three batches' worth of raster phases, up to
+    three sweeps in flight): the dataflow launch (in-kernel dependencies) and the slot launches (dependencies = launch
+    boundaries) must produce the same bits, the same sweep count and the same RMS trace."""
+    import torch
+
+    import levelsetfortran_amd as lsf
+    from levelsetfortran_amd import fields
+
+    npts, sweeps = (300, 250, 200), 70
+    nx, ny, nz = (v - 1 for v in npts)
+    phi0, dx = fields.two_sphere_phi0_device(npts, "cuda")
+    h = fields.reinit_step(dx)
+    res = {}
+    for schedule in ("dataflow", "skew"):
+        monkeypatch.setenv("LSF_GS_SCHEDULE", schedule)
+        phi, ps = phi0.clone(), phi0.clone()
+        rep = lsf.reinit(phi, None, None, nx, ny, nz, sweeps - 1, dx, h, tol=0.0, order="gs", arith=arith, phiS=ps)
+        res[schedule] = (rep.count, phi.cpu().numpy(), np.array(rep.rms))
+    assert res["dataflow"][0] == res["skew"][0] == sweeps
+    assert np.array_equal(res["dataflow"][1], res["skew"][1])
+    assert np.array_equal(res["dataflow"][2], res["skew"][2])
