@@ -16,7 +16,7 @@
 
 #include "../../include/lsf.h"
 #include "lsf_kernels.hpp"
-#include "lsf_flow.hpp"
+#include "lsf_boxtile.hpp"
 #include "lsf_skew.hpp"
 
 using namespace lsf;
@@ -104,7 +104,7 @@ struct BatchPlan {
     long total = 0;
 };
 
-enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_FLAGS, S_FLOWCTL, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_NSLOTS };
+enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_PLANECNT, S_DBG, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_NSLOTS };
 
 struct Ctx {
     Buf slot[S_NSLOTS];
@@ -335,9 +335,6 @@ int gs_schedule();
 int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
                      double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace, int trace_cap,
                      hipStream_t st);
-int reinit_flow_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
-                     double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace, int trace_cap,
-                     hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx,
@@ -352,11 +349,8 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     const bool strict = (mode & LSF_ARITH_STRICT) != 0;
     if (order != LSF_ORDER_GS && order != LSF_ORDER_JACOBI) return fail(LSF_ERR_INVALID, "unknown ordering");
     if (!d_phi) return fail(LSF_ERR_INVALID, "phi is NULL");
-    if (order == LSF_ORDER_GS && gs_schedule() != 2)
-        return reinit_slot_core(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done,
-                                rms_trace, trace_cap, st);
     if (order == LSF_ORDER_GS)
-        return reinit_flow_core(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done,
+        return reinit_slot_core(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done,
                                 rms_trace, trace_cap, st);
     Ctx& c = ctx();
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
@@ -431,230 +425,30 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Exact-GS reinit as persistent dataflow launches (lsf_flow.hpp): one launch per batch of <= 8 sweeps.
-// ---------------------------------------------------------------------------------------------
-constexpr int FLOW_TA = 16;
-constexpr int FLOW_BATCH = 8;
-
-struct OrderKey {
-    int nTi, nTj, nTk, first, ns;
-    bool operator<(const OrderKey& o) const
-    {
-        return std::tie(nTi, nTj, nTk, first, ns) < std::tie(o.nTi, o.nTj, o.nTk, o.first, o.ns);
-    }
-};
-struct OrderList {
-    uint2* d = nullptr;
-    long total = 0;
-};
-std::map<std::pair<int, OrderKey>, OrderList> g_orders;
-
-// Task list of a batch: sweep s occupies time slots start[s] + P (P = tile hyperplane in its own frame); the
-// merged list sorted by slot is a topological order of the dependency graph if
-//   start[s+1] >= start[s] + (sum over flipped axes of nT-1) + 2      (tile + face neighbours of sweep s)
-//   start[s+2] >= start[s] + nPlanes + 1                              (verdict of sweep s)
-int get_order(int nTi, int nTj, int nTk, int first_dir, int ns, TileList* tl, OrderList** out)
-{
-    const OrderKey key{nTi, nTj, nTk, first_dir, ns};
-    auto it = g_orders.find({g_device, key});
-    if (it == g_orders.end()) {
-        const int np = nTi + nTj + nTk - 2;
-        const int nT[3] = {nTi, nTj, nTk};
-        std::vector<int> start(ns, 0);
-        for (int s = 1; s < ns; ++s) {
-            const int* da = RASTER_SIGN[(first_dir + s - 1) & 7];
-            const int* db = RASTER_SIGN[(first_dir + s) & 7];
-            int H = 2;
-            for (int ax = 0; ax < 3; ++ax)
-                if (da[ax] != db[ax]) H += nT[ax] - 1;
-            start[s] = start[s - 1] + H;
-            if (s >= 2) start[s] = std::max(start[s], start[s - 2] + np + 1);
-        }
-        // download the plane-sorted frame tile list once
-        std::vector<uint32_t> tiles((size_t)tl->off.back());
-        HIPCHK(hipMemcpy(tiles.data(), tl->d, tiles.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        std::vector<uint2> h;
-        h.reserve(tiles.size() * (size_t)ns);
-        const int last_slot = start[ns - 1] + np;
-        for (int slot = 0; slot < last_slot; ++slot)
-            for (int s = 0; s < ns; ++s) {
-                const int P = slot - start[s];
-                if (P < 0 || P >= np) continue;
-                for (int q = tl->off[P]; q < tl->off[P + 1]; ++q) h.push_back(make_uint2(tiles[q], (unsigned)s));
-            }
-        OrderList ol;
-        ol.total = (long)h.size();
-        HIPCHK(hipMalloc((void**)&ol.d, h.size() * sizeof(uint2)));
-        HIPCHK(hipMemcpy(ol.d, h.data(), h.size() * sizeof(uint2), hipMemcpyHostToDevice));
-        // keep at most a handful of lists alive (each is 8 bytes per tile per sweep)
-        if (g_orders.size() > 12) {
-            for (auto& kv : g_orders)
-                if (kv.second.d) (void)hipFree(kv.second.d);
-            g_orders.clear();
-        }
-        it = g_orders.emplace(std::make_pair(g_device, key), ol).first;
-    }
-    *out = &it->second;
-    return LSF_OK;
-}
-
-// LSF_GS_SCHEDULE selects how the exact Gauss-Seidel tile graph is executed (all three are bit-identical):
-//   "slots"  (default) overlapped sweeps, one launch per time slot            reinit_slot_core
-//   "planes"           one launch per tile hyperplane, one sweep at a time     reinit_slot_core (no overlap)
-//   "flow"             persistent dataflow kernel with flag polling (experimental: correct, but the polling
-//                      waves slow the memory system down -- measurements in DESIGN.md)  reinit_flow_core
+// LSF_GS_SCHEDULE selects how the exact Gauss-Seidel tile graph is executed (all are bit-identical):
+//   "dataflow" (default) skewed tiles, one launch per batch of sweeps, dependencies resolved in the kernel
+//   "skew"               skewed tiles, one launch per time slot (also the fallback of a dataflow launch that timed out)
+//   "slots"              box tiles, overlapped sweeps, one launch per time slot
+//   "planes"             box tiles, one launch per tile hyperplane, one sweep at a time
 thread_local int g_schedule_override = -2; // set while a call is repeated on the slot schedule (see below)
 int gs_schedule()
 {
     if (g_schedule_override != -2) return g_schedule_override;
     const char* e = getenv("LSF_GS_SCHEDULE");
     if (e && std::strcmp(e, "planes") == 0) return 0;
-    if (e && std::strcmp(e, "flow") == 0) return 2;
     if (e && std::strcmp(e, "skew") == 0) return 3;
     if (e && std::strcmp(e, "slots") == 0) return 1;
     if (e && std::strcmp(e, "dataflow") == 0) return 5;
     return -1; // unset: dataflow on skewed tiles
 }
 
-int reinit_flow_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
-                     double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace, int trace_cap,
-                     hipStream_t st)
-{
-    int rc = check_dims(nx, ny, nz);
-    if (rc) return rc;
-    if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
-    if (first_raster < 0 || first_raster > 7) return fail(LSF_ERR_INVALID, "first_raster must be 0..7");
-    if (!d_phi) return fail(LSF_ERR_INVALID, "phi is NULL");
-    const bool strict = (mode & LSF_ARITH_STRICT) != 0;
-    Ctx& c = ctx();
-    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
-    const int max_sweeps = iter + 1;
-    if ((rc = ws(c.slot[S_PONG], n * sizeof(double)))) return rc;
-    const double* d_phiS = d_phiS_in;
-    if (!d_phiS) {
-        if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
-        HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        d_phiS = (const double*)c.slot[S_PHIS].p;
-    }
-    const int nTi = cdiv(nx - 1, FLOW_TA), nTj = cdiv(ny - 1, 4), nTk = cdiv(nz - 1, 4);
-    const long nTiles = (long)nTi * nTj * nTk;
-    TileList* tl = nullptr;
-    if ((rc = get_tiles(nTi, nTj, nTk, &tl))) return rc;
-    if ((rc = ws(c.slot[S_CTL], 64))) return rc;
-    if ((rc = ws(c.slot[S_TRACE], (size_t)max_sweeps * sizeof(double)))) return rc;
-    if ((rc = ws(c.slot[S_FLAGS], (size_t)nTiles * sizeof(int)))) return rc;
-    if ((rc = ws(c.slot[S_FLOWCTL], 256))) return rc;
-    if ((rc = ws(c.slot[S_COLSUM], (size_t)2 * nTj * nTk * sizeof(double)))) return rc;
-    int* ctl = (int*)c.slot[S_CTL].p;
-    int* fctl = (int*)c.slot[S_FLOWCTL].p; // [0] ticket, [1] verdict, [8..15] tiles_done
-    HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
-    HIPCHK(hipMemsetAsync(fctl, 0, 256, st));
-    HIPCHK(hipMemsetAsync(c.slot[S_FLAGS].p, 0, (size_t)nTiles * sizeof(int), st));
-    // the pong buffer must carry valid wall points for the first sweep's loader never to read garbage that it
-    // then consumes: it does not consume them (walls always come from the input buffer), nothing to do.
-
-    int host_ctl[4] = {0, 0, 0, 0};
-    prof_begin();
-    hipDeviceProp_t pr;
-    HIPCHK(hipGetDeviceProperties(&pr, g_device));
-    const char* bpc = getenv("LSF_FLOW_BLOCKS_PER_CU");
-    const int resident = pr.multiProcessorCount * (bpc ? atoi(bpc) : 12);
-    for (int g0 = 0; g0 < max_sweeps; g0 += FLOW_BATCH) {
-        const int ns = std::min(FLOW_BATCH, max_sweeps - g0);
-        const int first_dir = (first_raster + g0) & 7;
-        OrderList* ol = nullptr;
-        if ((rc = get_order(nTi, nTj, nTk, first_dir, ns, tl, &ol))) return rc;
-        FlowArgs fa;
-        fa.buf[0] = d_phi;
-        fa.buf[1] = (double*)c.slot[S_PONG].p;
-        fa.nbuf = 2;
-        fa.phiS = d_phiS;
-        fa.nx = nx, fa.ny = ny, fa.nz = nz, fa.nTi = nTi, fa.nTj = nTj, fa.nTk = nTk;
-        fa.dx = dx, fa.h = h;
-        fa.order = ol->d;
-        fa.total = ol->total;
-        fa.nsweeps = ns;
-        fa.g0 = g0;
-        for (int s = 0; s < 8; ++s)
-            for (int ax = 0; ax < 3; ++ax) fa.sign[s][ax] = RASTER_SIGN[(first_dir + s) & 7][ax];
-        fa.flags = (int*)c.slot[S_FLAGS].p;
-        fa.ticket = fctl;
-        fa.verdict = fctl + 1;
-        fa.tiles_done = fctl + 8;
-        fa.colsum = (double*)c.slot[S_COLSUM].p;
-        fa.trace = (double*)c.slot[S_TRACE].p;
-        fa.trace_cap = max_sweeps;
-        fa.den = rms_denominator(nx, ny, nz);
-        fa.tol = tol;
-        fa.ctl = ctl;
-        fa.nTiles = nTiles;
-        {
-            const char* kb = getenv("LSF_FLOW_KNOBS");
-            fa.knobs = kb ? atoi(kb) : 0;
-            fa.dbg = nullptr;
-            if (getenv("LSF_FLOW_DEBUG")) {
-                fa.dbg = (unsigned long long*)(fctl + 32);
-                HIPCHK(hipMemsetAsync(fctl + 32, 0, 64, st));
-            }
-        }
-        // per batch: ticket and per-sweep tile counters restart, flags/verdict keep counting
-        HIPCHK(hipMemsetAsync(fctl, 0, 4, st));
-        HIPCHK(hipMemsetAsync(fctl + 8, 0, 32, st));
-        const unsigned grid = (unsigned)std::min<long>(ol->total, resident);
-        prof_mark(st);
-        if (strict)
-            hipLaunchKernelGGL((k_reinit_gs_flow<FLOW_TA, 4, true, false>), dim3(grid), dim3(64), 0, st, fa);
-        else
-            hipLaunchKernelGGL((k_reinit_gs_flow<FLOW_TA, 4, false, false>), dim3(grid), dim3(64), 0, st, fa);
-        prof_mark(st);
-        prof_mark(st);
-        prof_mark(st);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (getenv("LSF_FLOW_DEBUG")) {
-            unsigned long long d[5];
-            HIPCHK(hipMemcpy(d, fctl + 32, sizeof d, hipMemcpyDeviceToHost));
-            const double k = d[4] ? 1e-2 / (double)d[4] : 0; // ticks of 10 ns -> us per task
-            fprintf(stderr, "[flow] tasks %llu  per task (us): wait %.2f  acquire+load %.2f  march %.2f  store+publish %.2f\n",
-                    d[4], d[0] * k, d[1] * k, d[2] * k, d[3] * k);
-        }
-        if (host_ctl[0]) break;
-    }
-    const int nsw = host_ctl[1];
-    // the profile brackets whole batches: spread the time over the sweeps of the call
-    if (g_prof.on) {
-        double ms = 0;
-        for (size_t b = 0; b + 3 < g_prof.ev.size(); b += 4) {
-            float a = 0;
-            (void)hipEventElapsedTime(&a, g_prof.ev[b], g_prof.ev[b + 1]);
-            ms += a;
-        }
-        g_prof.sweep_ms = ms;
-        g_prof.bc_ms = g_prof.finish_ms = 0;
-        g_prof.sweeps = nsw;
-        g_prof.sweep_launches = (long)(g_prof.ev.size() / 4);
-    }
-    double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
-    if (bufs[nsw & 1] != d_phi)
-        HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (rms_trace && trace_cap > 0 && nsw > 0)
-        HIPCHK(hipMemcpyAsync(rms_trace, c.slot[S_TRACE].p, sizeof(double) * (size_t)std::min(nsw, trace_cap),
-                              hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (sweeps_done) *sweeps_done = nsw;
-    if (host_ctl[2] == 2) return fail(LSF_ERR_HIP, "dataflow kernel timed out waiting for a predecessor tile");
-    if (host_ctl[2] == 1) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, subs.f90:926)");
-    return LSF_OK;
-}
-
 // ---------------------------------------------------------------------------------------------
-// Exact-GS reinit, slot-synchronous schedule with overlapped sweeps (default).
-// One launch per time slot; a slot holds the tile hyperplane P = slot - start[g] of every sweep g in flight
-// (at most two).  start[] obeys the two spacing rules of get_order(), so every predecessor of a task ran in
-// an earlier launch.  Compared with one launch per hyperplane of one sweep this halves the number of
-// dependent launches per sweep and fuses the BC, the wall mirror and the RMS epilogue into the tile kernel.
+// Exact-GS reinit: the dataflow launch (default) and the slot-synchronous schedules with overlapped sweeps.
+// Slot schedules: one launch per time slot; a slot holds the tile hyperplane P = slot - start[g] of every sweep g in
+// flight (at most three).  start[] obeys two spacing rules -- start[g] >= start[g-1] + H(raster flip) so that a tile's
+// neighbours finished the sweep before, and start[g] >= start[g-3] + nPlanes + 1 so that the stop verdict of the sweep
+// whose buffer is overwritten is known -- hence every predecessor of a task ran in an earlier launch.  The BC, the
+// wall mirror and the RMS epilogue are fused into the tile kernel.
 // ---------------------------------------------------------------------------------------------
 int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
                      double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace, int trace_cap,
@@ -679,7 +473,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     int sched = gs_schedule();
     // Default: skewed tiles (lsf_skew.hpp), 2 x 2 wavefronts each, dependencies resolved in the kernel (`dataflow`,
     // one launch per batch of sweeps).  Measured per sweep: dataflow / slot launches on skewed tiles (`skew`) / slot
-    // launches on the box tiles of lsf_flow.hpp (`slots`): 256^3 0.97 / 1.24 / 1.75 ms, 512^3 3.25 / 4.61 / 6.83 ms,
+    // launches on the box tiles of lsf_boxtile.hpp (`slots`): 256^3 0.97 / 1.24 / 1.75 ms, 512^3 3.25 / 4.61 / 6.83 ms,
     // 1024^3 24.7 / 25.2 / 38.0 ms.
     if (sched < 0) sched = 5;
     const bool persist = sched == 5; // k_reinit_gs_persist
@@ -707,7 +501,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
 
     // Three field buffers in rotation: sweep g overwrites the result of sweep g-3, so it has to wait for the
     // stop verdict of sweep g-3 only, and consecutive sweeps are spaced by the raster-flip rule alone.
-    FlowArgs fa;
+    GsArgs fa;
     std::memset(&fa, 0, sizeof fa);
     fa.buf[0] = d_phi;
     fa.buf[1] = (double*)c.slot[S_PONG].p;
@@ -757,15 +551,15 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         const int BATCH = (int)std::max<long>(8, std::min<long>(32, (256L << 20) / (ntiles * 8) / 8 * 8));
         const int nM = (nx - 2 + nyc * nTj - 1 + nzc * nTk - 1) / ta + 1; // m_max + 1 (get_skew_tiles)
         const size_t tile_flags = (size_t)BATCH * nM * nTj * nTk;
-        if ((rc = ws(c.slot[S_FLAGS], ((size_t)BATCH * np + BATCH + 16) * sizeof(int)))) return rc;
+        if ((rc = ws(c.slot[S_PLANECNT], ((size_t)BATCH * np + BATCH + 16) * sizeof(int)))) return rc;
         if ((rc = ws(c.slot[S_BFLAG], tile_flags * sizeof(int)))) return rc;
-        int* d_cnt = (int*)c.slot[S_FLAGS].p;
+        int* d_cnt = (int*)c.slot[S_PLANECNT].p;
         int* d_done = d_cnt + (size_t)BATCH * np;
         int* d_ticket = d_done + BATCH;
         unsigned long long* d_dbg = nullptr;
         if (getenv("LSF_TRACE")) {
-            if ((rc = ws(c.slot[S_FLOWCTL], 64))) return rc;
-            d_dbg = (unsigned long long*)c.slot[S_FLOWCTL].p;
+            if ((rc = ws(c.slot[S_DBG], 64))) return rc;
+            d_dbg = (unsigned long long*)c.slot[S_DBG].p;
         }
         for (int g0 = 0; g0 < max_sweeps; g0 += BATCH) {
             const int ns = std::min(BATCH, max_sweeps - g0), phase = (first_raster + g0) & 7;
@@ -872,7 +666,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             return;
         }
 #define LSF_LAUNCH_SLOT(TA_, NY_, ST_) \
-    hipLaunchKernelGGL((k_reinit_gs_flow<TA_, NY_, ST_, true>), dim3(grid), dim3(64), 0, s_, fa)
+    hipLaunchKernelGGL((k_reinit_gs_box<TA_, NY_, ST_>), dim3(grid), dim3(64), 0, s_, fa)
 #define LSF_LAUNCH_SLOT_NY(TA_, ST_)           \
     do {                                       \
         if (nyc == 5) LSF_LAUNCH_SLOT(TA_, 5, ST_); \
@@ -935,7 +729,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         g_prof.bc_ms = g_prof.finish_ms = 0;
         g_prof.sweeps = nsw;
         g_prof.sweep_launches = launches;
-        g_prof.kernel = !slots_loop ? "k_reinit_gs_persist" : (skew ? "k_reinit_gs_skew" : "k_reinit_gs_flow");
+        g_prof.kernel = !slots_loop ? "k_reinit_gs_persist" : (skew ? "k_reinit_gs_skew" : "k_reinit_gs_box");
     }
     if (fa.buf[nsw % 3] != d_phi)
         HIPCHK(hipMemcpyAsync(d_phi, fa.buf[nsw % 3], n * sizeof(double), hipMemcpyDeviceToDevice, st));

@@ -1,6 +1,6 @@
 // lsf_skew.hpp -- exact Gauss-Seidel reinit on SKEWED tiles (slot-synchronous schedule).
 //
-// The box tiles of lsf_flow.hpp (TA x NY x 4 cells, marched by in-tile hyperplanes a + b + c = step) keep only
+// The box tiles of lsf_boxtile.hpp (TA x NY x 4 cells, marched by in-tile hyperplanes a + b + c = step) keep only
 // TA / (TA + NY + 2) = 70 % of their lanes busy: the first and last steps of every tile are a ramp.  Here the ramp
 // is cut off: a tile is the set of cells of one (NY x 4) row bundle whose SKEW coordinate
 //     s = Fx + Fy + Fz        (F = cell index counted along the sweep direction, "frame" coordinates)
@@ -20,7 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "lsf_flow.hpp"
+#include "lsf_boxtile.hpp"
 
 namespace lsf {
 
@@ -64,7 +64,7 @@ struct SkTile {
 // (cdna_hip_programming.md G16).  Measured on the slot schedule: no cost (4.75 vs 4.82 ms per 512^3 sweep), whereas
 // an agent-scope acquire per tile (L2 invalidate) with plain loads made every tile 35 % slower.
 template <int TA, int WY, int WZ, bool STRICT, bool SC1>
-__device__ __forceinline__ void skew_tile(const FlowArgs& a, uint32_t packed, int g, int si, int sj, int sk)
+__device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int g, int si, int sj, int sk)
 {
     static_assert(TA == 16, "row-per-16-lanes loader");
     using T = SkTile<TA, WY, WZ>;
@@ -328,7 +328,7 @@ __device__ __forceinline__ void skew_tile(const FlowArgs& a, uint32_t packed, in
 
 // Slot schedule: one launch per time slot, one block per tile of the slot (dependencies resolved by launch order).
 template <int TA, int WY, int WZ, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY == 2 && WZ == 2 ? 5 : 1))) void k_reinit_gs_skew(FlowArgs a)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY == 2 && WZ == 2 ? 5 : 1))) void k_reinit_gs_skew(GsArgs a)
 {
     const int bx = (int)blockIdx.x;
     const int seg = (bx >= a.seg_end[0]) + (bx >= a.seg_end[1]) + (bx >= a.seg_end[2]);
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
 // time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
 // plane_cnt[s][P]; the last tile of a hyperplane publishes planes_done[s] = P + 1.
 template <int TA, int WY, int WZ, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY == 2 && WZ == 2 ? 5 : 1))) void k_reinit_gs_persist(FlowArgs a)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY == 2 && WZ == 2 ? 5 : 1))) void k_reinit_gs_persist(GsArgs a)
 {
     using T = SkTile<TA, WY, WZ>;
     __shared__ int sh_task[8]; // packed tile, s | P << 5, go flag, raster signs of the sweep

@@ -34,15 +34,15 @@ res = {"unit": "bytes per sweep", "N": 512, "note": "sum over the sweep-kernel d
        "(rocprofv3 FETCH_SIZE/WRITE_SIZE); fetch_corrected = 2 x fetch_raw (gfx950 wide-read correction, upper bound)"}
 traffic = {}
 def gs_kernel_name():
-    # the exact ordering launches k_reinit_gs_persist (dataflow, default), k_reinit_gs_skew or k_reinit_gs_flow (slots)
+    # the exact ordering launches k_reinit_gs_persist (dataflow, default), k_reinit_gs_skew or k_reinit_gs_box (slots)
     f = one("pmc_FETCH_SIZE_gs/**/*counter_collection.csv")
     if f:
         for r in csv.DictReader(open(f)):
             if "k_reinit_gs_" in r["Kernel_Name"]:
-                for name in ("k_reinit_gs_persist", "k_reinit_gs_skew", "k_reinit_gs_flow"):
+                for name in ("k_reinit_gs_persist", "k_reinit_gs_skew", "k_reinit_gs_box"):
                     if name in r["Kernel_Name"]:
                         return name
-    return "k_reinit_gs_flow"
+    return "k_reinit_gs_box"
 
 
 for mode, kern in (("gs", gs_kernel_name()), ("jacobi", "k_reinit_jacobi")):

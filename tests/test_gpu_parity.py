@@ -354,7 +354,7 @@ def test_reinit_odd_grid_shapes(lsf, oracle, monkeypatch, waves, schedule):
         assert np.allclose(rep.rms, tr_ref[:9], rtol=1e-9, atol=0), npts
 
 
-@pytest.mark.parametrize("schedule", ["planes", "slots", "flow", "skew", "dataflow", "dataflow:1", "dataflow:4x2", "skew:1", "skew:2", "skew:4", "skew:1x2", "skew:2x2", "skew:4x2", "skew:2x4"])
+@pytest.mark.parametrize("schedule", ["planes", "slots", "skew", "dataflow", "dataflow:1", "dataflow:4x2", "skew:1", "skew:2", "skew:4", "skew:1x2", "skew:2x2", "skew:4x2", "skew:2x4"])
 def test_reinit_alternative_schedules(lsf, synth, cube40, monkeypatch, schedule):
     """The exact-GS tile graph has several executors (LSF_GS_SCHEDULE): the dataflow launch on skewed 2x2-wavefront
     tiles (one launch per batch of sweeps, dependencies resolved in the kernel; the default and what every other test
