@@ -11,7 +11,10 @@ reference to the last bit (STRICT arithmetic) / to ~1e-16 (FAST arithmetic, used
 double-buffered Jacobi ordering (does not reproduce the reference field; shards across GPUs) is
 measured in the same run and reported under "jacobi".
 
-    python bench.py --gpus N --steps K --warmup W [--mode gs|jacobi] [--size 512]
+    python bench.py --gpus N --steps K --warmup W [--mode gs|jacobi] [--size 512] [--dtype f64|f32]
+
+--dtype f32 (BASELINE configuration 5; Jacobi ordering only, 12 B per cell-update) is a secondary measurement:
+the headline line is the default fp64 run.
 
 N > 1 is launched by torch.distributed.run, one rank per GPU:
   mode gs      exact ordering does not shard: N independent replicas, weak scaling
@@ -35,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6  # vendor vector fp64 (FMA counted as 2)
+FP32_VALU_PEAK_TFLOPS = 157.3  # vendor vector fp32 (packed FMA counted as 4 per lane-issue)
 BYTES_PER_CELL_UPDATE = 24.0  # read phi, read phiS, write phi
 
 
@@ -129,6 +133,8 @@ def main() -> None:
     ap.add_argument("--mode", choices=("gs", "jacobi"), default="gs")
     ap.add_argument("--arith", choices=("fast", "strict"), default="fast")
     ap.add_argument("--size", type=int, default=512, help="points per axis (per GPU)")
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
+                    help="f32 = single-precision Jacobi path (BASELINE configuration 5); implies --mode jacobi")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary-ordering measurement")
     ap.add_argument("--with-decomposed", action="store_true",
@@ -141,6 +147,10 @@ def main() -> None:
     if args.cpu_worker:
         _cpu_worker(args.cpu_worker, args.size, args.cpu_slab, args.cpu_sweeps)
         return
+    f32 = args.dtype == "f32"
+    if f32:
+        args.mode, args.no_secondary, args.no_cpu_baseline = "jacobi", True, True
+    bytes_per_cell = 12.0 if f32 else BYTES_PER_CELL_UPDATE  # read phi, read phiS, write phi
 
     import numpy as np
     import torch
@@ -174,7 +184,7 @@ def main() -> None:
     if args.mode == "jacobi" and world > 1:
         from levelsetfortran_amd import distributed as lsd
 
-        res = lsd.bench_weak_scaling(N, K, W, dev, arith=args.arith)
+        res = lsd.bench_weak_scaling(N, K, W, dev, arith=args.arith, dtype=args.dtype)
         cells_total, seconds, prof, parallelism = res["cells_total"], res["seconds"], res["prof"], res["parallelism"]
         order = "jacobi"
     else:
@@ -187,6 +197,8 @@ def main() -> None:
             phi0 = torch.from_numpy(phi0_np.reshape(-1, order="F")).to(dev)
             del phi0_np
         h = fields.reinit_step(dx)
+        if f32:
+            phi0 = phi0.to(torch.float32)
         phiS = phi0.clone()
         phi = phi0.clone()
 
@@ -238,7 +250,7 @@ def main() -> None:
             return None
         kernel = prof_["kernel"]  # the exact ordering picks box or skewed tiles by grid size
         per_sweep_s = prof_["sweep_ms"] * 1e-3 / prof_["sweeps"]
-        ach = cells_per_sweep * BYTES_PER_CELL_UPDATE / per_sweep_s / 1e9
+        ach = cells_per_sweep * bytes_per_cell / per_sweep_s / 1e9
         lps = prof_["launches"] / prof_["sweeps"]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -251,16 +263,16 @@ def main() -> None:
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic / lps if traffic else None, "kernel": kernel, "launches_per_sweep": lps,
             "avg_launch_us": per_sweep_s / lps * 1e6,
-            "algorithmic_bytes_per_launch": cells_per_sweep * BYTES_PER_CELL_UPDATE / lps,
-            "traffic_per_sweep": traffic, "algorithmic_bytes_per_sweep": cells_per_sweep * BYTES_PER_CELL_UPDATE,
-            "note": "achieved = 24 B x (N-2)^3 cells / HIP-event time of the sweep kernel launch(es) of one sweep; "
+            "algorithmic_bytes_per_launch": cells_per_sweep * bytes_per_cell / lps,
+            "traffic_per_sweep": traffic, "algorithmic_bytes_per_sweep": cells_per_sweep * bytes_per_cell,
+            "note": f"achieved = {bytes_per_cell:.0f} B x (N-2)^3 cells / HIP-event time of the sweep kernel launch(es) of one sweep; "
                     "traffic = measured HBM bytes per launch (per sweep / launches per sweep) from the rocprofv3 PMC "
                     "passes summarised in profiles/, null if not collected for this size",
         }
 
     per_gpu_cells_per_sweep = cells_total / K / world
     out = {
-        "metric": f"cell-updates/s (WENO5 reinit, {N}^3 fp64)",
+        "metric": f"cell-updates/s (WENO5 reinit, {N}^3 {'fp32' if f32 else 'fp64'})",
         "value": cells_total / seconds,
         "unit": "cell-updates/s",
         "n_gpus": world,
@@ -270,10 +282,10 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": args.dtype,
         "data": "synthetic",
         "config": {
-            "workload": f"WENO5 HJ reinit sweep (weno+Godunov+Euler, BC, RMS), {N}^3 fp64 per GPU, synthetic two-sphere "
+            "workload": f"WENO5 HJ reinit sweep (weno+Godunov+Euler, BC, RMS), {N}^3 {'fp32' if f32 else 'fp64'} per GPU, synthetic two-sphere "
                         f"phi0 (SURVEY.md 8d), HBM-resident",
             "grid": [N, N, N],
             "ordering": "exact Gauss-Seidel raster order of the reference (tiled hyperplane wavefront)" if order == "gs"
@@ -285,13 +297,18 @@ def main() -> None:
     }
     if prof:
         out["step_breakdown_ms"] = {k: prof[k] / max(prof["sweeps"], 1) for k in ("sweep_ms", "bc_ms", "finish_ms")}
-    out["roofline_fp64_valu"] = {
-        "bound": "fp64-valu", "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "note": "the update is ~505 fp64 flop/cell as written in subs.f90 (SURVEY.md 8d): at 24 B/cell the fp64 vector "
-                "unit, not HBM, is the first bound; achieved = 505 x value",
+    out["roofline_fp32_valu" if f32 else "roofline_fp64_valu"] = {
+        "bound": "fp32-valu (packed)" if f32 else "fp64-valu", "peak": FP32_VALU_PEAK_TFLOPS if f32 else FP64_VALU_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "note": ("the update is ~505 flop/cell as written in subs.f90 (SURVEY.md 8d): at 12 B/cell the vector unit, not "
+                 "HBM, is the first bound; achieved = 505 x value; the peak needs every instruction to be a packed FMA")
+                if f32 else
+                ("the update is ~505 fp64 flop/cell as written in subs.f90 (SURVEY.md 8d): at 24 B/cell the fp64 vector "
+                 "unit, not HBM, is the first bound; achieved = 505 x value"),
         "achieved": 505.0 * (cells_total / seconds) / world / 1e12,
     }
-    out["roofline_fp64_valu"]["frac"] = out["roofline_fp64_valu"]["achieved"] / FP64_VALU_PEAK_TFLOPS
+    vkey = "roofline_fp32_valu" if f32 else "roofline_fp64_valu"
+    out[vkey]["frac"] = out[vkey]["achieved"] / out[vkey]["peak"]
 
     if world == 1 and not args.no_secondary and not (args.mode == "jacobi" and world > 1):
         other = "jacobi" if order == "gs" else "gs"

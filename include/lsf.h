@@ -176,6 +176,32 @@ int lsf_pack_box(const double *d_field, const lsf_box *box, const int lo[3], con
 int lsf_unpack_box(double *d_field, const lsf_box *box, const int lo[3], const int hi[3],
                    const double *d_buf, void *stream);
 
+/* ---- single precision (BASELINE.json configuration 5: 1536^3 fp32 on 2x2x2 GPUs) -------------------
+ * The reference is fp64 only (Makefile:4, -fdefault-real-8): there is no fp32 field to be identical to,
+ * so these entry points exist for the Jacobi ordering and the FAST arithmetic only (mode must be
+ * LSF_ORDER_JACOBI | LSF_ARITH_FAST, anything else is LSF_ERR_INVALID).  Same update as subs.f90:743-852 with
+ * weno :489-711 and phiSign :152-172; the epsilon floor 1e-99 of subs.f90:533-534, which fp32 cannot hold,
+ * becomes 1e-30 (in the unscaled units of the FAST algebra) and the three non-linear weights of a WENO side
+ * are formed from q_k / (q_0+q_1+q_2) so that their products stay inside the fp32 range.  Fields are
+ * `float` with the layout of the fp64 entry points; dx, h, tol and the RMS trace stay double (the RMS is
+ * accumulated in double from fp32 differences).  Checked against the fp64 path within the tolerance
+ * stated in tests/test_gpu_f32.py. */
+int lsf_reinit_f32(float *phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,
+                   int *sweeps_done, double *rms_trace, int trace_cap);
+int lsf_reinit_f32_device(float *d_phi, const float *d_phiS, int nx, int ny, int nz, int iter, double dx,
+                          double h, double tol, int mode, int *sweeps_done, double *rms_trace, int trace_cap,
+                          void *stream);
+/* fp32 twins of the block-decomposed building blocks above (same contracts) */
+int lsf_jacobi_sweep_box_f32(const float *d_in, float *d_out, const float *d_phiS, const lsf_box *box,
+                             const int lo[3], const int hi[3], double dx, double h, int mode,
+                             double *d_sumsq, void *stream);
+int lsf_bc_box_f32(const float *d_in, float *d_out, const lsf_box *box, const int lo[3], const int hi[3],
+                   double dx, double *d_sumsq, void *stream);
+int lsf_pack_box_f32(const float *d_field, const lsf_box *box, const int lo[3], const int hi[3],
+                     float *d_buf, void *stream);
+int lsf_unpack_box_f32(float *d_field, const lsf_box *box, const int lo[3], const int hi[3],
+                       const float *d_buf, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,16 @@ SIGNATURES = {
                            c_void_p]),
     "lsf_pack_box": (c_int, [c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_void_p, c_void_p]),
     "lsf_unpack_box": (c_int, [c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_void_p, c_void_p]),
+    "lsf_reinit_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_int,
+                               POINTER(c_int), c_void_p, c_int]),
+    "lsf_reinit_f32_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
+                                      c_int, POINTER(c_int), c_void_p, c_int, c_void_p]),
+    "lsf_jacobi_sweep_box_f32": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3,
+                                         c_double, c_double, c_int, c_void_p, c_void_p]),
+    "lsf_bc_box_f32": (c_int, [c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_double, c_void_p,
+                               c_void_p]),
+    "lsf_pack_box_f32": (c_int, [c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_void_p, c_void_p]),
+    "lsf_unpack_box_f32": (c_int, [c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_void_p, c_void_p]),
 }
 
 _lib = None

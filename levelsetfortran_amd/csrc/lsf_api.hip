@@ -18,6 +18,7 @@
 #include "lsf_kernels.hpp"
 #include "lsf_boxtile.hpp"
 #include "lsf_skew.hpp"
+#include "lsf_f32.hpp"
 
 using namespace lsf;
 
@@ -395,7 +396,7 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
             hipLaunchKernelGGL((k_reinit_jacobi<false>), jgrid, dim3(JAC_BX, JAC_BY), 0, st, A, B, d_phiS, bx, 1, 1, 1,
                                nx, ny, nz, dx, h, part, ctl);
         prof_mark(st);
-        hipLaunchKernelGGL(k_bc, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, dx,
+        hipLaunchKernelGGL(k_bc<double>, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, dx,
                            part + n_sweep_part, ctl);
         prof_mark(st);
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
@@ -424,6 +425,80 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     return LSF_OK;
 }
 
+
+// fp32 Jacobi reinit (BASELINE configuration 5).  Same loop as the Jacobi branch of reinit_core; the RMS is
+// accumulated in double from fp32 differences.
+int reinit_f32_core(float* d_phi, const float* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
+                    double tol, int* sweeps_done, double* rms_trace, int trace_cap, hipStream_t st)
+{
+    int rc = check_dims(nx, ny, nz);
+    if (rc) return rc;
+    if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
+    if (!d_phi) return fail(LSF_ERR_INVALID, "phi is NULL");
+    Ctx& c = ctx();
+    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    const int max_sweeps = iter + 1;
+    if ((rc = ws(c.slot[S_PONG], n * sizeof(float)))) return rc;
+    const float* d_phiS = d_phiS_in;
+    if (!d_phiS) {
+        if ((rc = ws(c.slot[S_PHIS], n * sizeof(float)))) return rc;
+        HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        d_phiS = (const float*)c.slot[S_PHIS].p;
+    }
+    if ((rc = ws(c.slot[S_CTL], 64))) return rc;
+    if ((rc = ws(c.slot[S_TRACE], (size_t)max_sweeps * sizeof(double)))) return rc;
+    int* ctl = (int*)c.slot[S_CTL].p;
+    double* d_trace = (double*)c.slot[S_TRACE].p;
+    HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
+
+    const dim3 jgrid(cdiv(nx - 1, F32_BX), cdiv(cdiv(ny - 1, 2), F32_BY), cdiv(nz - 1, F32_KC));
+    const long n_sweep_part = (long)jgrid.x * jgrid.y * jgrid.z;
+    const dim3 bgrid = bc_grid(nx + 1, ny + 1, nz + 1);
+    const long n_bc_part = (long)bgrid.x * bgrid.y * bgrid.z;
+    const long n_part = n_sweep_part + n_bc_part;
+    if ((rc = ws(c.slot[S_PART], (size_t)n_part * sizeof(double)))) return rc;
+    double* part = (double*)c.slot[S_PART].p;
+    const double den = rms_denominator(nx, ny, nz);
+    const Box bx{nx + 1, ny + 1, nz + 1, 0, 0, 0, nx, ny, nz};
+
+    float* bufs[2] = {d_phi, (float*)c.slot[S_PONG].p};
+    int host_ctl[3] = {0, 0, 0};
+    prof_begin();
+    for (int s = 0; s < max_sweeps; ++s) {
+        const float* A = bufs[s & 1];
+        float* B = bufs[(s + 1) & 1];
+        prof_mark(st);
+        hipLaunchKernelGGL((k_reinit_jacobi_f32<false>), jgrid, dim3(F32_BX, F32_BY), 0, st, A, B, d_phiS, bx, 1, 1, 1, nx,
+                           ny, nz, (float)dx, (float)h, part, ctl);
+        prof_mark(st);
+        hipLaunchKernelGGL(k_bc<float>, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, (float)dx,
+                           part + n_sweep_part, ctl);
+        prof_mark(st);
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
+        prof_mark(st);
+        if ((s + 1) % CHECK_EVERY == 0 && s + 1 < max_sweeps) {
+            HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (host_ctl[0]) break;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int nsw = host_ctl[1];
+    prof_end(nsw);
+    g_prof.sweep_launches = g_prof.sweeps;
+    g_prof.kernel = "k_reinit_jacobi_f32";
+    if (bufs[nsw & 1] != d_phi)
+        HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (rms_trace && trace_cap > 0 && nsw > 0)
+        HIPCHK(hipMemcpyAsync(rms_trace, d_trace, sizeof(double) * (size_t)std::min(nsw, trace_cap),
+                              hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (sweeps_done) *sweeps_done = nsw;
+    if (host_ctl[2]) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, subs.f90:926)");
+    return LSF_OK;
+}
 
 // LSF_GS_SCHEDULE selects how the exact Gauss-Seidel tile graph is executed (all are bit-identical):
 //   "dataflow" (default) skewed tiles, one launch per batch of sweeps, dependencies resolved in the kernel
@@ -962,6 +1037,25 @@ int box_ok(const lsf_box* b, const int lo[3], const int hi[3])
     return LSF_OK;
 }
 
+// the region of a box sweep must consist of interior cells of the global grid with their stencil inside the box
+int sweep_region_ok(const lsf_box* box, const int lo[3], const int hi[3])
+{
+    const int g0[3] = {box->gx0, box->gy0, box->gz0}, nn[3] = {box->nx, box->ny, box->nz};
+    const int ext[3] = {box->lx, box->ly, box->lz};
+    for (int a = 0; a < 3; ++a) {
+        if (lo[a] + g0[a] < 1 || hi[a] - 1 + g0[a] > nn[a] - 1)
+            return fail(LSF_ERR_INVALID, "sweep region must lie in the global interior 1..n-1");
+        for (int e = 0; e < 2; ++e) {
+            const int l = e ? hi[a] - 1 : lo[a], g = l + g0[a];
+            // reach: 3 only if the cell can take the WENO branch along this axis; 1 is always needed
+            const int reach = (g > 3 && g < nn[a] - 4) ? 3 : 1;
+            if (l - reach < 0 || l + reach > ext[a] - 1)
+                return fail(LSF_ERR_INVALID, "stencil of the sweep region leaves the local box (ghost layers missing)");
+        }
+    }
+    return LSF_OK;
+}
+
 int stream_partials(hipStream_t st, size_t count, double** out)
 {
     Ctx& c = ctx();
@@ -969,6 +1063,56 @@ int stream_partials(hipStream_t st, size_t count, double** out)
     int rc = ws(b, count * sizeof(double));
     if (rc) return rc;
     *out = (double*)b.p;
+    return LSF_OK;
+}
+
+template <typename T>
+int bc_box_impl(const T* d_in, T* d_out, const lsf_box* box, const int lo[3], const int hi[3], double dx,
+                       double* d_sumsq, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = box_ok(box, lo, hi))) return rc;
+    if (!d_in || !d_out || !d_sumsq) return fail(LSF_ERR_INVALID, "NULL pointer");
+    if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) return LSF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid = bc_grid(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
+    const long np = (long)grid.x * grid.y * grid.z;
+    double* part = nullptr;
+    if ((rc = stream_partials(st, (size_t)np, &part))) return rc;
+    const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
+    hipLaunchKernelGGL(k_bc<T>, grid, dim3(64), 0, st, d_in, d_out, bx, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], (T)dx,
+                       part, (const int*)nullptr);
+    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(256), 0, st, part, np, d_sumsq);
+    HIPCHK(hipGetLastError());
+    return LSF_OK;
+}
+
+template <typename T>
+int pack_impl(const T* d_field, T* d_field_w, const lsf_box* box, const int lo[3], const int hi[3], T* d_buf,
+                     int unpack, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = box_ok(box, lo, hi))) return rc;
+    if (!d_buf || (!d_field && !d_field_w)) return fail(LSF_ERR_INVALID, "NULL pointer");
+    const int e0 = hi[0] - lo[0], e1 = hi[1] - lo[1], e2 = hi[2] - lo[2];
+    if (e0 <= 0 || e1 <= 0 || e2 <= 0) return LSF_OK;
+    const long n = (long)e0 * e1 * e2;
+    const int grid = (int)std::min<long>((n + 255) / 256, 4096);
+    const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
+    hipLaunchKernelGGL(k_pack<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_field, d_buf, bx, lo[0], lo[1],
+                       lo[2], e0, e1, e2, unpack, d_field_w);
+    HIPCHK(hipGetLastError());
+    return LSF_OK;
+}
+
+int f32_mode_ok(int mode)
+{
+    if ((mode & LSF_ORDER_MASK) != LSF_ORDER_JACOBI || (mode & LSF_ARITH_STRICT))
+        return fail(LSF_ERR_INVALID,
+                    "fp32 fields: only LSF_ORDER_JACOBI | LSF_ARITH_FAST exists (the reference is fp64; there is no "
+                    "fp32 field to be identical to)");
     return LSF_OK;
 }
 
@@ -1286,20 +1430,7 @@ int lsf_jacobi_sweep_box(const double* d_in, double* d_out, const double* d_phiS
     if ((rc = box_ok(box, lo, hi))) return rc;
     if (!d_in || !d_out || !d_phiS || !d_sumsq) return fail(LSF_ERR_INVALID, "NULL pointer");
     if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) return LSF_OK; // empty region
-    // the region must consist of interior cells of the global grid with their stencil inside the box
-    const int g0[3] = {box->gx0, box->gy0, box->gz0}, nn[3] = {box->nx, box->ny, box->nz};
-    const int ext[3] = {box->lx, box->ly, box->lz};
-    for (int a = 0; a < 3; ++a) {
-        if (lo[a] + g0[a] < 1 || hi[a] - 1 + g0[a] > nn[a] - 1)
-            return fail(LSF_ERR_INVALID, "sweep region must lie in the global interior 1..n-1");
-        for (int e = 0; e < 2; ++e) {
-            const int l = e ? hi[a] - 1 : lo[a], g = l + g0[a];
-            // reach: 3 only if the cell can take the WENO branch along this axis; 1 is always needed
-            const int reach = (g > 3 && g < nn[a] - 4) ? 3 : 1;
-            if (l - reach < 0 || l + reach > ext[a] - 1)
-                return fail(LSF_ERR_INVALID, "stencil of the sweep region leaves the local box (ghost layers missing)");
-        }
-    }
+    if ((rc = sweep_region_ok(box, lo, hi))) return rc;
     hipStream_t st = (hipStream_t)stream;
     // regions a few cells wide in x (the x rim of a decomposed sweep) run with the lanes along y
     const bool thinx = hi[0] - lo[0] <= 8 && hi[1] - lo[1] >= 32;
@@ -1328,52 +1459,103 @@ int lsf_jacobi_sweep_box(const double* d_in, double* d_out, const double* d_phiS
 int lsf_bc_box(const double* d_in, double* d_out, const lsf_box* box, const int lo[3], const int hi[3],
                double dx, double* d_sumsq, void* stream)
 {
-    int rc = ensure_device();
-    if (rc) return rc;
-    if ((rc = box_ok(box, lo, hi))) return rc;
-    if (!d_in || !d_out || !d_sumsq) return fail(LSF_ERR_INVALID, "NULL pointer");
-    if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) return LSF_OK;
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 grid = bc_grid(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
-    const long np = (long)grid.x * grid.y * grid.z;
-    double* part = nullptr;
-    if ((rc = stream_partials(st, (size_t)np, &part))) return rc;
-    const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
-    hipLaunchKernelGGL(k_bc, grid, dim3(64), 0, st, d_in, d_out, bx, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], dx,
-                       part, (const int*)nullptr);
-    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(256), 0, st, part, np, d_sumsq);
-    HIPCHK(hipGetLastError());
-    return LSF_OK;
+    return bc_box_impl<double>(d_in, d_out, box, lo, hi, dx, d_sumsq, stream);
 }
 
-static int pack_impl(const double* d_field, double* d_field_w, const lsf_box* box, const int lo[3], const int hi[3],
-                     double* d_buf, int unpack, void* stream)
+int lsf_bc_box_f32(const float* d_in, float* d_out, const lsf_box* box, const int lo[3], const int hi[3],
+                   double dx, double* d_sumsq, void* stream)
 {
-    int rc = ensure_device();
-    if (rc) return rc;
-    if ((rc = box_ok(box, lo, hi))) return rc;
-    if (!d_buf || (!d_field && !d_field_w)) return fail(LSF_ERR_INVALID, "NULL pointer");
-    const int e0 = hi[0] - lo[0], e1 = hi[1] - lo[1], e2 = hi[2] - lo[2];
-    if (e0 <= 0 || e1 <= 0 || e2 <= 0) return LSF_OK;
-    const long n = (long)e0 * e1 * e2;
-    const int grid = (int)std::min<long>((n + 255) / 256, 4096);
-    const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
-    hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_field, d_buf, bx, lo[0], lo[1], lo[2],
-                       e0, e1, e2, unpack, d_field_w);
-    HIPCHK(hipGetLastError());
-    return LSF_OK;
+    return bc_box_impl<float>(d_in, d_out, box, lo, hi, dx, d_sumsq, stream);
 }
 
 int lsf_pack_box(const double* d_field, const lsf_box* box, const int lo[3], const int hi[3], double* d_buf,
                  void* stream)
 {
-    return pack_impl(d_field, nullptr, box, lo, hi, d_buf, 0, stream);
+    return pack_impl<double>(d_field, nullptr, box, lo, hi, d_buf, 0, stream);
 }
 
 int lsf_unpack_box(double* d_field, const lsf_box* box, const int lo[3], const int hi[3], const double* d_buf,
                    void* stream)
 {
-    return pack_impl(nullptr, d_field, box, lo, hi, const_cast<double*>(d_buf), 1, stream);
+    return pack_impl<double>(nullptr, d_field, box, lo, hi, const_cast<double*>(d_buf), 1, stream);
+}
+
+int lsf_pack_box_f32(const float* d_field, const lsf_box* box, const int lo[3], const int hi[3], float* d_buf,
+                     void* stream)
+{
+    return pack_impl<float>(d_field, nullptr, box, lo, hi, d_buf, 0, stream);
+}
+
+int lsf_unpack_box_f32(float* d_field, const lsf_box* box, const int lo[3], const int hi[3], const float* d_buf,
+                       void* stream)
+{
+    return pack_impl<float>(nullptr, d_field, box, lo, hi, const_cast<float*>(d_buf), 1, stream);
+}
+
+// ---- fp32 Jacobi path (BASELINE configuration 5) -------------------------------------------------
+int lsf_jacobi_sweep_box_f32(const float* d_in, float* d_out, const float* d_phiS, const lsf_box* box,
+                             const int lo[3], const int hi[3], double dx, double h, int mode, double* d_sumsq,
+                             void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = f32_mode_ok(mode))) return rc;
+    if ((rc = box_ok(box, lo, hi))) return rc;
+    if (!d_in || !d_out || !d_phiS || !d_sumsq) return fail(LSF_ERR_INVALID, "NULL pointer");
+    if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) return LSF_OK;
+    if ((rc = sweep_region_ok(box, lo, hi))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int npair = cdiv(hi[1] - lo[1], 2);
+    const bool thinx = hi[0] - lo[0] <= 8 && hi[1] - lo[1] >= 64;
+    const dim3 grid = thinx ? dim3(cdiv(npair, F32_BX), cdiv(hi[0] - lo[0], F32_BY), cdiv(hi[2] - lo[2], F32_KC))
+                            : dim3(cdiv(hi[0] - lo[0], F32_BX), cdiv(npair, F32_BY), cdiv(hi[2] - lo[2], F32_KC));
+    const long np = (long)grid.x * grid.y * grid.z;
+    double* part = nullptr;
+    if ((rc = stream_partials(st, (size_t)np, &part))) return rc;
+    const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
+    if (thinx)
+        hipLaunchKernelGGL((k_reinit_jacobi_f32<true>), grid, dim3(F32_BX, F32_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0],
+                           lo[1], lo[2], hi[0], hi[1], hi[2], (float)dx, (float)h, part, (const int*)nullptr);
+    else
+        hipLaunchKernelGGL((k_reinit_jacobi_f32<false>), grid, dim3(F32_BX, F32_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0],
+                           lo[1], lo[2], hi[0], hi[1], hi[2], (float)dx, (float)h, part, (const int*)nullptr);
+    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(256), 0, st, part, np, d_sumsq);
+    HIPCHK(hipGetLastError());
+    return LSF_OK;
+}
+
+int lsf_reinit_f32_device(float* d_phi, const float* d_phiS, int nx, int ny, int nz, int iter, double dx, double h,
+                          double tol, int mode, int* sweeps_done, double* rms_trace, int trace_cap, void* stream)
+{
+    Trace trace_("lsf_reinit_f32_device");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = f32_mode_ok(mode))) return rc;
+    return reinit_f32_core(d_phi, d_phiS, nx, ny, nz, iter, dx, h, tol, sweeps_done, rms_trace, trace_cap,
+                           (hipStream_t)stream);
+}
+
+int lsf_reinit_f32(float* phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,
+                   int* sweeps_done, double* rms_trace, int trace_cap)
+{
+    Trace trace_("lsf_reinit_f32");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = f32_mode_ok(mode))) return rc;
+    if ((rc = check_dims(nx, ny, nz))) return rc;
+    if (!phi) return fail(LSF_ERR_INVALID, "phi is NULL");
+    Ctx& c = ctx();
+    const size_t bytes = (size_t)(nx + 1) * (ny + 1) * (nz + 1) * sizeof(float);
+    if ((rc = ws(c.slot[S_HPHI], bytes))) return rc;
+    float* d = (float*)c.slot[S_HPHI].p;
+    HIPCHK(hipMemcpy(d, phi, bytes, hipMemcpyHostToDevice));
+    rc = reinit_f32_core(d, nullptr, nx, ny, nz, iter, dx, h, tol, sweeps_done, rms_trace, trace_cap, nullptr);
+    if (rc == LSF_OK || rc == LSF_ERR_NAN) {
+        const std::string keep = g_err;
+        HIPCHK(hipMemcpy(phi, d, bytes, hipMemcpyDeviceToHost));
+        g_err = keep;
+    }
+    return rc;
 }
 
 } // extern "C"

@@ -1,0 +1,219 @@
+// lsf_f32.hpp -- single-precision Jacobi reinitialisation for gfx950 (BASELINE.json configuration 5:
+// 1536^3 fp32 on 2x2x2 GPUs; SURVEY.md section 8d "C5").
+//
+// The reference is fp64 only (Makefile:4 -fdefault-real-8), so there is no fp32 field to be identical
+// to: this path is checked against the fp64 oracle within a stated tolerance (tests/test_gpu_f32.py) and
+// against the analytic signed distance.  Same update as subs.f90:743-852 / weno :489-711 / phiSign
+// :152-172, in the operation-lean algebra of weno_axis_fast (lsf_cell.hpp), with two changes fp32 forces:
+//   * the reference's epsilon floor 1e-99 (subs.f90:533-534) is below the fp32 range: the floor is
+//     LSF_F32_FLOOR (in the unscaled units of weno_axis_fast, like `floor2` there);
+//   * the products of four q_k = eps + IS_k underflow fp32 (q ~ 1e-11 ... 1e-22 on a 1536^3 grid), so the
+//     three q_k of a side are divided by their sum first (the weights are ratios: nothing changes
+//     mathematically, and a constant field still gives the linear weights 0.1 / 0.6 / 0.3).
+//
+// Packed arithmetic: a lane owns TWO cells, (i,j,k) and (i,j+1,k), held in the two halves of a float2, so
+// that the adds, multiplies and FMAs of the WENO algebra issue as v_pk_add_f32 / v_pk_mul_f32 /
+// v_pk_fma_f32 (two results per lane per issue slot; fp32 scalar instructions issue at the fp64 rate on
+// CDNA4, so without packing fp32 would buy nothing on this VALU-bound kernel).  max/min/rcp/rsq/sqrt have
+// no packed form and are done per half.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lsf_kernels.hpp"
+
+namespace lsf {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr float LSF_F32_FLOOR = 1.0e-30f;
+
+__device__ __forceinline__ f2 mk2(float a, float b)
+{
+    f2 r;
+    r.x = a;
+    r.y = b;
+    return r;
+}
+__device__ __forceinline__ f2 splat(float a) { return mk2(a, a); }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 max2(f2 a, f2 b) { return mk2(__builtin_fmaxf(a.x, b.x), __builtin_fmaxf(a.y, b.y)); }
+__device__ __forceinline__ f2 abs2(f2 a) { return mk2(__builtin_fabsf(a.x), __builtin_fabsf(a.y)); }
+__device__ __forceinline__ f2 rcp2(f2 a) { return mk2(__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)); }
+
+// One WENO side from the normalised q's: returns r * (n0/3 * Sa + m2/2 * S0) - S0/12  (see weno_axis_fast).
+__device__ __forceinline__ f2 weno_side_f32(f2 q0, f2 q1, f2 q2, f2 Sa, f2 S0, f2 S12)
+{
+    const f2 s = rcp2(q0 + q1 + q2);
+    q0 *= s, q1 *= s, q2 *= s;
+    const f2 t12 = q1 * q2, t02 = q0 * q2, t01 = q0 * q1;
+    const f2 n0 = t12 * t12, n1 = t02 * t02, m2 = t01 * t01;
+    const f2 D = fma2(splat(3.0f), m2, fma2(splat(6.0f), n1, n0));
+    const f2 r = rcp2(D);
+    return fma2(r, fma2(n0 * splat(1.0f / 3.0f), Sa, (m2 * splat(0.5f)) * S0), -S12);
+}
+
+// One axis for the two cells of a lane, unscaled like weno_axis_fast: returns dm*dx and dp*dx.
+// q[0..6] = phi at -3..+3 along the axis.  yquirk = subs.f90:576 (p5 = 0 on the y axis).
+__device__ __forceinline__ void weno_axis_f32(const f2 q[7], bool yquirk, f2& dm, f2& dp)
+{
+    const f2 d0 = q[1] - q[0], d1 = q[2] - q[1], d2 = q[3] - q[2];
+    const f2 d3 = q[4] - q[3], d4 = q[5] - q[4], d5 = q[6] - q[5];
+    const f2 am = d1 - d0, bm = d2 - d1, cp = d3 - d2, bp = d4 - d3, ap = d5 - d4;
+    const f2 e_ab = ap - bp, e_bc = bp - cp, e_cm = cp - bm, e_mm = am - bm;
+    const f2 s_ab = e_ab * e_ab, s_bc = e_bc * e_bc, s_cm = e_cm * e_cm, s_mm = e_mm * e_mm;
+    const f2 K = splat(3.0f / 13.0f), three = splat(3.0f);
+    auto isf = [&](f2 sq, f2 t) { return fma2(K * t, t, sq); }; // (13 e^2 + 3 t^2)/13
+    const f2 IS0p = isf(s_ab, fma2(-three, bp, ap));
+    const f2 IS1p = isf(s_bc, bp + cp);
+    const f2 IS2p = isf(s_cm, fma2(three, cp, -bm));
+    const f2 IS0m = isf(s_mm, fma2(-three, bm, am));
+    const f2 IS1m = isf(s_cm, bm + cp);
+    const f2 IS2m = isf(s_bc, fma2(three, cp, -bp));
+
+    const f2 mid = max2(max2(abs2(d1), abs2(d2)), max2(abs2(d3), abs2(d4)));
+    const f2 mp = yquirk ? mid : max2(mid, abs2(d5));
+    const f2 mm = max2(mid, abs2(d0));
+    const f2 E = splat(1.E-6f / 13.0f), fl = splat(LSF_F32_FLOOR);
+    const f2 epsp = fma2(E * mp, mp, fl);
+    const f2 epsm = fma2(E * mm, mm, fl);
+
+    const f2 S0 = e_bc - e_cm;
+    const f2 S12 = S0 * splat(1.0f / 12.0f);
+    const f2 PWp = weno_side_f32(epsp + IS0p, epsp + IS1p, epsp + IS2p, e_ab - e_bc, S0, S12);
+    const f2 PWm = weno_side_f32(epsm + IS0m, epsm + IS1m, epsm + IS2m, e_mm + e_cm, S0, S12);
+    const f2 cen = splat(1.0f / 12.0f) * (splat(7.0f) * (d2 + d3) - (d1 + d4));
+    dm = cen - PWm;
+    dp = cen + PWp;
+}
+
+// Godunov term of one axis for one cell (subs.f90:684-692), unscaled one-sided differences
+__device__ __forceinline__ float godunov_f32(float phic, float dm, float dp)
+{
+    const bool pos = phic > 0.f;
+    const float ua = pos ? __builtin_fmaxf(dm, 0.f) : __builtin_fminf(dm, 0.f);
+    const float ub = pos ? __builtin_fminf(dp, 0.f) : __builtin_fmaxf(dp, 0.f);
+    return __builtin_fmaxf(ua * ua, ub * ub);
+}
+
+// gM, smeared sign and Euler step (subs.f90:702, :169, :749-750) for one cell; S = gX+gY+gZ unscaled
+__device__ __forceinline__ float finish_f32(float phic, float S, float pS, float dx2, float inv_dx, float h)
+{
+    const float gM = __builtin_sqrtf(S) * inv_dx;
+    const float t = __builtin_fmaf(pS, pS, dx2 * gM);
+    const float sgn = pS * __builtin_amdgcn_rsqf(t); // pS = 0 and gM = 0 -> NaN, like the reference
+    return __builtin_fmaf(h, sgn * (1.f - gM), phic);
+}
+
+// =============================================================================================
+// Jacobi sweep of a box region, fp32.  Block 64 x F32_BY threads; thread (tx,ty) owns the cell pair
+// (i, j) / (i, j+1), j = lo1 + 2*(blockIdx.y*F32_BY + ty), and marches F32_KC cells in k with a 7-deep
+// window of pairs; x / y neighbours come through the vector L1/L2.  Partial sums of (new-old)^2 go to
+// `partials` in double (fixed order -> reproducible).
+// =============================================================================================
+constexpr int F32_BX = 64, F32_BY = 4, F32_KC = 32;
+
+template <bool THINX>
+__global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const float* __restrict__ A,
+                                                                      float* __restrict__ Bout,
+                                                                      const float* __restrict__ phiS, Box bx, int lo0,
+                                                                      int lo1, int lo2, int hi0, int hi1, int hi2,
+                                                                      float dx, float h,
+                                                                      double* __restrict__ partials,
+                                                                      const int* __restrict__ done)
+{
+    __shared__ double red[F32_BX * F32_BY / 64];
+    if (done && *done) return;
+    // THINX (x rim of a decomposed sweep, a few cells wide): lanes along the pair index instead of x
+    const int li = THINX ? lo0 + (int)(blockIdx.y * F32_BY + threadIdx.y) : lo0 + (int)(blockIdx.x * F32_BX + threadIdx.x);
+    const int lj = THINX ? lo1 + 2 * (int)(blockIdx.x * F32_BX + threadIdx.x)
+                         : lo1 + 2 * (int)(blockIdx.y * F32_BY + threadIdx.y);
+    const int k0 = lo2 + blockIdx.z * F32_KC;
+    const int k1 = min(k0 + F32_KC, hi2);
+    const int sx = bx.lx;
+    const long sxy = (long)bx.lx * bx.ly;
+    float acc = 0.f;
+    if (li < hi0 && lj < hi1) {
+        const bool two = lj + 1 < hi1; // the second cell of the pair exists
+        const int gi = li + bx.gx0, gj = lj + bx.gy0;
+        const bool i_weno = gi > 3 && gi < bx.nx - 4;
+        const bool jA = i_weno && gj > 3 && gj < bx.ny - 4;
+        const bool jB = i_weno && two && gj + 1 > 3 && gj + 1 < bx.ny - 4;
+        const float inv_dx = 1.0f / dx, dx2 = dx * dx;
+        // the eight rows j-3..j+4 of the pair, clamped to the box (rows beyond the reach of the branch in
+        // use are never consumed); offsets relative to the plane
+        int row[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int r = lj + t - 3;
+            row[t] = li + sx * (r < 0 ? 0 : (r > bx.ly - 1 ? bx.ly - 1 : r));
+        }
+        const int colA = row[3], colB = row[4];
+        auto ldz = [&](int k) -> f2 {
+            const int kk = k < 0 ? 0 : (k > bx.lz - 1 ? bx.lz - 1 : k);
+            const float* p = A + sxy * kk;
+            return mk2(p[colA], p[colB]);
+        };
+        f2 qz[7];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) qz[m + 1] = ldz(k0 - 3 + m);
+        for (int k = k0; k < k1; ++k) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) qz[m] = qz[m + 1];
+            qz[6] = ldz(k + 3);
+            const int gk = k + bx.gz0;
+            const bool k_weno = gk > 3 && gk < bx.nz - 4;
+            const bool wA = jA && k_weno, wB = jB && k_weno;
+            const float* P = A + sxy * k;
+            const f2 c = qz[3];
+            // first-order one-sided differences (subs.f90:657-662), always valid
+            const f2 xm1 = mk2(P[colA - 1], P[colB - 1]), xp1 = mk2(P[colA + 1], P[colB + 1]);
+            const float r2 = P[row[2]], r5 = P[row[5]];
+            f2 a = c - xm1, b = xp1 - c;
+            f2 cc = c - mk2(r2, c.x), d = mk2(c.y, r5) - c;
+            f2 e = c - qz[2], f = qz[4] - c;
+            if (wA || wB) {
+                f2 qx[7], qy[7];
+                qx[0] = mk2(P[colA - 3], P[colB - 3]);
+                qx[1] = mk2(P[colA - 2], P[colB - 2]);
+                qx[2] = xm1, qx[3] = c, qx[4] = xp1;
+                qx[5] = mk2(P[colA + 2], P[colB + 2]);
+                qx[6] = mk2(P[colA + 3], P[colB + 3]);
+                const float r0 = P[row[0]], r1 = P[row[1]], r6 = P[row[6]], r7 = P[row[7]];
+                qy[0] = mk2(r0, r1), qy[1] = mk2(r1, r2), qy[2] = mk2(r2, c.x), qy[3] = c;
+                qy[4] = mk2(c.y, r5), qy[5] = mk2(r5, r6), qy[6] = mk2(r6, r7);
+                f2 wa, wb, wc, wd, we, wf;
+                weno_axis_f32(qx, false, wa, wb);
+                weno_axis_f32(qy, true, wc, wd);
+                weno_axis_f32(qz, false, we, wf);
+                if (wA) a.x = wa.x, b.x = wb.x, cc.x = wc.x, d.x = wd.x, e.x = we.x, f.x = wf.x;
+                if (wB) a.y = wa.y, b.y = wb.y, cc.y = wc.y, d.y = wd.y, e.y = we.y, f.y = wf.y;
+            }
+            const long cidx = sxy * k;
+            {
+                const float S = godunov_f32(c.x, a.x, b.x) + godunov_f32(c.x, cc.x, d.x) + godunov_f32(c.x, e.x, f.x);
+                const float nv = finish_f32(c.x, S, phiS[cidx + colA], dx2, inv_dx, h);
+                Bout[cidx + colA] = nv;
+                const float dl = nv - c.x;
+                acc = __builtin_fmaf(dl, dl, acc);
+            }
+            if (two) {
+                const float S = godunov_f32(c.y, a.y, b.y) + godunov_f32(c.y, cc.y, d.y) + godunov_f32(c.y, e.y, f.y);
+                const float nv = finish_f32(c.y, S, phiS[cidx + colB], dx2, inv_dx, h);
+                Bout[cidx + colB] = nv;
+                const float dl = nv - c.y;
+                acc = __builtin_fmaf(dl, dl, acc);
+            }
+        }
+    }
+    const double tot = wave_sum((double)acc);
+    const int tid = threadIdx.x + F32_BX * threadIdx.y;
+    if ((tid & 63) == 0) red[tid >> 6] = tot;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < F32_BX * F32_BY / 64; ++w) t += red[w];
+        partials[blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)] = t;
+    }
+}
+
+} // namespace lsf

@@ -113,8 +113,9 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi
 // wall point <- interior point clamp(i,1,n-1) + dx added m = min(nb, 1+nh) times in sequence.
 // grid = (ceil(maxext/64), maxext, 6 faces); each wall point is owned by exactly one face.
 // =============================================================================================
-__global__ __launch_bounds__(64) void k_bc(const double* __restrict__ A, double* __restrict__ Bout, Box bx,
-                                           int lo0, int lo1, int lo2, int hi0, int hi1, int hi2, double dx,
+template <typename T>
+__global__ __launch_bounds__(64) void k_bc(const T* __restrict__ A, T* __restrict__ Bout, Box bx,
+                                           int lo0, int lo1, int lo2, int hi0, int hi1, int hi2, T dx,
                                            double* __restrict__ partials, const int* __restrict__ done)
 {
     if (done && *done) return;
@@ -146,12 +147,12 @@ __global__ __launch_bounds__(64) void k_bc(const double* __restrict__ A, double*
             const int cj = min(max(gj, 1), bx.ny - 1) - bx.gy0;
             const int ck = min(max(gk, 1), bx.nz - 1) - bx.gz0;
             const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
-            double val = Bout[ci + sx * cj + sxy * ck];
+            T val = Bout[ci + sx * cj + sxy * ck];
             for (int t = 0; t < m; ++t) val = val + dx;
             const long p = l[0] + sx * l[1] + sxy * l[2];
-            const double dlt = val - A[p];
+            const T dlt = val - A[p];
             Bout[p] = val;
-            contrib = dlt * dlt;
+            contrib = (double)(dlt * dlt);
         }
     }
     contrib = wave_sum(contrib);
@@ -676,9 +677,10 @@ __global__ __launch_bounds__(64) void k_advect_nodes(const double* __restrict__ 
 // =============================================================================================
 // pack / unpack of a sub-box (halo slabs)
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_pack(const double* __restrict__ f, double* __restrict__ buf, Box bx,
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack(const T* __restrict__ f, T* __restrict__ buf, Box bx,
                                               int lo0, int lo1, int lo2, int e0, int e1, int e2, int unpack,
-                                              double* __restrict__ fw)
+                                              T* __restrict__ fw)
 {
     const long n = (long)e0 * e1 * e2;
     const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;

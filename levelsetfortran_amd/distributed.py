@@ -172,7 +172,7 @@ def halo_plan(b: Block):
 class HipBackend:
     """Device arithmetic through the C ABI; tensors are 1-D torch CUDA float64, i fastest."""
 
-    def __init__(self, device, arith: str = "fast", host_staging: bool = False):
+    def __init__(self, device, arith: str = "fast", host_staging: bool = False, dtype: str = "f64"):
         import torch
 
         from . import _lib
@@ -185,18 +185,28 @@ class HipBackend:
         self.lib = _lib.load()
         self.device = device
         self.mode = _lib.LSF_ORDER_JACOBI | (_lib.LSF_ARITH_STRICT if arith == "strict" else _lib.LSF_ARITH_FAST)
+        # dtype "f32": the single-precision twins of the four building blocks (BASELINE configuration 5)
+        if dtype not in ("f64", "f32"):
+            raise ValueError("dtype must be 'f64' or 'f32'")
+        self.dtype = torch.float32 if dtype == "f32" else torch.float64
+        sfx = "_f32" if dtype == "f32" else ""
+        self._sweep = getattr(self.lib, "lsf_jacobi_sweep_box" + sfx)
+        self._bc = getattr(self.lib, "lsf_bc_box" + sfx)
+        self._pack = getattr(self.lib, "lsf_pack_box" + sfx)
+        self._unpack = getattr(self.lib, "lsf_unpack_box" + sfx)
         _lib.check(self.lib.lsf_set_device(device.index or 0))
         self.compute = torch.cuda.current_stream(device)
         self.comm = torch.cuda.Stream(device)
 
     def empty(self, n, dtype=None):
-        return self.torch.empty(n, dtype=dtype or self.torch.float64, device=self.device)
+        return self.torch.empty(n, dtype=dtype or self.dtype, device=self.device)
 
     def zeros(self, n):
+        # sums of squares are accumulated in double whatever the field type
         return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
 
     def from_numpy(self, a):
-        return self.torch.from_numpy(np.ascontiguousarray(a.ravel(order="F"))).to(self.device)
+        return self.torch.from_numpy(np.ascontiguousarray(a.ravel(order="F"))).to(self.device).to(self.dtype)
 
     def to_numpy(self, t, shape):
         return t.cpu().numpy().reshape(shape, order="F")
@@ -212,23 +222,23 @@ class HipBackend:
 
     def sweep(self, a_in, a_out, phiS, b, region, dx, h, sumsq, stream):
         lo, hi = self._lohi(region)
-        self.L.check(self.lib.lsf_jacobi_sweep_box(a_in.data_ptr(), a_out.data_ptr(), phiS.data_ptr(),
+        self.L.check(self._sweep(a_in.data_ptr(), a_out.data_ptr(), phiS.data_ptr(),
                                                    ctypes.byref(self._box(b)), lo, hi, dx, h, self.mode,
                                                    sumsq.data_ptr(), stream.cuda_stream))
 
     def bc(self, a_in, a_out, b, region, dx, sumsq, stream):
         lo, hi = self._lohi(region)
-        self.L.check(self.lib.lsf_bc_box(a_in.data_ptr(), a_out.data_ptr(), ctypes.byref(self._box(b)), lo, hi, dx,
+        self.L.check(self._bc(a_in.data_ptr(), a_out.data_ptr(), ctypes.byref(self._box(b)), lo, hi, dx,
                                          sumsq.data_ptr(), stream.cuda_stream))
 
     def pack(self, f, b, region, buf, stream):
         lo, hi = self._lohi(region)
-        self.L.check(self.lib.lsf_pack_box(f.data_ptr(), ctypes.byref(self._box(b)), lo, hi, buf.data_ptr(),
+        self.L.check(self._pack(f.data_ptr(), ctypes.byref(self._box(b)), lo, hi, buf.data_ptr(),
                                            stream.cuda_stream))
 
     def unpack(self, f, b, region, buf, stream):
         lo, hi = self._lohi(region)
-        self.L.check(self.lib.lsf_unpack_box(f.data_ptr(), ctypes.byref(self._box(b)), lo, hi, buf.data_ptr(),
+        self.L.check(self._unpack(f.data_ptr(), ctypes.byref(self._box(b)), lo, hi, buf.data_ptr(),
                                              stream.cuda_stream))
 
     def stream_ctx(self, stream):
@@ -267,8 +277,8 @@ class DistributedReinit:
         if self.staging:
             import torch
 
-            self.send_host = [torch.empty(b.numel(), dtype=torch.float64).pin_memory() for b in self.send_bufs]
-            self.recv_host = [torch.empty(b.numel(), dtype=torch.float64).pin_memory() for b in self.recv_bufs]
+            self.send_host = [torch.empty(b.numel(), dtype=b.dtype).pin_memory() for b in self.send_bufs]
+            self.recv_host = [torch.empty(b.numel(), dtype=b.dtype).pin_memory() for b in self.recv_bufs]
         self.sumsq = backend.zeros(1)
         # INTEGER*4 product nx*ny*nz of the GLOBAL grid (subs.f90:914), wrapping like the reference
         nx, ny, nz = block.n
@@ -351,7 +361,7 @@ class DistributedReinit:
 
 
 # ------------------------------------------------------------------------------------------------
-def bench_weak_scaling(N: int, K: int, W: int, device, arith: str = "fast"):
+def bench_weak_scaling(N: int, K: int, W: int, device, arith: str = "fast", dtype: str = "f64"):
     """bench.py --mode jacobi --gpus >1: every rank owns an N^3-point block of a (Px N, Py N, Pz N) grid."""
     import time
 
@@ -365,7 +375,7 @@ def bench_weak_scaling(N: int, K: int, W: int, device, arith: str = "fast"):
     gpts = tuple(d * N for d in dims)
     n = tuple(g - 1 for g in gpts)
     b = make_block(rank, dims, n)
-    be = HipBackend(device, arith)
+    be = HipBackend(device, arith, dtype=dtype)
     rng = tuple((g, g + e) for g, e in zip(b.g0, b.ext))
     phi_np, dx = fields.two_sphere_phi0(gpts, ranges=rng)
     h = fields.reinit_step(dx)

@@ -113,6 +113,8 @@ def reinit(phi, gradPhi=None, gradPhiMag=None, nx: int = 0, ny: int = 0, nz: int
     reads what reinit stores there (set3d.f90:372-375 zeroes them).
     Runs at most iter+1 sweeps (subs.f90:735).  Raises LsfNaNError where the reference STOPs.
     echo=True prints the reference's per-sweep lines.
+    A float32 field (numpy or torch) selects the single-precision path of BASELINE configuration 5, which
+    exists for order="jacobi", arith="fast" only (the reference is fp64; see include/lsf.h).
     """
     lib = _lib.load()
     cap = int(iter) + 1
@@ -122,17 +124,30 @@ def reinit(phi, gradPhi=None, gradPhiMag=None, nx: int = 0, ny: int = 0, nz: int
     if _is_torch(phi):
         import torch
 
-        p = _dev_ptr(phi, torch.float64, nx, ny, nz, "phi")
-        ps = _dev_ptr(phiS, torch.float64, nx, ny, nz, "phiS") if phiS is not None else None
+        f32 = phi.dtype == torch.float32
+        tdt = torch.float32 if f32 else torch.float64
+        p = _dev_ptr(phi, tdt, nx, ny, nz, "phi")
+        ps = _dev_ptr(phiS, tdt, nx, ny, nz, "phiS") if phiS is not None else None
         st = _stream_and_device(phi)
-        rc = lib.lsf_reinit_device(p, ps, nx, ny, nz, int(iter), float(dx), float(h), float(tol), mode,
-                                   int(first_raster), ctypes.byref(done), trace.ctypes.data, cap, st)
+        if f32:  # single precision: Jacobi ordering, FAST arithmetic only (include/lsf.h)
+            if first_raster != 0:
+                raise ValueError("first_raster has no meaning for the Jacobi ordering")
+            rc = lib.lsf_reinit_f32_device(p, ps, nx, ny, nz, int(iter), float(dx), float(h), float(tol), mode,
+                                           ctypes.byref(done), trace.ctypes.data, cap, st)
+        else:
+            rc = lib.lsf_reinit_device(p, ps, nx, ny, nz, int(iter), float(dx), float(h), float(tol), mode,
+                                       int(first_raster), ctypes.byref(done), trace.ctypes.data, cap, st)
     else:
         if first_raster != 0 or phiS is not None:
             raise ValueError("first_raster / phiS are only available on the device seam")
-        p = _host_ptr(phi, np.float64, nx, ny, nz, "phi")
-        rc = lib.lsf_reinit(p, nx, ny, nz, int(iter), float(dx), float(h), float(tol), mode, ctypes.byref(done),
-                            trace.ctypes.data, cap)
+        if isinstance(phi, np.ndarray) and phi.dtype == np.float32:
+            p = _host_ptr(phi, np.float32, nx, ny, nz, "phi")
+            rc = lib.lsf_reinit_f32(p, nx, ny, nz, int(iter), float(dx), float(h), float(tol), mode,
+                                    ctypes.byref(done), trace.ctypes.data, cap)
+        else:
+            p = _host_ptr(phi, np.float64, nx, ny, nz, "phi")
+            rc = lib.lsf_reinit(p, nx, ny, nz, int(iter), float(dx), float(h), float(tol), mode, ctypes.byref(done),
+                                trace.ctypes.data, cap)
     n = done.value
     rep = SweepReport(n, [float(v) for v in trace[:n]], bool(n and trace[n - 1] < tol))
     if echo:

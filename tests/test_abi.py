@@ -57,7 +57,7 @@ def test_argument_validation_happens_before_the_library():
     with pytest.raises(ValueError):
         lsf.reinit(np.ones((6, 6, 6), order="C")[::1, :, ::-1], None, None, 5, 5, 5, 0, 0.1, 0.01)
     with pytest.raises(TypeError):
-        lsf.reinit(np.ones((6, 6, 6), dtype=np.float32, order="F"), None, None, 5, 5, 5, 0, 0.1, 0.01)
+        lsf.reinit(np.ones((6, 6, 6), dtype=np.float16, order="F"), None, None, 5, 5, 5, 0, 0.1, 0.01)
     with pytest.raises(TypeError):
         lsf.narrowBand(5, 5, 5, 0.1, np.ones((6, 6, 6), order="F"), np.zeros((6, 6, 6), order="F"),
                        np.zeros((6, 6, 6), dtype=np.int32, order="F"))
