@@ -42,14 +42,16 @@ def reinit_step(dx: float, extent=(2.0, 2.0, 2.0), cfl: float = 0.1) -> float:
     return cfl * dx / float(np.sqrt(extent[0] ** 2 + extent[1] ** 2 + extent[2] ** 2))
 
 
-def two_sphere_phi0_device(npts, device, lo=-1.5, hi=1.5):
+def two_sphere_phi0_device(npts, device, lo=-1.5, hi=1.5, ranges=None):
     """Same field as two_sphere_phi0, generated directly in HBM with torch (for grids whose numpy temporaries
-    would not fit in host memory, e.g. 1024^3).  Returns (1-D float64 CUDA tensor, i fastest; dx)."""
+    would not fit in host memory, e.g. 1024^3).  Returns (1-D float64 CUDA tensor, i fastest; dx).
+    ranges = ((i0,i1),(j0,j1),(k0,k1)) returns only that index block of the global field."""
     import torch
 
     nxp, nyp, nzp = npts
     dx = (hi - lo) / (nxp - 1)
-    ax = [lo + dx * torch.arange(n, dtype=torch.float64, device=device) for n in (nxp, nyp, nzp)]
+    rng = ranges if ranges is not None else ((0, nxp), (0, nyp), (0, nzp))
+    ax = [lo + dx * torch.arange(r[0], r[1], dtype=torch.float64, device=device) for r in rng]
     d = None
     for c in ((-0.6, 0.0, 0.0), (0.6, 0.0, 0.0)):
         r2 = (ax[2][:, None, None] - c[2]) ** 2 + (ax[1][None, :, None] - c[1]) ** 2 + (ax[0][None, None, :] - c[0]) ** 2

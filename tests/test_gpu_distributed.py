@@ -71,3 +71,21 @@ def test_two_ranks_one_gpu_equal_single_domain(tmp_path, dims):
         assert int(z["nsw"]) == sweeps
         assert np.allclose(z["rms"], rep.rms, rtol=1e-11, atol=0)
     assert np.array_equal(got, ref)
+
+
+def test_device_field_block_is_a_slice_of_the_whole_field():
+    """bench.py builds every rank's block of the synthetic phi0 directly in HBM (fields.two_sphere_phi0_device with
+    ranges): it must be the corresponding slice of the single-domain field."""
+    from levelsetfortran_amd import fields
+
+    npts = (40, 33, 27)
+    dev = torch.device("cuda", 0)
+    whole, dx = fields.two_sphere_phi0_device(npts, dev)
+    whole = whole.reshape(npts[2], npts[1], npts[0])
+    rng = ((5, 31), (0, 20), (9, 27))
+    part, dx2 = fields.two_sphere_phi0_device(npts, dev, ranges=rng)
+    assert dx == dx2
+    part = part.reshape(rng[2][1] - rng[2][0], rng[1][1] - rng[1][0], rng[0][1] - rng[0][0])
+    assert torch.equal(part, whole[rng[2][0]:rng[2][1], rng[1][0]:rng[1][1], rng[0][0]:rng[0][1]])
+    host, _ = fields.two_sphere_phi0(npts)
+    assert np.allclose(whole.cpu().numpy().transpose(2, 1, 0), host, rtol=0, atol=1e-14)
