@@ -40,10 +40,19 @@ __device__ __forceinline__ f2 max2(f2 a, f2 b) { return mk2(__builtin_fmaxf(a.x,
 __device__ __forceinline__ f2 abs2(f2 a) { return mk2(__builtin_fabsf(a.x), __builtin_fabsf(a.y)); }
 __device__ __forceinline__ f2 rcp2(f2 a) { return mk2(__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)); }
 
+// 2^-e for x = m * 2^e, 1 <= m < 2 (x positive, normal): two integer instructions per half instead of a
+// quarter-rate reciprocal; only a scale, so its value need not be exact
+__device__ __forceinline__ f2 pow2_inv(f2 x)
+{
+    const unsigned a = (254u << 23) - (__float_as_uint(x.x) & 0x7f800000u);
+    const unsigned b = (254u << 23) - (__float_as_uint(x.y) & 0x7f800000u);
+    return mk2(__uint_as_float(a), __uint_as_float(b));
+}
+
 // One WENO side from the normalised q's: returns r * (n0/3 * Sa + m2/2 * S0) - S0/12  (see weno_axis_fast).
 __device__ __forceinline__ f2 weno_side_f32(f2 q0, f2 q1, f2 q2, f2 Sa, f2 S0, f2 S12)
 {
-    const f2 s = rcp2(q0 + q1 + q2);
+    const f2 s = pow2_inv(q0 + q1 + q2); // q_k * s < 2, the largest >= 1/3
     q0 *= s, q1 *= s, q2 *= s;
     const f2 t12 = q1 * q2, t02 = q0 * q2, t01 = q0 * q1;
     const f2 n0 = t12 * t12, n1 = t02 * t02, m2 = t01 * t01;
@@ -86,22 +95,24 @@ __device__ __forceinline__ void weno_axis_f32(const f2 q[7], bool yquirk, f2& dm
     dp = cen + PWp;
 }
 
-// Godunov term of one axis for one cell (subs.f90:684-692), unscaled one-sided differences
-__device__ __forceinline__ float godunov_f32(float phic, float dm, float dp)
+// Godunov term of one axis for the pair (subs.f90:684-692), unscaled one-sided differences.  With
+// sg = sign(phic) (+1 / -1): max(max(sg dm, 0)^2, min(sg dp, 0)^2) is the reference's switch in one expression.
+__device__ __forceinline__ f2 godunov_f32(f2 sg, f2 dm, f2 dp)
 {
-    const bool pos = phic > 0.f;
-    const float ua = pos ? __builtin_fmaxf(dm, 0.f) : __builtin_fminf(dm, 0.f);
-    const float ub = pos ? __builtin_fminf(dp, 0.f) : __builtin_fmaxf(dp, 0.f);
-    return __builtin_fmaxf(ua * ua, ub * ub);
+    const f2 u = sg * dm, v = sg * dp;
+    const f2 ua = mk2(__builtin_fmaxf(u.x, 0.f), __builtin_fmaxf(u.y, 0.f));
+    const f2 ub = mk2(__builtin_fminf(v.x, 0.f), __builtin_fminf(v.y, 0.f));
+    return max2(ua * ua, ub * ub);
 }
 
-// gM, smeared sign and Euler step (subs.f90:702, :169, :749-750) for one cell; S = gX+gY+gZ unscaled
-__device__ __forceinline__ float finish_f32(float phic, float S, float pS, float dx2, float inv_dx, float h)
+// gM, smeared sign and Euler step (subs.f90:702, :169, :749-750) for the pair; S = gX+gY+gZ unscaled
+__device__ __forceinline__ f2 finish_f32(f2 phic, f2 S, f2 pS, float dx2, float inv_dx, float h)
 {
-    const float gM = __builtin_sqrtf(S) * inv_dx;
-    const float t = __builtin_fmaf(pS, pS, dx2 * gM);
-    const float sgn = pS * __builtin_amdgcn_rsqf(t); // pS = 0 and gM = 0 -> NaN, like the reference
-    return __builtin_fmaf(h, sgn * (1.f - gM), phic);
+    const f2 gM = mk2(__builtin_sqrtf(S.x), __builtin_sqrtf(S.y)) * splat(inv_dx);
+    const f2 t = fma2(pS, pS, splat(dx2) * gM);
+    // pS = 0 and gM = 0 -> NaN, like the reference
+    const f2 sgn = pS * mk2(__builtin_amdgcn_rsqf(t.x), __builtin_amdgcn_rsqf(t.y));
+    return fma2(splat(h), sgn * (splat(1.f) - gM), phic);
 }
 
 // =============================================================================================
@@ -141,17 +152,29 @@ __global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const floa
         const float inv_dx = 1.0f / dx, dx2 = dx * dx;
         // the eight rows j-3..j+4 of the pair, clamped to the box (rows beyond the reach of the branch in
         // use are never consumed); offsets relative to the plane
-        int row[8];
+        // Addressing: one buffer descriptor per k-plane (rebuilt on the scalar unit every step; a whole 1536^3
+        // field is beyond a descriptor's 4 GB) + the lane's 32-bit byte offset inside the plane, so the loop has no
+        // 64-bit address arithmetic and the seven x neighbours of a row arrive as one dwordx4 + one dwordx3.
+        // The descriptor of the stencil plane starts 3 floats early: x offsets -3..+3 become immediates 0..24
+        // (nothing is ever read below the plane: offsets < 12 are only used by cells with i >= 4).
+        unsigned row[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int r = lj + t - 3;
-            row[t] = li + sx * (r < 0 ? 0 : (r > bx.ly - 1 ? bx.ly - 1 : r));
+            row[t] = 4u * (unsigned)(li + sx * (r < 0 ? 0 : (r > bx.ly - 1 ? bx.ly - 1 : r)));
         }
-        const int colA = row[3], colB = row[4];
+        const unsigned colA = row[3], colB = row[4];
+        const unsigned plane_bytes = 4u * (unsigned)sxy;
+        auto desc = [&](const float* base, int shift) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) - shift, 0, (int)(plane_bytes + 24u), 0x00020000);
+        };
+        auto at = [](__amdgpu_buffer_rsrc_t r, unsigned boff) -> float {
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, boff, 0, 0));
+        };
         auto ldz = [&](int k) -> f2 {
             const int kk = k < 0 ? 0 : (k > bx.lz - 1 ? bx.lz - 1 : k);
-            const float* p = A + sxy * kk;
-            return mk2(p[colA], p[colB]);
+            const auto r = desc(A + sxy * kk, 0);
+            return mk2(at(r, colA), at(r, colB));
         };
         f2 qz[7];
 #pragma unroll
@@ -163,22 +186,23 @@ __global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const floa
             const int gk = k + bx.gz0;
             const bool k_weno = gk > 3 && gk < bx.nz - 4;
             const bool wA = jA && k_weno, wB = jB && k_weno;
-            const float* P = A + sxy * k;
+            const auto P = desc(A + sxy * k, 3); // offset of (col, x+m): col + 4*(m+3)
             const f2 c = qz[3];
             // first-order one-sided differences (subs.f90:657-662), always valid
-            const f2 xm1 = mk2(P[colA - 1], P[colB - 1]), xp1 = mk2(P[colA + 1], P[colB + 1]);
-            const float r2 = P[row[2]], r5 = P[row[5]];
+            const f2 xm1 = mk2(at(P, colA + 8), at(P, colB + 8)), xp1 = mk2(at(P, colA + 16), at(P, colB + 16));
+            const float r2 = at(P, row[2] + 12), r5 = at(P, row[5] + 12);
             f2 a = c - xm1, b = xp1 - c;
             f2 cc = c - mk2(r2, c.x), d = mk2(c.y, r5) - c;
             f2 e = c - qz[2], f = qz[4] - c;
             if (wA || wB) {
                 f2 qx[7], qy[7];
-                qx[0] = mk2(P[colA - 3], P[colB - 3]);
-                qx[1] = mk2(P[colA - 2], P[colB - 2]);
+                qx[0] = mk2(at(P, colA), at(P, colB));
+                qx[1] = mk2(at(P, colA + 4), at(P, colB + 4));
                 qx[2] = xm1, qx[3] = c, qx[4] = xp1;
-                qx[5] = mk2(P[colA + 2], P[colB + 2]);
-                qx[6] = mk2(P[colA + 3], P[colB + 3]);
-                const float r0 = P[row[0]], r1 = P[row[1]], r6 = P[row[6]], r7 = P[row[7]];
+                qx[5] = mk2(at(P, colA + 20), at(P, colB + 20));
+                qx[6] = mk2(at(P, colA + 24), at(P, colB + 24));
+                const float r0 = at(P, row[0] + 12), r1 = at(P, row[1] + 12), r6 = at(P, row[6] + 12),
+                            r7 = at(P, row[7] + 12);
                 qy[0] = mk2(r0, r1), qy[1] = mk2(r1, r2), qy[2] = mk2(r2, c.x), qy[3] = c;
                 qy[4] = mk2(c.y, r5), qy[5] = mk2(r5, r6), qy[6] = mk2(r6, r7);
                 f2 wa, wb, wc, wd, we, wf;
@@ -188,20 +212,17 @@ __global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const floa
                 if (wA) a.x = wa.x, b.x = wb.x, cc.x = wc.x, d.x = wd.x, e.x = we.x, f.x = wf.x;
                 if (wB) a.y = wa.y, b.y = wb.y, cc.y = wc.y, d.y = wd.y, e.y = we.y, f.y = wf.y;
             }
-            const long cidx = sxy * k;
-            {
-                const float S = godunov_f32(c.x, a.x, b.x) + godunov_f32(c.x, cc.x, d.x) + godunov_f32(c.x, e.x, f.x);
-                const float nv = finish_f32(c.x, S, phiS[cidx + colA], dx2, inv_dx, h);
-                Bout[cidx + colA] = nv;
-                const float dl = nv - c.x;
-                acc = __builtin_fmaf(dl, dl, acc);
-            }
+            const f2 sg = mk2(c.x > 0.f ? 1.f : -1.f, c.y > 0.f ? 1.f : -1.f);
+            const f2 S = godunov_f32(sg, a, b) + godunov_f32(sg, cc, d) + godunov_f32(sg, e, f);
+            const auto PS = desc(phiS + sxy * k, 0);
+            const auto PB = desc(Bout + sxy * k, 0);
+            const f2 nv = finish_f32(c, S, mk2(at(PS, colA), two ? at(PS, colB) : 1.f), dx2, inv_dx, h);
+            const f2 dl = nv - c;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nv.x), PB, colA, 0, 0);
+            acc = __builtin_fmaf(dl.x, dl.x, acc);
             if (two) {
-                const float S = godunov_f32(c.y, a.y, b.y) + godunov_f32(c.y, cc.y, d.y) + godunov_f32(c.y, e.y, f.y);
-                const float nv = finish_f32(c.y, S, phiS[cidx + colB], dx2, inv_dx, h);
-                Bout[cidx + colB] = nv;
-                const float dl = nv - c.y;
-                acc = __builtin_fmaf(dl, dl, acc);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nv.y), PB, colB, 0, 0);
+                acc = __builtin_fmaf(dl.y, dl.y, acc);
             }
         }
     }
