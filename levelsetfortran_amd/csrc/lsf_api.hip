@@ -399,7 +399,7 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
         hipLaunchKernelGGL(k_bc<double>, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, dx,
                            part + n_sweep_part, ctl);
         prof_mark(st);
-        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
         prof_mark(st);
         if ((s + 1) % CHECK_EVERY == 0 && s + 1 < max_sweeps) {
             HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
@@ -474,7 +474,7 @@ int reinit_f32_core(float* d_phi, const float* d_phiS_in, int nx, int ny, int nz
         hipLaunchKernelGGL(k_bc<float>, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, (float)dx,
                            part + n_sweep_part, ctl);
         prof_mark(st);
-        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
         prof_mark(st);
         if ((s + 1) % CHECK_EVERY == 0 && s + 1 < max_sweeps) {
             HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
@@ -928,7 +928,7 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
             hipLaunchKernelGGL((k_minmax_fp<2>), gwide, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, stamp, fp_chunks, 0,
                                cap, (const int*)(chg + cap - 1), (int*)nullptr, part, ctl);
             hipLaunchKernelGGL(k_reduce_slices, dim3(256), dim3(256), 0, st, (const double*)part, fp_chunks, part2);
-            hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, (const double*)part2, 256L, den, tol, d_trace,
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, (const double*)part2, 256L, den, tol, d_trace,
                                std::max(iter, 1), ctl);
         } else if (order == LSF_ORDER_GS) {
             const int nplanes = (int)tl->off.size() - 1;
@@ -943,7 +943,7 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
                                ctl);
         }
         if (!fixed_point)
-            hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, n_part, den, tol, d_trace, std::max(iter, 1),
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, part, n_part, den, tol, d_trace, std::max(iter, 1),
                                ctl);
         if (fixed_point && trace_fp) {
             int hc[MM_MAX_FIX + 1] = {0};
@@ -1083,7 +1083,7 @@ int bc_box_impl(const T* d_in, T* d_out, const lsf_box* box, const int lo[3], co
     const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
     hipLaunchKernelGGL(k_bc<T>, grid, dim3(64), 0, st, d_in, d_out, bx, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], (T)dx,
                        part, (const int*)nullptr);
-    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(256), 0, st, part, np, d_sumsq);
+    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(RED_T), 0, st, part, np, d_sumsq);
     HIPCHK(hipGetLastError());
     return LSF_OK;
 }
@@ -1451,7 +1451,7 @@ int lsf_jacobi_sweep_box(const double* d_in, double* d_out, const double* d_phiS
         else LSF_LAUNCH_JAC(false, false);
     }
 #undef LSF_LAUNCH_JAC
-    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(256), 0, st, part, np, d_sumsq);
+    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(RED_T), 0, st, part, np, d_sumsq);
     HIPCHK(hipGetLastError());
     return LSF_OK;
 }
@@ -1519,7 +1519,7 @@ int lsf_jacobi_sweep_box_f32(const float* d_in, float* d_out, const float* d_phi
     else
         hipLaunchKernelGGL((k_reinit_jacobi_f32<false>), grid, dim3(F32_BX, F32_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0],
                            lo[1], lo[2], hi[0], hi[1], hi[2], (float)dx, (float)h, part, (const int*)nullptr);
-    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(256), 0, st, part, np, d_sumsq);
+    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(RED_T), 0, st, part, np, d_sumsq);
     HIPCHK(hipGetLastError());
     return LSF_OK;
 }

@@ -61,13 +61,28 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi
         const int gi = li + bx.gx0, gj = lj + bx.gy0;
         const bool ij_weno = gi > 3 && gi < bx.nx - 4 && gj > 3 && gj < bx.ny - 4;
         const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
-        const long col = li + sx * lj;
+        // Addressing: one buffer descriptor per k-plane (rebuilt on the scalar unit every step; a 1024^3 field is
+        // beyond a descriptor's 4 GB) + the lane's 32-bit byte offset inside the plane: no 64-bit address
+        // arithmetic in the loop, and the x neighbours of a cell arrive as a few wide loads.  The descriptor of the
+        // stencil plane starts 3 doubles early, so x offsets -3..+3 are immediates 0..48 (offsets < 24 are only
+        // used by cells with i >= 4: nothing is ever read below the plane).
+        const unsigned plane_bytes = 8u * (unsigned)sxy, rowb = 8u * (unsigned)sx;
+        const unsigned col = 8u * (unsigned)(li + sx * lj);
+        auto desc = [&](const double* base, int shift) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base) - shift, 0, (int)(plane_bytes + 48u),
+                                                     0x00020000);
+        };
+        auto at = [](__amdgpu_buffer_rsrc_t r, unsigned boff) -> double {
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, boff, 0, 0);
+            return __hiloint2double((int)v.y, (int)v.x);
+        };
         double qz[7];
         // window holds k-3..k+3 of the current cell; clamp reads to the box (values outside the
         // +-1 / +-3 reach of the branch in use are never consumed)
         auto ldz = [&](int k) -> double {
             const int kk = k < 0 ? 0 : (k > bx.lz - 1 ? bx.lz - 1 : k);
-            return A[col + sxy * kk];
+            return at(desc(A + sxy * kk, 0), col);
         };
 #pragma unroll
         for (int m = 0; m < 6; ++m) qz[m + 1] = ldz(k0 - 3 + m);
@@ -77,22 +92,30 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi
             qz[6] = ldz(k + 3);
             const int gk = k + bx.gz0;
             const bool weno_ok = ij_weno && gk > 3 && gk < bx.nz - 4;
-            const long cidx = col + sxy * k;
+            const auto P = desc(A + sxy * k, 3); // (x+m, y+n) of this cell: col + 8*(m+3) + n*rowb
             double qx[7], qy[7];
             if (weno_ok) {
 #pragma unroll
                 for (int m = 0; m < 7; ++m) {
-                    qx[m] = (m == 3) ? qz[3] : A[cidx + (m - 3)];
-                    qy[m] = (m == 3) ? qz[3] : A[cidx + sx * (m - 3)];
+                    qx[m] = (m == 3) ? qz[3] : at(P, col + 8u * (unsigned)m);
+                    qy[m] = (m == 3) ? qz[3] : at(P, col + 24u + (unsigned)(m - 3) * rowb);
                 }
             } else {
 #pragma unroll
                 for (int m = 0; m < 7; ++m) { qx[m] = 0.0; qy[m] = 0.0; }
-                qx[2] = A[cidx - 1]; qx[3] = qz[3]; qx[4] = A[cidx + 1];
-                qy[2] = A[cidx - sx]; qy[3] = qz[3]; qy[4] = A[cidx + sx];
+                qx[2] = at(P, col + 16u); qx[3] = qz[3]; qx[4] = at(P, col + 32u);
+                qy[2] = at(P, col + 24u - rowb); qy[3] = qz[3]; qy[4] = at(P, col + 24u + rowb);
             }
-            const double newv = cell_update<STRICT>(qx, qy, qz, weno_ok, phiS[cidx], dx, inv_dx, floor2, h);
-            Bout[cidx] = newv;
+            const auto PS = desc(phiS + sxy * k, 0);
+            const auto PB = desc(Bout + sxy * k, 0);
+            const double newv = cell_update<STRICT>(qx, qy, qz, weno_ok, at(PS, col), dx, inv_dx, floor2, h);
+            {
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                u2 w;
+                w.x = (unsigned)__double2loint(newv);
+                w.y = (unsigned)__double2hiint(newv);
+                __builtin_amdgcn_raw_buffer_store_b64(w, PB, col, 0, 0);
+            }
             const double dlt = newv - qz[3];
             acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
         }
@@ -164,22 +187,39 @@ __global__ __launch_bounds__(64) void k_bc(const T* __restrict__ A, T* __restric
 // host never has to synchronise per sweep (subs.f90:902-926 / set3d.f90:435-458).
 // ctl[0]=done flag, ctl[1]=sweeps completed, ctl[2]=status (0 ok, 1 NaN)
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_finish(const double* __restrict__ partials, long nPart, double den,
-                                                double tol, double* __restrict__ trace, int trace_cap,
-                                                int* __restrict__ ctl)
+// fixed-order sum of partials[0..nPart) by one block of RED_T threads: thread t adds elements t, t+RED_T, ... in
+// eight independent chains (the loads of a round are all in flight together: a serial chain of ~1 us loads is
+// what made the first version of this kernel cost 50 us), then a tree over the block.  Result valid in thread 0.
+constexpr int RED_T = 1024;
+__device__ __forceinline__ double block_sum(const double* __restrict__ partials, long nPart, double* red)
 {
-    __shared__ double red[256];
-    if (ctl[0]) return;
-    double t = 0.0;
-    for (long p = threadIdx.x; p < nPart; p += 256) t += partials[p];
-    red[threadIdx.x] = t;
+    double t[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+    long p = threadIdx.x;
+    for (; p + 7L * RED_T < nPart; p += 8L * RED_T) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] += partials[p + (long)u * RED_T];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (p + (long)u * RED_T < nPart) t[u] += partials[p + (long)u * RED_T];
+    red[threadIdx.x] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
+    for (int s = RED_T / 2; s >= 1; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
+    return red[0];
+}
+
+__global__ __launch_bounds__(RED_T) void k_finish(const double* __restrict__ partials, long nPart, double den,
+                                                  double tol, double* __restrict__ trace, int trace_cap,
+                                                  int* __restrict__ ctl)
+{
+    __shared__ double red[RED_T];
+    if (ctl[0]) return;
+    const double tot = block_sum(partials, nPart, red);
     if (threadIdx.x == 0) {
-        const double rms = __builtin_sqrt(red[0] / den);
+        const double rms = __builtin_sqrt(tot / den);
         const int n = ctl[1];
         if (n < trace_cap) trace[n] = rms;
         ctl[1] = n + 1;
@@ -189,19 +229,12 @@ __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ parti
 }
 
 // adds the fixed-order sum of the partials to *acc (building block for the decomposed path)
-__global__ __launch_bounds__(256) void k_accumulate(const double* __restrict__ partials, long nPart,
-                                                    double* __restrict__ accum)
+__global__ __launch_bounds__(RED_T) void k_accumulate(const double* __restrict__ partials, long nPart,
+                                                      double* __restrict__ accum)
 {
-    __shared__ double red[256];
-    double t = 0.0;
-    for (long p = threadIdx.x; p < nPart; p += 256) t += partials[p];
-    red[threadIdx.x] = t;
-    __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *accum += red[0];
+    __shared__ double red[RED_T];
+    const double tot = block_sum(partials, nPart, red);
+    if (threadIdx.x == 0) *accum += tot;
 }
 
 // =============================================================================================
