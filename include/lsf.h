@@ -184,7 +184,9 @@ int lsf_unpack_box(double *d_field, const lsf_box *box, const int lo[3], const i
  * becomes 1e-30 (in the unscaled units of the FAST algebra) and the three non-linear weights of a WENO side
  * are formed from q_k / (q_0+q_1+q_2) so that their products stay inside the fp32 range.  Fields are
  * `float` with the layout of the fp64 entry points; dx, h, tol and the RMS trace stay double (the RMS is
- * accumulated in double from fp32 differences).  Checked against the fp64 path within the tolerance
+ * accumulated in double from fp32 differences, and divided by the true product nx*ny*nz: the reference's
+ * INTEGER*4 product, subs.f90:914, which the fp64 entry points reproduce, is negative for the 1536^3 grid of
+ * configuration 5).  Checked against the fp64 path within the tolerance
  * stated in tests/test_gpu_f32.py. */
 int lsf_reinit_f32(float *phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,
                    int *sweeps_done, double *rms_trace, int trace_cap);

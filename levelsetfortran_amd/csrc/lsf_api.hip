@@ -458,7 +458,9 @@ int reinit_f32_core(float* d_phi, const float* d_phiS_in, int nx, int ny, int nz
     const long n_part = n_sweep_part + n_bc_part;
     if ((rc = ws(c.slot[S_PART], (size_t)n_part * sizeof(double)))) return rc;
     double* part = (double*)c.slot[S_PART].p;
-    const double den = rms_denominator(nx, ny, nz);
+    // the reference's INTEGER*4 product nx*ny*nz (subs.f90:914) is negative for the 1536^3 grid of configuration 5
+    // (RMS = NaN, STOP); there is no fp32 reference behaviour to mirror, so the fp32 path divides by the true product
+    const double den = (double)nx * (double)ny * (double)nz;
     const Box bx{nx + 1, ny + 1, nz + 1, 0, 0, 0, nx, ny, nz};
 
     float* bufs[2] = {d_phi, (float*)c.slot[S_PONG].p};

@@ -283,6 +283,9 @@ class DistributedReinit:
         # INTEGER*4 product nx*ny*nz of the GLOBAL grid (subs.f90:914), wrapping like the reference
         nx, ny, nz = block.n
         self.den = float(np.int32(np.uint32((nx * ny * nz) & 0xFFFFFFFF)))
+        if str(getattr(backend, "dtype", "")).endswith("float32"):
+            # fp32 path (BASELINE configuration 5, 1536^3): the wrapped product is negative there; no reference to mirror
+            self.den = float(nx) * float(ny) * float(nz)
 
     # -- halo exchange of field f on the comm stream ------------------------------------------------
     def exchange(self, f):

@@ -9,10 +9,13 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
+# the fp32 Jacobi path (BASELINE configuration 5), same command shape
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_f32" -- python3 bench.py --dtype f32 > "$OUT/bench_f32_under_rocprof.json" 2> "$OUT/trace_f32.log"
 for C in FETCH_SIZE WRITE_SIZE; do
   for M in gs jacobi; do
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_$M" -- python3 bench.py --steps 2 --warmup 0 --mode $M --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/pmc_${C}_$M.log"
   done
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_f32" -- python3 bench.py --steps 2 --warmup 0 --dtype f32 > /dev/null 2> "$OUT/pmc_${C}_f32.log"
 done
 cat > "$OUT/cal.py" <<'PY'
 import sys, torch
@@ -23,6 +26,13 @@ phi = torch.rand((n + 1) ** 3, dtype=torch.float64, device='cuda')
 nb = torch.zeros(phi.numel(), dtype=torch.int32, device='cuda'); sb = torch.zeros_like(nb)
 for _ in range(2):
     L.narrowBand(n, n, n, 0.01, phi, nb, sb)
+# 4 B per lane: k_pack<float> over the whole field reads n floats and writes n floats
+import ctypes
+from levelsetfortran_amd import _lib
+f = torch.rand((n + 1) ** 3, dtype=torch.float32, device='cuda'); g = torch.empty_like(f)
+box = _lib.LsfBox(n + 1, n + 1, n + 1, 0, 0, 0, n, n, n)
+for _ in range(2):
+    _lib.check(_lib.load().lsf_pack_box_f32(f.data_ptr(), ctypes.byref(box), _lib.int3((0, 0, 0)), _lib.int3((n + 1,) * 3), g.data_ptr(), None))
 torch.cuda.synchronize()
 PY
 for C in FETCH_SIZE WRITE_SIZE; do

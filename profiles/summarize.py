@@ -21,14 +21,15 @@ def one(pattern):
     return g[0] if g else None
 
 
-stats = one("trace/**/*kernel_stats.csv")
-if stats:
-    rows = list(csv.DictReader(open(stats)))
-    with open(os.path.join(here, f"{tag}_kernel_stats.csv"), "w") as f:
-        w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"])
-        for r in rows:
-            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]])
+for sub, suffix in (("trace", ""), ("trace_f32", "_f32")):
+    stats = one(f"{sub}/**/*kernel_stats.csv")
+    if stats:
+        rows = list(csv.DictReader(open(stats)))
+        with open(os.path.join(here, f"{tag}_kernel_stats{suffix}.csv"), "w") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"])
+            for r in rows:
+                w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]])
 
 res = {"unit": "bytes per sweep", "N": 512, "note": "sum over the sweep-kernel dispatches of one sweep; counters are in KiB "
        "(rocprofv3 FETCH_SIZE/WRITE_SIZE); fetch_corrected = 2 x fetch_raw (gfx950 wide-read correction, upper bound)"}
@@ -45,15 +46,17 @@ def gs_kernel_name():
     return "k_reinit_gs_box"
 
 
-for mode, kern in (("gs", gs_kernel_name()), ("jacobi", "k_reinit_jacobi")):
+for mode, kern in (("gs", gs_kernel_name()), ("jacobi", "k_reinit_jacobi"), ("f32", "k_reinit_jacobi_f32")):
     entry = {}
+    bytes_per_cell = 12.0 if mode == "f32" else 24.0
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         f = one(f"pmc_{ctr}_{mode}/**/*counter_collection.csv")
         if not f:
             continue
         tot, ndisp = 0.0, 0
         for r in csv.DictReader(open(f)):
-            if kern in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+            hit = kern in r["Kernel_Name"] and (mode == "f32" or "_f32" not in r["Kernel_Name"])
+            if hit and r["Counter_Name"] == ctr:
                 tot += float(r["Counter_Value"])
                 ndisp += 1
         entry[ctr] = {"sum_KiB": tot, "dispatches": ndisp}
@@ -62,7 +65,7 @@ for mode, kern in (("gs", gs_kernel_name()), ("jacobi", "k_reinit_jacobi")):
         fr = entry["FETCH_SIZE"]["sum_KiB"] * 1024 / sweeps
         wr = entry["WRITE_SIZE"]["sum_KiB"] * 1024 / sweeps
         entry["per_sweep"] = {"fetch_raw": fr, "fetch_corrected": 2 * fr, "write": wr, "hbm_raw": fr + wr,
-                              "hbm_corrected": 2 * fr + wr, "algorithmic": 24.0 * 510 ** 3}
+                              "hbm_corrected": 2 * fr + wr, "algorithmic": bytes_per_cell * 510 ** 3}
         traffic[kern] = {"512": 2 * fr + wr}
     res[kern] = entry
 # calibration of the counters on a kernel with a known byte count in the same access width (8 B per lane):
@@ -75,19 +78,30 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         if vals:
             cal[ctr] = {"measured_bytes": vals[-1] * 1024, "true_bytes": 8.0 * 512 ** 3, "ratio": vals[-1] * 1024 / (8.0 * 512 ** 3)}
 res["calibration_k_narrowband_512"] = cal
+# the same for 4 B per lane: k_pack<float> over a 512^3 field moves 4n bytes each way
+cal32 = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = one(f"pmc_{ctr}_cal/**/*counter_collection.csv")
+    if f:
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_pack" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+        if vals:
+            cal32[ctr] = {"measured_bytes": vals[-1] * 1024, "true_bytes": 4.0 * 512 ** 3, "ratio": vals[-1] * 1024 / (4.0 * 512 ** 3)}
+res["calibration_k_pack_f32_512"] = cal32
 if "FETCH_SIZE" in cal:
     # use the measured ratio instead of the blanket x2 for the committed traffic numbers
     for kern in list(traffic):
         e = res[kern]["per_sweep"]
-        e["fetch_calibrated"] = e["fetch_raw"] / cal["FETCH_SIZE"]["ratio"]
-        e["hbm_calibrated"] = e["fetch_calibrated"] + e["write"] / cal.get("WRITE_SIZE", {"ratio": 1.0})["ratio"]
+        cc = cal32 if (kern.endswith("_f32") and "FETCH_SIZE" in cal32) else cal
+        e["fetch_calibrated"] = e["fetch_raw"] / cc["FETCH_SIZE"]["ratio"]
+        e["hbm_calibrated"] = e["fetch_calibrated"] + e["write"] / cc.get("WRITE_SIZE", {"ratio": 1.0})["ratio"]
         traffic[kern] = {"512": e["hbm_calibrated"]}
 json.dump(res, open(os.path.join(here, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 if traffic:
     json.dump(traffic, open(os.path.join(here, "traffic.json"), "w"), indent=1)
-b = os.path.join(out_dir, "bench_under_rocprof.json")
-if os.path.exists(b):
-    lines = [l for l in open(b) if l.startswith("{")]
-    if lines:
-        open(os.path.join(here, f"{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
+for name in ("bench_under_rocprof.json", "bench_f32_under_rocprof.json"):
+    b = os.path.join(out_dir, name)
+    if os.path.exists(b):
+        lines = [l for l in open(b) if l.startswith("{")]
+        if lines:
+            open(os.path.join(here, f"{tag}_{name}"), "w").write(lines[-1])
 print(json.dumps(res)[:1500])

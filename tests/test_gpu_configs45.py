@@ -1,0 +1,88 @@
+"""BASELINE.json configurations 4 and 5 at their full grid sizes, on the one GPU of the test box.
+
+C4: synthetic single-sphere phi0, 1024^3 fp64 (the 4-GPU job's GLOBAL grid) -- Jacobi ordering, STRICT arithmetic.
+C5: synthetic two-sphere phi0, 1536^3 fp32 (the 8-GPU job's GLOBAL grid)   -- Jacobi ordering, fp32 path.
+The oracle cannot sweep such fields, so parity is checked on a block cut through a sphere's surface: after s Jacobi
+sweeps the cells more than 3 s (+4 for the first-order rim of the block's own walls) inside a block depend on that
+block alone, so the oracle run on the block must reproduce them -- bit for bit in fp64, within the stated fp32
+tolerance in fp32.  The multi-GPU decomposition of the same sweep is covered by the gloo / shared-GPU tests
+(bit-identical to the single-domain sweep), so this pins the single-domain sweep at the size those jobs run.
+The fields are built in HBM slab by slab (formulas of SURVEY.md 8d: domain [-1.5,1.5]^3, dx = 3/(N-1),
+phi0 = d/sqrt(d^2+dx^2)).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(N, centers, radius, dtype, slab=64):
+    dev = torch.device("cuda", 0)
+    dx = 3.0 / (N - 1)
+    out = torch.empty((N, N, N), dtype=dtype, device=dev)  # [k][j][i], i fastest
+    ax = -1.5 + dx * torch.arange(N, dtype=torch.float64, device=dev)
+    for k0 in range(0, N, slab):
+        z = ax[k0:k0 + slab]
+        d = None
+        for c in centers:
+            r = ((z[:, None, None] - c[2]) ** 2 + (ax[None, :, None] - c[1]) ** 2 + (ax[None, None, :] - c[0]) ** 2).sqrt_().sub_(radius)
+            d = r if d is None else torch.minimum(d, r)
+        out[k0:k0 + slab] = (d / torch.sqrt(d * d + dx * dx)).to(dtype)
+        del d, r
+    return out, dx
+
+
+def _block(t, lo, w):
+    """(i,j,k)-ordered Fortran numpy copy of the block [lo, lo+w)^3 of a [k][j][i] device tensor"""
+    b = t[lo[2]:lo[2] + w, lo[1]:lo[1] + w, lo[0]:lo[0] + w].cpu().numpy()
+    return np.asfortranarray(b.transpose(2, 1, 0))
+
+
+def test_config4_1024_fp64_single_sphere_block_equals_oracle(oracle):
+    import levelsetfortran_amd as lsf
+    from levelsetfortran_amd import fields
+
+    N, s, w = 1024, 2, 44
+    phi, dx = _build(N, ((0.0, 0.0, 0.0),), 1.0, torch.float64)
+    h = fields.reinit_step(dx)
+    # the sphere's surface crosses the x axis at i = (1.5 - 1.0)/dx = 170.5; centre of the grid in y and z
+    lo = (170 - w // 2, N // 2 - w // 2, N // 2 - w // 2)
+    blk = _block(phi, lo, w)
+    assert blk.min() < 0 < blk.max()
+    flat = phi.reshape(-1)
+    rep = lsf.reinit(flat, None, None, N - 1, N - 1, N - 1, s - 1, dx, h, tol=0.0, order="jacobi", arith="strict")
+    assert rep.count == s and np.isfinite(rep.rms).all()
+    got = _block(phi, lo, w)
+    oracle.reinit(blk, w - 1, w - 1, w - 1, s - 1, dx, h, tol=0.0, order=oracle.JACOBI)
+    a, b = 4 + 3 * s + 1, w - 5 - 3 * s - 1
+    assert np.array_equal(got[a:b, a:b, a:b], blk[a:b, a:b, a:b])
+    lsf._lib.load().lsf_release_workspace()
+
+
+def test_config5_1536_fp32_two_spheres_block_tracks_oracle(oracle):
+    import levelsetfortran_amd as lsf
+    from levelsetfortran_amd import fields
+
+    N, s, w = 1536, 4, 56
+    eps = float(np.finfo(np.float32).eps)
+    phi, dx = _build(N, ((-0.6, 0.0, 0.0), (0.6, 0.0, 0.0)), 0.5, torch.float32)
+    h = fields.reinit_step(dx)
+    # left sphere: surface on the x axis at x = -1.1 -> i = 0.4/dx = 204.7
+    lo = (205 - w // 2, N // 2 - w // 2, N // 2 - w // 2)
+    blk32 = _block(phi, lo, w)
+    assert blk32.dtype == np.float32 and blk32.min() < 0 < blk32.max()
+    flat = phi.reshape(-1)
+    rep = lsf.reinit(flat, None, None, N - 1, N - 1, N - 1, s - 1, dx, h, tol=0.0, order="jacobi")
+    assert rep.count == s and np.isfinite(rep.rms).all()
+    got = _block(phi, lo, w).astype(np.float64)
+    ref = np.asfortranarray(blk32.astype(np.float64))
+    oracle.reinit(ref, w - 1, w - 1, w - 1, s - 1, dx, h, tol=0.0, order=oracle.JACOBI)
+    a, b = 4 + 3 * s + 1, w - 5 - 3 * s - 1
+    err = got[a:b, a:b, a:b] - ref[a:b, a:b, a:b]
+    # fp32 rounding of phi (6e-8 per update) dominates: a few ulp per sweep (tests/test_gpu_f32.py)
+    assert np.abs(err).max() < 4 * s * eps, np.abs(err).max()
+    far = np.abs(ref[a:b, a:b, a:b]) > 4 * s * eps
+    assert np.array_equal(np.signbit(got[a:b, a:b, a:b][far]), np.signbit(ref[a:b, a:b, a:b][far]))
+    assert bool(torch.isfinite(phi).all())
+    lsf._lib.load().lsf_release_workspace()
