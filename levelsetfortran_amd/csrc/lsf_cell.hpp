@@ -270,9 +270,12 @@ __device__ __forceinline__ double axis_godunov(double phic, double dm, double dp
         if (phic > 0.) return fmax2(pa * pa, nb * nb);
         return fmax2(pb * pb, na * na);
     } else {
-        const bool pos = phic > 0.;
-        const double ua = pos ? __builtin_fmax(dm, 0.) : __builtin_fmin(dm, 0.);
-        const double ub = pos ? __builtin_fmin(dp, 0.) : __builtin_fmax(dp, 0.);
+        // with sg = sign(phic): max(max(sg dm, 0)^2, min(sg dp, 0)^2) is both cases of the switch (squares are
+        // even); flipping a sign is one XOR on the high word instead of two selects per operand
+        const unsigned flip = phic > 0. ? 0u : 0x80000000u;
+        const double u = __hiloint2double(__double2hiint(dm) ^ (int)flip, __double2loint(dm));
+        const double v = __hiloint2double(__double2hiint(dp) ^ (int)flip, __double2loint(dp));
+        const double ua = __builtin_fmax(u, 0.), ub = __builtin_fmin(v, 0.);
         return __builtin_fmax(ua * ua, ub * ub);
     }
 }
@@ -298,9 +301,7 @@ __device__ __forceinline__ double finish_update(double phic, double gX, double g
         return phic + h * k1;
     } else {
         const double S = gX + gY + gZ; // unscaled: true value * dx^2
-        const double y = rsqrt_nr(S);
-        double g = S * y;
-        g = __builtin_fma(__builtin_fma(-g, g, S), 0.5 * y, g);
+        const double g = S * rsqrt_nr(S); // sqrt(S) to 4e-15 relative: h (1 - gM) moves phi by < 1e-18 of that
         const double gM = (S > 0. ? g : 0.) * inv_dx;
         const double sgn = pS * rsqrt_nr(__builtin_fma(pS, pS, dx * dx * gM));
         return __builtin_fma(h, sgn * (1. - gM), phic);
