@@ -329,6 +329,8 @@ int check_dims(int nx, int ny, int nz)
 {
     if (nx < 2 || ny < 2 || nz < 2) return fail(LSF_ERR_INVALID, "nx, ny, nz must be >= 2");
     if ((double)(nx + 1) * (ny + 1) * (nz + 1) > 9.0e9) return fail(LSF_ERR_INVALID, "field too large");
+    // the Jacobi kernels address one k-plane through a buffer descriptor with 32-bit byte offsets
+    if ((double)(nx + 1) * (ny + 1) * 8.0 > 2.0e9) return fail(LSF_ERR_INVALID, "a k-plane of the field exceeds 2 GB");
     return LSF_OK;
 }
 
@@ -1033,6 +1035,7 @@ int box_ok(const lsf_box* b, const int lo[3], const int hi[3])
 {
     if (!b || !lo || !hi) return fail(LSF_ERR_INVALID, "NULL box/range");
     if (b->lx < 1 || b->ly < 1 || b->lz < 1) return fail(LSF_ERR_INVALID, "empty box");
+    if ((double)b->lx * b->ly * 8.0 > 2.0e9) return fail(LSF_ERR_INVALID, "a k-plane of the box exceeds 2 GB");
     const int ext[3] = {b->lx, b->ly, b->lz};
     for (int a = 0; a < 3; ++a)
         if (lo[a] < 0 || hi[a] > ext[a]) return fail(LSF_ERR_INVALID, "range outside the local box");

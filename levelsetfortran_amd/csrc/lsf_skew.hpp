@@ -152,49 +152,69 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
         return ps_t[(unsigned)(e_ps.x >> 2) + (unsigned)min(max(e_ps.y + (si > 0 ? t : -t), 0), nx)];
     };
     {
-        constexpr int UM = T::NR / (4 * W);                             // 16 entries of 4 rows per wave instruction
-        constexpr int XC = 6 * T::NCORE, XH = 2 * (T::NR - T::NCORE);   // the remaining 6 (bundle) / 2 (halo) entries
-        constexpr int UX = (XC + XH + NT - 1) / NT;
-        constexpr int NV = UM + UX;
+        // 16 entries of one row per 16 lanes, 4 W rows per load instruction.  Rows are taken CLASS BY CLASS (bundle /
+        // upstream halo / downstream halo) so that everything that depends on the class -- first entry, where the row
+        // lives in the LDS image, whether a value of this sweep has to be fetched from `out` -- is a compile-time
+        // property of the instruction (the class boundaries are not multiples of 4 W rows: the last instruction of a
+        // class re-loads its last row in the lanes that would overshoot, which rewrites the same LDS value).
+        constexpr int RPI = 4 * W;                                        // rows per load instruction
+        constexpr int NB = T::NCORE / RPI;                                // bundle rows: entries 3..18, old values
+        constexpr int NU = (T::YD0 - T::YU0 + RPI - 1) / RPI;             // upstream halo: 2..17, this sweep's inside the interior
+        constexpr int ND = (T::NR - T::YD0 + RPI - 1) / RPI;              // downstream halo: 4..19, old values
+        constexpr int XC = 6 * T::NCORE, XH = 2 * (T::NR - T::NCORE);     // the remaining 6 (bundle) / 2 (halo) entries
+        constexpr int NXC = (XC + NT - 1) / NT, NXH = (XH + NT - 1) / NT;
+        constexpr int NV = NB + NU + ND + NXC + NXH;
         double v[NV];
         int dst[NV];
         const int xx = tid & 15, rsub = tid >> 4;
         int n_ = 0;
+        auto gi_of = [&](int2 e, int k) { return e.y + (si > 0 ? k - 3 : 3 - k); };
+        auto off_of = [&](int2 e, int gi_r) { return (unsigned)(e.x >> 2) + (unsigned)min(max(gi_r, 0), nx); };
 #pragma unroll
-        for (int u = 0; u < UM; ++u, ++n_) {
-            const int r0 = 4 * W * u + 4 * wave, r = 4 * W * u + rsub; // r0: first row of this wave's group (uniform)
+        for (int u = 0; u < NB; ++u, ++n_) {
+            const int r = RPI * u + rsub, k = 3 + xx;
             const int2 e = rowtab[r];
-            // bundle rows: entries 3..18 (old); upstream halo: 2..17 (this sweep's, except wall points); downstream: 4..19
-            const int k = (r0 < T::YU0 ? 3 : (r0 < T::YD0 ? 2 : 4)) + xx;
-            const int gi_r = e.y + (si > 0 ? k - 3 : 3 - k);
-            const unsigned o = (unsigned)(e.x >> 2) + (unsigned)min(max(gi_r, 0), nx);
-            dst[n_] = T::at(r, k);
-            if (r0 >= T::YU0 && r0 < T::YD0) {
-                const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 1);
-                v[n_] = ldp((fresh ? (const double*)out_t : in_t) + o);
-            } else {
-                v[n_] = ldp(in_t + o);
-            }
+            dst[n_] = r * RA + k;
+            v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
         }
 #pragma unroll
-        for (int u = 0; u < UX; ++u, ++n_) {
-            const int idx = min(tid + NT * u, XC + XH - 1);
-            int r, k;
-            if (idx < XC) { // bundle rows: entries 0..2 (previous tile of the row: this sweep's) and 19..21
-                r = idx / 6;
-                const int ee = idx - 6 * r;
-                k = ee < 3 ? ee : TA + ee;
-            } else { // halo rows: entries 0, 1 (upstream) or 20, 21 (downstream)
-                const int hh = idx - XC;
-                r = T::NCORE + (hh >> 1);
-                k = (r < T::YD0 ? 0 : TA + 4) + (hh & 1);
-            }
+        for (int u = 0; u < NU; ++u, ++n_) {
+            const int r = min(T::YU0 + RPI * u + rsub, T::YD0 - 1), k = 2 + xx;
             const int2 e = rowtab[r];
-            const int gi_r = e.y + (si > 0 ? k - 3 : 3 - k);
-            const unsigned o = (unsigned)(e.x >> 2) + (unsigned)min(max(gi_r, 0), nx);
-            const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 2) & (k < 3);
+            const int gi_r = gi_of(e, k);
+            const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 1);
+            dst[n_] = T::NCORE * RA + (r - T::NCORE) * T::RH + k;
+            v[n_] = ldp((fresh ? (const double*)out_t : in_t) + off_of(e, gi_r));
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u, ++n_) {
+            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = 4 + xx;
+            const int2 e = rowtab[r];
+            dst[n_] = T::NCORE * RA + (r - T::NCORE) * T::RH + k - 4;
+            v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
+        }
+#pragma unroll
+        for (int u = 0; u < NXC; ++u, ++n_) { // bundle rows: entries 0..2 (previous tile of the row: this sweep's) and 19..21
+            const int idx = min(tid + NT * u, XC - 1);
+            const int r = idx / 6, ee = idx - 6 * r;
+            const int k = ee < 3 ? ee : TA + ee;
+            const int2 e = rowtab[r];
+            const int gi_r = gi_of(e, k);
+            const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 2) & (ee < 3);
+            dst[n_] = r * RA + k;
+            v[n_] = ldp((fresh ? (const double*)out_t : in_t) + off_of(e, gi_r));
+        }
+#pragma unroll
+        for (int u = 0; u < NXH; ++u, ++n_) { // halo rows: entries 0, 1 (upstream) or 20, 21 (downstream)
+            const int hh = min(tid + NT * u, XH - 1);
+            const int r = T::NCORE + (hh >> 1);
+            const bool upr = r < T::YD0;
+            const int k = (upr ? 0 : TA + 4) + (hh & 1);
+            const int2 e = rowtab[r];
+            const int gi_r = gi_of(e, k);
+            const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 2) & upr;
             dst[n_] = T::at(r, k);
-            v[n_] = ldp((fresh ? (const double*)out_t : in_t) + o);
+            v[n_] = ldp((fresh ? (const double*)out_t : in_t) + off_of(e, gi_r));
         }
 #pragma unroll
         for (int t = 0; t < TA / 2; ++t) ps[t] = ps_load(t);
