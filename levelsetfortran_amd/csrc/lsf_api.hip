@@ -86,6 +86,10 @@ int gs_ny()
 }
 constexpr int MM_TA = 32;      // tile length along i of the exact-GS min/max kernel
 constexpr int CHECK_EVERY = 8; // sweeps between host reads of the device stop flag
+// fp32 sweep: the pure x-face wall points are written by the sweep kernel instead of k_bc (kernel argument `xwall`):
+// k_bc 41 -> 17 us for +8 us in the sweep kernel at 512^3.  Not done for the fp64 kernel: k_bc 48 -> 18 us there, but
+// the sweep kernel itself lost 30-50 us (same bench command, 1.70 -> 1.73..1.75 ms): no net gain.
+constexpr int F32_XWALL = 1;
 
 struct Buf {
     void* p = nullptr;
@@ -399,7 +403,7 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
                                nx, ny, nz, dx, h, part, ctl);
         prof_mark(st);
         hipLaunchKernelGGL(k_bc<double>, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, dx,
-                           part + n_sweep_part, ctl);
+                           part + n_sweep_part, ctl, 0);
         prof_mark(st);
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
         prof_mark(st);
@@ -473,10 +477,10 @@ int reinit_f32_core(float* d_phi, const float* d_phiS_in, int nx, int ny, int nz
         float* B = bufs[(s + 1) & 1];
         prof_mark(st);
         hipLaunchKernelGGL((k_reinit_jacobi_f32<false>), jgrid, dim3(F32_BX, F32_BY), 0, st, A, B, d_phiS, bx, 1, 1, 1, nx,
-                           ny, nz, (float)dx, (float)h, part, ctl);
+                           ny, nz, (float)dx, (float)h, part, ctl, F32_XWALL);
         prof_mark(st);
         hipLaunchKernelGGL(k_bc<float>, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, (float)dx,
-                           part + n_sweep_part, ctl);
+                           part + n_sweep_part, ctl, F32_XWALL);
         prof_mark(st);
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
         prof_mark(st);
@@ -1087,7 +1091,7 @@ int bc_box_impl(const T* d_in, T* d_out, const lsf_box* box, const int lo[3], co
     if ((rc = stream_partials(st, (size_t)np, &part))) return rc;
     const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
     hipLaunchKernelGGL(k_bc<T>, grid, dim3(64), 0, st, d_in, d_out, bx, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], (T)dx,
-                       part, (const int*)nullptr);
+                       part, (const int*)nullptr, 0);
     hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(RED_T), 0, st, part, np, d_sumsq);
     HIPCHK(hipGetLastError());
     return LSF_OK;
@@ -1520,10 +1524,10 @@ int lsf_jacobi_sweep_box_f32(const float* d_in, float* d_out, const float* d_phi
     const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
     if (thinx)
         hipLaunchKernelGGL((k_reinit_jacobi_f32<true>), grid, dim3(F32_BX, F32_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0],
-                           lo[1], lo[2], hi[0], hi[1], hi[2], (float)dx, (float)h, part, (const int*)nullptr);
+                           lo[1], lo[2], hi[0], hi[1], hi[2], (float)dx, (float)h, part, (const int*)nullptr, 0);
     else
         hipLaunchKernelGGL((k_reinit_jacobi_f32<false>), grid, dim3(F32_BX, F32_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0],
-                           lo[1], lo[2], hi[0], hi[1], hi[2], (float)dx, (float)h, part, (const int*)nullptr);
+                           lo[1], lo[2], hi[0], hi[1], hi[2], (float)dx, (float)h, part, (const int*)nullptr, 0);
     hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(RED_T), 0, st, part, np, d_sumsq);
     HIPCHK(hipGetLastError());
     return LSF_OK;

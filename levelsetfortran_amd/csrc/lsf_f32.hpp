@@ -130,7 +130,7 @@ __global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const floa
                                                                       int lo1, int lo2, int hi0, int hi1, int hi2,
                                                                       float dx, float h,
                                                                       double* __restrict__ partials,
-                                                                      const int* __restrict__ done)
+                                                                      const int* __restrict__ done, int xwall)
 {
     __shared__ double red[F32_BX * F32_BY / 64];
     if (done && *done) return;
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const floa
         const bool jA = i_weno && gj > 3 && gj < bx.ny - 4;
         const bool jB = i_weno && two && gj + 1 > 3 && gj + 1 < bx.ny - 4;
         const float inv_dx = 1.0f / dx, dx2 = dx * dx;
+        const bool wave_on_xwall = xwall && __any((int)(gi == 1 || gi == bx.nx - 1)) != 0;
         // the eight rows j-3..j+4 of the pair, clamped to the box (rows beyond the reach of the branch in
         // use are never consumed); offsets relative to the plane
         // Addressing: one buffer descriptor per k-plane (rebuilt on the scalar unit every step; a whole 1536^3
@@ -223,6 +224,22 @@ __global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const floa
             if (two) {
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nv.y), PB, colB, 0, 0);
                 acc = __builtin_fmaf(dl.y, dl.y, acc);
+            }
+            // xwall (single-domain sweeps): the pure x-face wall points beside this pair, see k_reinit_jacobi
+            if (wave_on_xwall && (gi == 1 || gi == bx.nx - 1)) {
+                const f2 wv = nv + splat(dx);
+                for (int side = 0; side < 2; ++side) {
+                    if (side == 0 ? gi != 1 : gi != bx.nx - 1) continue;
+                    const f2 old = side == 0 ? xm1 : xp1;
+                    const f2 wd = wv - old;
+                    const unsigned sh = side == 0 ? (unsigned)-4 : 4u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wv.x), PB, colA + sh, 0, 0);
+                    acc = __builtin_fmaf(wd.x, wd.x, acc);
+                    if (two) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wv.y), PB, colB + sh, 0, 0);
+                        acc = __builtin_fmaf(wd.y, wd.y, acc);
+                    }
+                }
             }
         }
     }

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi
 template <typename T>
 __global__ __launch_bounds__(64) void k_bc(const T* __restrict__ A, T* __restrict__ Bout, Box bx,
                                            int lo0, int lo1, int lo2, int hi0, int hi1, int hi2, T dx,
-                                           double* __restrict__ partials, const int* __restrict__ done)
+                                           double* __restrict__ partials, const int* __restrict__ done,
+                                           int skip_xface)
 {
     if (done && *done) return;
     const int face = blockIdx.z; // 0:i=0 1:i=nx 2:j=0 3:j=ny 4:k=0 5:k=nz
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(64) void k_bc(const T* __restrict__ A, T* __restric
         const bool wi = gi == 0 || gi == bx.nx, wj = gj == 0 || gj == bx.ny, wk = gk == 0 || gk == bx.nz;
         // ownership: x faces own everything on them; y faces skip points on x walls; z faces skip
         // points on x or y walls
-        const bool own = axis == 0 || (axis == 1 && !wi) || (axis == 2 && !wi && !wj);
+        // skip_xface: the sweep kernel has written the pure x-face points (k_reinit_jacobi_f32, xwall)
+        const bool own = (axis == 0 && !(skip_xface && !wj && !wk)) || (axis == 1 && !wi) || (axis == 2 && !wi && !wj);
         if (own) {
             const int nb = (int)wi + (int)wj + (int)wk;
             const int nh = (int)(gi == bx.nx) + (int)(gj == bx.ny) + (int)(gk == bx.nz);
