@@ -128,8 +128,8 @@ def cpu_baseline(n: int, slab: int = 20, sweeps: int = 8):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--mode", choices=("gs", "jacobi"), default="gs")
     ap.add_argument("--arith", choices=("fast", "strict"), default="fast")
     ap.add_argument("--size", type=int, default=512, help="points per axis (per GPU)")

@@ -105,7 +105,7 @@ struct TileList {
 // dataflow schedule of the exact ordering: tiles of a batch of sweeps in slot order, per-sweep table, hyperplane sizes
 struct BatchPlan {
     uint2* d_order = nullptr;
-    int* d_aux = nullptr; // [4 * 32] {sign i, j, k, spacing} per sweep, then [np] tiles per hyperplane
+    int* d_aux = nullptr; // [4 * DF_BATCH] {sign i, j, k, spacing} per sweep, then [np] tiles per hyperplane
     long total = 0;
 };
 
@@ -625,13 +625,14 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     prof_mark(st);
     long launches = 0;
     if (persist && skew) {
-        // Dataflow schedule (k_reinit_gs_persist): one launch per batch of up to 32 sweeps, one block per tile,
+        // Dataflow schedule (k_reinit_gs_persist): one launch per batch of up to DF_BATCH = 64 sweeps, one block per tile,
         // dependencies resolved in the kernel.  The batch plan (tiles in slot order, spacing table) depends on the grid,
         // the raster phase of the batch's first sweep and the number of sweeps only, and is cached on the device.
         const long ntiles = tl->off[np];
-        // sweeps per launch: 32 (the sweep index has 5 bits in the task word), fewer on very large grids so that the
-        // task list stays below 256 MB; a multiple of 8 keeps the raster phase, hence the cached plan, the same
-        const int BATCH = (int)std::max<long>(8, std::min<long>(32, (256L << 20) / (ntiles * 8) / 8 * 8));
+        // sweeps per launch: 64 (a batch costs about one sweep time of fill and drain, measured 26.6 / 50.0 / 73.9 /
+        // 97.4 ms for 8 / 16 / 24 / 32 sweeps at 512^3), fewer on very large grids so that the task list stays below
+        // 512 MB; a multiple of 8 keeps the raster phase, hence the cached plan, the same
+        const int BATCH = (int)std::max<long>(8, std::min<long>(DF_BATCH, (512L << 20) / (ntiles * 8) / 8 * 8));
         const int nM = (nx - 2 + nyc * nTj - 1 + nzc * nTk - 1) / ta + 1; // m_max + 1 (get_skew_tiles)
         const size_t tile_flags = (size_t)BATCH * nM * nTj * nTk;
         if ((rc = ws(c.slot[S_PLANECNT], ((size_t)BATCH * np + BATCH + 16) * sizeof(int)))) return rc;
@@ -652,7 +653,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
                 BatchPlan bp;
                 std::vector<uint32_t> h_tiles((size_t)ntiles);
                 HIPCHK(hipMemcpy(h_tiles.data(), tl->d, (size_t)ntiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                std::vector<int> h_aux(4 * 32 + np, 0); // sweep table, then tiles per hyperplane
+                std::vector<int> h_aux(4 * DF_BATCH + np, 0); // sweep table, then tiles per hyperplane
                 std::vector<long> st0(ns, 0);
                 for (int q = 0; q < ns; ++q) {
                     const int* db = RASTER_SIGN[(phase + q) & 7];
@@ -663,7 +664,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
                     st0[q] = st0[q - 1] + H;
                     if (q >= 3) st0[q] = std::max(st0[q], st0[q - 3] + np + 1); // list order respects condition (c)
                 }
-                for (int P = 0; P < np; ++P) h_aux[4 * 32 + P] = tl->off[P + 1] - tl->off[P];
+                for (int P = 0; P < np; ++P) h_aux[4 * DF_BATCH + P] = tl->off[P + 1] - tl->off[P];
                 // the entries of the batch in slot order (what the slot schedule would launch, launch after launch)
                 std::vector<uint2> order;
                 order.reserve((size_t)ns * ntiles);
@@ -673,7 +674,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
                         const long P = slot - st0[q];
                         if (P >= np) continue;
                         for (int i = tl->off[P]; i < tl->off[P + 1]; ++i)
-                            order.push_back(make_uint2(h_tiles[i], (unsigned)q | ((unsigned)P << 5)));
+                            order.push_back(make_uint2(h_tiles[i], (unsigned)q | ((unsigned)P << DF_SWEEP_BITS)));
                     }
                     while (lo_s < ns && st0[lo_s] + np <= slot + 1) ++lo_s;
                 }
@@ -688,7 +689,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             HIPCHK(hipMemsetAsync(d_cnt, 0, ((size_t)BATCH * np + BATCH + 16) * sizeof(int), st)); // counters, ticket
             HIPCHK(hipMemsetAsync(c.slot[S_BFLAG].p, 0, (size_t)ns * nM * nTj * nTk * sizeof(int), st));
             if (d_dbg) HIPCHK(hipMemsetAsync(d_dbg, 0, 64, st));
-            fa.sweep_tab = bp.d_aux, fa.plane_size = bp.d_aux + 4 * 32;
+            fa.sweep_tab = bp.d_aux, fa.plane_size = bp.d_aux + 4 * DF_BATCH;
             fa.order = bp.d_order, fa.total = bp.total;
             fa.nsweeps = ns, fa.g0 = g0, fa.np = np;
             fa.plane_cnt = d_cnt, fa.planes_done = d_done, fa.ticket = d_ticket;

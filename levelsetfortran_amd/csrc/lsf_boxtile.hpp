@@ -22,13 +22,16 @@
 
 namespace lsf {
 
+// dataflow launch: sweeps per batch (the sweep index s of a task shares a word with its hyperplane P)
+constexpr int DF_SWEEP_BITS = 6, DF_BATCH = 1 << DF_SWEEP_BITS;
+
 struct GsArgs {
     double* buf[3];     // sweep g reads buf[g % nbuf] and writes buf[(g + 1) % nbuf]
     int nbuf;           // 3: three sweeps in flight (reinit_slot_core)
     const double* phiS;
     int nx, ny, nz, nTi, nTj, nTk;
     double dx, h;
-    const uint2* order; // dataflow launch: task list in slot order, {packed tile, s | P << 5}
+    const uint2* order; // dataflow launch: task list in slot order, {packed tile, s | P << DF_SWEEP_BITS}
     long total;
     int nsweeps;        // sweeps in this batch
     int g0;             // global index of the first sweep of the batch

@@ -371,7 +371,7 @@ template <int TA, int WY, int WZ, bool STRICT>
 __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY == 2 && WZ == 2 ? 5 : 1))) void k_reinit_gs_persist(GsArgs a)
 {
     using T = SkTile<TA, WY, WZ>;
-    __shared__ int sh_task[8]; // packed tile, s | P << 5, go flag, raster signs of the sweep
+    __shared__ int sh_task[8]; // packed tile, s | P << DF_SWEEP_BITS, go flag, raster signs of the sweep
     const int tid = threadIdx.x;
     const int np = a.np;
     const int nM = a.nM;                       // tile_done[s] is indexed m + nM * (B + nTj * C)
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
             uint2 e = make_uint2(0u, 0u);
             if (t < a.total) {
                 e = a.order[t];
-                const int s = (int)(e.y & 31u), P = (int)(e.y >> 5);
+                const int s = (int)(e.y & (unsigned)(DF_BATCH - 1)), P = (int)(e.y >> DF_SWEEP_BITS);
                 const int m = e.x & 0x3ff, B = (e.x >> 10) & 0x3ff, C = (e.x >> 20) & 0x3ff;
                 auto m_lo = [&](int B_, int C_) { return (T::NYT * B_ + T::NZT * C_) / TA; };
                 auto m_hi = [&](int B_, int C_) { return (T::NYT * B_ + T::NYT - 1 + T::NZT * C_ + T::NZT - 1 + a.nx - 2) / TA; };
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
         auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
         const uint32_t packed = (uint32_t)uni(sh_task[0]);
         const int sP = uni(sh_task[1]), go = uni(sh_task[2]);
-        const int s = sP & 31, P = (int)((unsigned)sP >> 5);
+        const int s = sP & (DF_BATCH - 1), P = (int)((unsigned)sP >> DF_SWEEP_BITS);
         if (go == 0) return;
         const unsigned long long tsB = __builtin_amdgcn_s_memrealtime();
         if (go == 1) {
