@@ -70,3 +70,49 @@ def test_halo_plan_is_symmetric():
 def test_block_too_thin_is_rejected():
     with pytest.raises(ValueError):
         D.make_block(0, (8, 1, 1), (30, 30, 30))
+
+
+def test_device_field_builder_matches_numpy_and_slices():
+    """fields.two_sphere_phi0_device (used by bench.py to build every rank's block in HBM) on the CPU device: equal to
+    the numpy formula to rounding, and a `ranges` block is exactly the slice of the whole field."""
+    import torch
+
+    from levelsetfortran_amd import fields
+
+    npts = (21, 18, 15)
+    whole, dx = fields.two_sphere_phi0_device(npts, torch.device("cpu"))
+    host, dx2 = fields.two_sphere_phi0(npts)
+    assert dx == dx2
+    w = whole.reshape(npts[2], npts[1], npts[0])
+    assert np.allclose(w.numpy().transpose(2, 1, 0), host, rtol=0, atol=1e-14)
+    rng = ((3, 17), (0, 9), (4, 15))
+    part, _ = fields.two_sphere_phi0_device(npts, torch.device("cpu"), ranges=rng)
+    part = part.reshape(rng[2][1] - rng[2][0], rng[1][1] - rng[1][0], rng[0][1] - rng[0][0])
+    assert torch.equal(part, w[rng[2][0]:rng[2][1], rng[1][0]:rng[1][1], rng[0][0]:rng[0][1]])
+
+
+def test_rms_denominator_of_the_decomposed_loop():
+    """fp64: the reference's INTEGER*4 product nx*ny*nz, wrapping (subs.f90:914); fp32 (no reference): the true product,
+    because the wrapped one is negative on the 1536^3 grid of BASELINE configuration 5."""
+    import torch
+
+    class _Backend:
+        host_staging = False
+
+        def __init__(self, dtype):
+            self.dtype = dtype
+
+        def empty(self, n, dtype=None):
+            return torch.empty(n, dtype=dtype or self.dtype)
+
+        def zeros(self, n):
+            return torch.zeros(n, dtype=torch.float64)
+
+    n = (1535, 1535, 1535)
+    b = D.make_block(0, (1, 1, 1), n)
+    d64 = D.DistributedReinit(_Backend(torch.float64), b, 1e-3, 1e-5)
+    d32 = D.DistributedReinit(_Backend(torch.float32), b, 1e-3, 1e-5)
+    assert d64.den == float(np.int32(np.uint32((1535 ** 3) & 0xFFFFFFFF))) and d64.den < 0
+    assert d32.den == 1535.0 ** 3
+    small = D.make_block(0, (1, 1, 1), (61, 61, 61))
+    assert D.DistributedReinit(_Backend(torch.float64), small, 1e-3, 1e-5).den == 61.0 ** 3
