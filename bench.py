@@ -169,14 +169,25 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # test aid (LSF_BENCH_SHARED_GPU=1): all ranks share GPU 0 and talk over gloo, so that the N > 1 control flow of this
+    # file can be rehearsed on a one-GPU box (RCCL refuses two ranks on one device); never a measurement
+    shared_gpu = os.environ.get("LSF_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if shared_gpu:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize(dev)
 
     lib = _lib.load()
@@ -187,7 +198,7 @@ def main() -> None:
     if args.mode == "jacobi" and world > 1:
         from levelsetfortran_amd import distributed as lsd
 
-        res = lsd.bench_weak_scaling(N, K, W, dev, arith=args.arith, dtype=args.dtype)
+        res = lsd.bench_weak_scaling(N, K, W, dev, arith=args.arith, dtype=args.dtype, shared_gpu=shared_gpu)
         cells_total, seconds, prof, parallelism = res["cells_total"], res["seconds"], res["prof"], res["parallelism"]
         order = "jacobi"
     else:
@@ -373,7 +384,7 @@ def main() -> None:
         watchdog.start()
         try:
             del phi, phi0, phiS
-            r = lsd.bench_weak_scaling(N, K, W, dev, arith=args.arith)
+            r = lsd.bench_weak_scaling(N, K, W, dev, arith=args.arith, shared_gpu=shared_gpu)
             t = torch.tensor([r["seconds"]], device=dev, dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)

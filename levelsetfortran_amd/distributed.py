@@ -364,7 +364,7 @@ class DistributedReinit:
 
 
 # ------------------------------------------------------------------------------------------------
-def bench_weak_scaling(N: int, K: int, W: int, device, arith: str = "fast", dtype: str = "f64"):
+def bench_weak_scaling(N: int, K: int, W: int, device, arith: str = "fast", dtype: str = "f64", shared_gpu: bool = False):
     """bench.py --mode jacobi --gpus >1: every rank owns an N^3-point block of a (Px N, Py N, Pz N) grid."""
     import time
 
@@ -378,14 +378,17 @@ def bench_weak_scaling(N: int, K: int, W: int, device, arith: str = "fast", dtyp
 
     def barrier():
         if live:
-            dist.barrier(device_ids=[device.index])
+            if shared_gpu:  # rehearsal on one GPU over gloo (bench.py LSF_BENCH_SHARED_GPU)
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[device.index])
         torch.cuda.synchronize(device)
 
     dims = default_dims(world)
     gpts = tuple(d * N for d in dims)
     n = tuple(g - 1 for g in gpts)
     b = make_block(rank, dims, n)
-    be = HipBackend(device, arith, dtype=dtype)
+    be = HipBackend(device, arith, host_staging=shared_gpu, dtype=dtype)
     rng = tuple((g, g + e) for g, e in zip(b.g0, b.ext))
     phi, dx = fields.two_sphere_phi0_device(gpts, device, ranges=rng)  # built in HBM: no host temporaries
     phi = phi.to(be.dtype)

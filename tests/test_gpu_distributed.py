@@ -89,3 +89,26 @@ def test_device_field_block_is_a_slice_of_the_whole_field():
     assert torch.equal(part, whole[rng[2][0]:rng[2][1], rng[1][0]:rng[1][1], rng[0][0]:rng[0][1]])
     host, _ = fields.two_sphere_phi0(npts)
     assert np.allclose(whole.cpu().numpy().transpose(2, 1, 0), host, rtol=0, atol=1e-14)
+
+
+def test_bench_multi_rank_control_flow_on_one_gpu():
+    """bench.py --gpus 2 under torch.distributed.run, both ranks sharing this box's GPU over gloo (LSF_BENCH_SHARED_GPU:
+    RCCL refuses two ranks on one device).  Not a measurement: it checks that the N > 1 path prints exactly one JSON
+    line with the whole-job aggregate and the block-decomposed secondary measurement."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, LSF_BENCH_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "96", "--steps", "4",
+           "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
+    cells = 2 * 4 * 94.0 ** 3
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 4 - cells) < 1e-6 * cells  # value = cells of ALL ranks / time
+    jd = d["jacobi_decomposed"]
+    assert jd["value"] > 0 and jd["global_grid"] == [192, 96, 96]
