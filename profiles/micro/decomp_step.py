@@ -1,0 +1,36 @@
+"""Compute-side cost of ONE decomposed sweep of rank (0,0,0) of a 2x2x2 decomposition (512^3 owned + ghosts) on one GPU:
+the real DistributedReinit.sweep with the message exchange replaced by its pack / unpack kernels only (no peers here).
+Tells how far the block-decomposed sweep is from the single-domain sweep before any network time."""
+import sys, time, torch
+sys.path.insert(0, '.')
+from levelsetfortran_amd import distributed as lsd, fields
+dev = torch.device('cuda', 0)
+for dtype in ('f64', 'f32'):
+    N = 1024
+    b = lsd.make_block(0, (2, 2, 2), (N - 1, N - 1, N - 1))
+    be = lsd.HipBackend(dev, dtype=dtype)
+    dx = 3.0 / (N - 1); h = fields.reinit_step(dx)
+    dr = lsd.DistributedReinit(be, b, dx, h)
+    def fake_exchange(f):  # pack + unpack on the comm stream, no transport
+        be.wait(be.comm, be.compute)
+        with be.stream_ctx(be.comm):
+            for (peer, s_box, _r, _a, _s), sb in zip(dr.plan, dr.send_bufs): be.pack(f, b, s_box, sb, be.comm)
+            for (peer, _s, r_box, _a, _sd), rb in zip(dr.plan, dr.recv_bufs): be.unpack(f, b, r_box, rb, be.comm)
+    dr.exchange = fake_exchange
+    n = b.npoints_local()
+    a = (torch.rand(n, dtype=torch.float64, device=dev) * 0.1).to(be.dtype)
+    bufs = [a, a.clone()]; ps = a.clone()
+    def steps(k):
+        for s in range(k):
+            dr.sweep(bufs[s & 1], bufs[(s + 1) & 1], ps); dr.rms_async()
+    steps(4); torch.cuda.synchronize()
+    t0 = time.perf_counter(); steps(16); torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 16 * 1e3
+    # the single-domain sweep of the same number of owned cells
+    import levelsetfortran_amd as lsf
+    M = 512
+    f = (torch.rand(M ** 3, dtype=torch.float64, device=dev) * 0.1).to(be.dtype)
+    lsf.reinit(f, None, None, M - 1, M - 1, M - 1, 3, dx, h, tol=0.0, order='jacobi'); torch.cuda.synchronize()
+    t0 = time.perf_counter(); lsf.reinit(f, None, None, M - 1, M - 1, M - 1, 15, dx, h, tol=0.0, order='jacobi'); torch.cuda.synchronize()
+    ms1 = (time.perf_counter() - t0) / 16 * 1e3
+    print(dtype, 'decomposed step (rank 0 of 2x2x2, 512^3 owned):', round(ms, 3), 'ms; single-domain 512^3 step:', round(ms1, 3), 'ms')
