@@ -136,7 +136,8 @@ __device__ __forceinline__ double rcp_nr(double x)
 }
 
 // One axis, unscaled: returns dm*dx and dp*dx (the caller multiplies by 1/dx once).
-// floor2 = 1e-99 * dx^2 / 13 (the reference's epsilon floor in unscaled units, /13 like the IS).
+// floor2 = 1e-99 * dx^2 / 13 (the reference's epsilon floor in unscaled units; the function works with IS / 3 and
+// eps / 3 and rescales the floor itself).
 //
 // Algebra used (same mathematics as subs.f90:509-552, fewer operations):
 //  * the six smoothness indicators need only four distinct differences of second differences,
@@ -153,11 +154,12 @@ __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2,
     const double d3 = q[4] - q[3], d4 = q[5] - q[4], d5 = q[6] - q[5];
     // second differences (am,bm,cp,bp,ap)*dx
     const double am = d1 - d0, bm = d2 - d1, cp = d3 - d2, bp = d4 - d3, ap = d5 - d4;
-    // the four distinct differences and their squares
+    // the four distinct differences; their squares carry the factor 13/3, so that an indicator is one FMA:
+    // IS_k * 13/3 = (13/3) e^2 + t^2 (epsilon is scaled alike, the weights are ratios)
     const double e_ab = ap - bp, e_bc = bp - cp, e_cm = cp - bm, e_mm = am - bm;
-    const double s_ab = e_ab * e_ab, s_bc = e_bc * e_bc, s_cm = e_cm * e_cm, s_mm = e_mm * e_mm;
-    constexpr double K = 3.0 / 13.0;
-    auto isf = [](double sq, double t) { return __builtin_fma(K * t, t, sq); }; // (13 e^2 + 3 t^2)/13
+    constexpr double C = 13.0 / 3.0;
+    const double s_ab = (C * e_ab) * e_ab, s_bc = (C * e_bc) * e_bc, s_cm = (C * e_cm) * e_cm, s_mm = (C * e_mm) * e_mm;
+    auto isf = [](double sq, double t) { return __builtin_fma(t, t, sq); }; // (13 e^2 + 3 t^2)/3
     const double IS0p = isf(s_ab, __builtin_fma(-3.0, bp, ap));
     const double IS1p = isf(s_bc, bp + cp);
     const double IS2p = isf(s_cm, __builtin_fma(3.0, cp, -bm));
@@ -165,17 +167,18 @@ __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2,
     const double IS1m = isf(s_cm, bm + cp);
     const double IS2m = isf(s_bc, __builtin_fma(3.0, cp, -bp));
 
-    // eps = 1e-6 max(p^2) + 1e-99 (subs.f90:533-534), in unscaled units and divided by 13 like the IS;
-    // max of squares = square of the max magnitude (|x| is a free source modifier)
+    // eps = 1e-6 max(p^2) + 1e-99 (subs.f90:533-534), in unscaled units and times 1/3 like the IS (floor2 is the
+    // floor divided by 13: times 13/3 here); max of squares = square of the max magnitude (|x| is a free modifier)
     const double mid = __builtin_fmax(__builtin_fmax(__builtin_fabs(d1), __builtin_fabs(d2)),
                                       __builtin_fmax(__builtin_fabs(d3), __builtin_fabs(d4)));
     const double mp = yquirk ? mid : __builtin_fmax(mid, __builtin_fabs(d5));
     const double mm = __builtin_fmax(mid, __builtin_fabs(d0));
-    const double epsp = __builtin_fma((1.E-6 / 13.0) * mp, mp, floor2);
-    const double epsm = __builtin_fma((1.E-6 / 13.0) * mm, mm, floor2);
+    const double fl = C * floor2;
+    const double epsp = __builtin_fma((1.E-6 / 3.0) * mp, mp, fl);
+    const double epsm = __builtin_fma((1.E-6 / 3.0) * mm, mm, fl);
 
     const double S0 = e_bc - e_cm;  // bp - 2cp + bm   (= b-2c+d on both sides)
-    const double S12 = S0 * (1.0 / 12.0);
+    const double S12 = S0 * (1.0 / 12.0), S0h = S0 * 0.5;
     double PWp, PWm;
     {
         const double q0 = epsp + IS0p, q1 = epsp + IS1p, q2 = epsp + IS2p;
@@ -184,7 +187,7 @@ __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2,
         const double D = __builtin_fma(3.0, m2, __builtin_fma(6.0, n1, n0));
         const double r = rcp_nr(__builtin_fmax(D, 1e-300));
         const double Sa = e_ab - e_bc; // ap - 2bp + cp
-        PWp = __builtin_fma(r, __builtin_fma(n0 * (1.0 / 3.0), Sa, (m2 * 0.5) * S0), -S12);
+        PWp = __builtin_fma(r, __builtin_fma(n0 * (1.0 / 3.0), Sa, m2 * S0h), -S12);
     }
     {
         const double q0 = epsm + IS0m, q1 = epsm + IS1m, q2 = epsm + IS2m;
@@ -193,11 +196,11 @@ __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2,
         const double D = __builtin_fma(3.0, m2, __builtin_fma(6.0, n1, n0));
         const double r = rcp_nr(__builtin_fmax(D, 1e-300));
         const double Sa = e_mm + e_cm; // am - 2bm + cp = (am-bm) - (bm-cp)
-        PWm = __builtin_fma(r, __builtin_fma(n0 * (1.0 / 3.0), Sa, (m2 * 0.5) * S0), -S12);
+        PWm = __builtin_fma(r, __builtin_fma(n0 * (1.0 / 3.0), Sa, m2 * S0h), -S12);
     }
-    const double cen = (1.0 / 12.0) * (7.0 * (d2 + d3) - (d1 + d4));
-    dm = cen - PWm;
-    dp = cen + PWp;
+    const double cen12 = __builtin_fma(7.0, d2 + d3, -(d1 + d4));
+    dm = __builtin_fma(1.0 / 12.0, cen12, -PWm);
+    dp = __builtin_fma(1.0 / 12.0, cen12, PWp);
 }
 
 template <bool STRICT>

@@ -49,8 +49,8 @@ __device__ __forceinline__ f2 pow2_inv(f2 x)
     return mk2(__uint_as_float(a), __uint_as_float(b));
 }
 
-// One WENO side from the normalised q's: returns r * (n0/3 * Sa + m2/2 * S0) - S0/12  (see weno_axis_fast).
-__device__ __forceinline__ f2 weno_side_f32(f2 q0, f2 q1, f2 q2, f2 Sa, f2 S0, f2 S12)
+// One WENO side from the normalised q's: returns r * (n0/3 * Sa + m2 * S0/2) - S0/12  (see weno_axis_fast).
+__device__ __forceinline__ f2 weno_side_f32(f2 q0, f2 q1, f2 q2, f2 Sa, f2 S0h, f2 S12)
 {
     const f2 s = pow2_inv(q0 + q1 + q2); // q_k * s < 2, the largest >= 1/3
     q0 *= s, q1 *= s, q2 *= s;
@@ -58,7 +58,7 @@ __device__ __forceinline__ f2 weno_side_f32(f2 q0, f2 q1, f2 q2, f2 Sa, f2 S0, f
     const f2 n0 = t12 * t12, n1 = t02 * t02, m2 = t01 * t01;
     const f2 D = fma2(splat(3.0f), m2, fma2(splat(6.0f), n1, n0));
     const f2 r = rcp2(D);
-    return fma2(r, fma2(n0 * splat(1.0f / 3.0f), Sa, (m2 * splat(0.5f)) * S0), -S12);
+    return fma2(r, fma2(n0 * splat(1.0f / 3.0f), Sa, m2 * S0h), -S12);
 }
 
 // One axis for the two cells of a lane, unscaled like weno_axis_fast: returns dm*dx and dp*dx.
@@ -69,9 +69,10 @@ __device__ __forceinline__ void weno_axis_f32(const f2 q[7], bool yquirk, f2& dm
     const f2 d3 = q[4] - q[3], d4 = q[5] - q[4], d5 = q[6] - q[5];
     const f2 am = d1 - d0, bm = d2 - d1, cp = d3 - d2, bp = d4 - d3, ap = d5 - d4;
     const f2 e_ab = ap - bp, e_bc = bp - cp, e_cm = cp - bm, e_mm = am - bm;
-    const f2 s_ab = e_ab * e_ab, s_bc = e_bc * e_bc, s_cm = e_cm * e_cm, s_mm = e_mm * e_mm;
-    const f2 K = splat(3.0f / 13.0f), three = splat(3.0f);
-    auto isf = [&](f2 sq, f2 t) { return fma2(K * t, t, sq); }; // (13 e^2 + 3 t^2)/13
+    // squares carry 13/3 so that an indicator is one FMA: IS_k / 3 = (13/3) e^2 + t^2 (epsilon scaled alike)
+    const f2 C = splat(13.0f / 3.0f), three = splat(3.0f);
+    const f2 s_ab = (C * e_ab) * e_ab, s_bc = (C * e_bc) * e_bc, s_cm = (C * e_cm) * e_cm, s_mm = (C * e_mm) * e_mm;
+    auto isf = [&](f2 sq, f2 t) { return fma2(t, t, sq); }; // (13 e^2 + 3 t^2)/3
     const f2 IS0p = isf(s_ab, fma2(-three, bp, ap));
     const f2 IS1p = isf(s_bc, bp + cp);
     const f2 IS2p = isf(s_cm, fma2(three, cp, -bm));
@@ -82,17 +83,17 @@ __device__ __forceinline__ void weno_axis_f32(const f2 q[7], bool yquirk, f2& dm
     const f2 mid = max2(max2(abs2(d1), abs2(d2)), max2(abs2(d3), abs2(d4)));
     const f2 mp = yquirk ? mid : max2(mid, abs2(d5));
     const f2 mm = max2(mid, abs2(d0));
-    const f2 E = splat(1.E-6f / 13.0f), fl = splat(LSF_F32_FLOOR);
+    const f2 E = splat(1.E-6f / 3.0f), fl = splat(LSF_F32_FLOOR);
     const f2 epsp = fma2(E * mp, mp, fl);
     const f2 epsm = fma2(E * mm, mm, fl);
 
     const f2 S0 = e_bc - e_cm;
-    const f2 S12 = S0 * splat(1.0f / 12.0f);
-    const f2 PWp = weno_side_f32(epsp + IS0p, epsp + IS1p, epsp + IS2p, e_ab - e_bc, S0, S12);
-    const f2 PWm = weno_side_f32(epsm + IS0m, epsm + IS1m, epsm + IS2m, e_mm + e_cm, S0, S12);
-    const f2 cen = splat(1.0f / 12.0f) * (splat(7.0f) * (d2 + d3) - (d1 + d4));
-    dm = cen - PWm;
-    dp = cen + PWp;
+    const f2 S12 = S0 * splat(1.0f / 12.0f), S0h = S0 * splat(0.5f);
+    const f2 PWp = weno_side_f32(epsp + IS0p, epsp + IS1p, epsp + IS2p, e_ab - e_bc, S0h, S12);
+    const f2 PWm = weno_side_f32(epsm + IS0m, epsm + IS1m, epsm + IS2m, e_mm + e_cm, S0h, S12);
+    const f2 cen12 = fma2(splat(7.0f), d2 + d3, -(d1 + d4));
+    dm = fma2(splat(1.0f / 12.0f), cen12, -PWm);
+    dp = fma2(splat(1.0f / 12.0f), cen12, PWp);
 }
 
 // Godunov term of one axis for the pair (subs.f90:684-692), unscaled one-sided differences.  With
