@@ -304,7 +304,11 @@ __device__ __forceinline__ double finish_update(double phic, double gX, double g
         return phic + h * k1;
     } else {
         const double S = gX + gY + gZ; // unscaled: true value * dx^2
-        const double g = S * rsqrt_nr(S); // sqrt(S) to 4e-15 relative: h (1 - gM) moves phi by < 1e-18 of that
+        // sqrt(S) = S y0 refined once with the residual (y0 = v_rsq_f64, 5e-8 relative -> ~1e-15): h (1 - gM) moves
+        // phi by < 1e-18 of that
+        const double y0 = __builtin_amdgcn_rsq(S);
+        const double g0 = S * y0;
+        const double g = __builtin_fma(__builtin_fma(-g0, g0, S), 0.5 * y0, g0);
         const double gM = (S > 0. ? g : 0.) * inv_dx;
         const double sgn = pS * rsqrt_nr(__builtin_fma(pS, pS, dx * dx * gM));
         return __builtin_fma(h, sgn * (1. - gM), phic);
