@@ -179,25 +179,24 @@ __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2,
 
     const double S0 = e_bc - e_cm;  // bp - 2cp + bm   (= b-2c+d on both sides)
     const double S12 = S0 * (1.0 / 12.0), S0h = S0 * 0.5;
-    double PWp, PWm;
-    {
-        const double q0 = epsp + IS0p, q1 = epsp + IS1p, q2 = epsp + IS2p;
-        const double t12 = q1 * q2, t02 = q0 * q2, t01 = q0 * q1;
-        const double n0 = t12 * t12, n1 = t02 * t02, m2 = t01 * t01;
-        const double D = __builtin_fma(3.0, m2, __builtin_fma(6.0, n1, n0));
-        const double r = rcp_nr(__builtin_fmax(D, 1e-300));
-        const double Sa = e_ab - e_bc; // ap - 2bp + cp
-        PWp = __builtin_fma(r, __builtin_fma(n0 * (1.0 / 3.0), Sa, m2 * S0h), -S12);
-    }
-    {
-        const double q0 = epsm + IS0m, q1 = epsm + IS1m, q2 = epsm + IS2m;
-        const double t12 = q1 * q2, t02 = q0 * q2, t01 = q0 * q1;
-        const double n0 = t12 * t12, n1 = t02 * t02, m2 = t01 * t01;
-        const double D = __builtin_fma(3.0, m2, __builtin_fma(6.0, n1, n0));
-        const double r = rcp_nr(__builtin_fmax(D, 1e-300));
-        const double Sa = e_mm + e_cm; // am - 2bm + cp = (am-bm) - (bm-cp)
-        PWm = __builtin_fma(r, __builtin_fma(n0 * (1.0 / 3.0), Sa, m2 * S0h), -S12);
-    }
+    // both sides' products first, then ONE reciprocal for the two normalisations: 1/Dp = Dm * 1/(Dp Dm) (v_rcp_f64 is a
+    // quarter-rate instruction).  Dp Dm underflows only where the stencil is flat to ~1e-30 relative, or exactly flat
+    // (D = 0: eps is the floor); the clamp then turns both correction terms into -S0/12, the central candidate, which is
+    // what every candidate equals there.
+    const double q0p = epsp + IS0p, q1p = epsp + IS1p, q2p = epsp + IS2p;
+    const double q0m = epsm + IS0m, q1m = epsm + IS1m, q2m = epsm + IS2m;
+    const double t12p = q1p * q2p, t02p = q0p * q2p, t01p = q0p * q1p;
+    const double t12m = q1m * q2m, t02m = q0m * q2m, t01m = q0m * q1m;
+    const double n0p = t12p * t12p, n1p = t02p * t02p, m2p = t01p * t01p;
+    const double n0m = t12m * t12m, n1m = t02m * t02m, m2m = t01m * t01m;
+    const double Dp = __builtin_fma(3.0, m2p, __builtin_fma(6.0, n1p, n0p));
+    const double Dm = __builtin_fma(3.0, m2m, __builtin_fma(6.0, n1m, n0m));
+    const double R = rcp_nr(__builtin_fmax(Dp * Dm, 1e-300));
+    const double rp = Dm * R, rm = Dp * R;
+    const double Sap = e_ab - e_bc; // ap - 2bp + cp
+    const double Sam = e_mm + e_cm; // am - 2bm + cp = (am-bm) - (bm-cp)
+    const double PWp = __builtin_fma(rp, __builtin_fma(n0p * (1.0 / 3.0), Sap, m2p * S0h), -S12);
+    const double PWm = __builtin_fma(rm, __builtin_fma(n0m * (1.0 / 3.0), Sam, m2m * S0h), -S12);
     const double cen12 = __builtin_fma(7.0, d2 + d3, -(d1 + d4));
     dm = __builtin_fma(1.0 / 12.0, cen12, -PWm);
     dp = __builtin_fma(1.0 / 12.0, cen12, PWp);
