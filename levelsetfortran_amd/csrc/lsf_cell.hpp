@@ -154,28 +154,31 @@ __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2,
     const double d3 = q[4] - q[3], d4 = q[5] - q[4], d5 = q[6] - q[5];
     // second differences (am,bm,cp,bp,ap)*dx
     const double am = d1 - d0, bm = d2 - d1, cp = d3 - d2, bp = d4 - d3, ap = d5 - d4;
-    // the four distinct differences; their squares carry the factor 13/3, so that an indicator is one FMA:
-    // IS_k * 13/3 = (13/3) e^2 + t^2 (epsilon is scaled alike, the weights are ratios)
+    // the four distinct differences of second differences and the six linear forms of the indicators
     const double e_ab = ap - bp, e_bc = bp - cp, e_cm = cp - bm, e_mm = am - bm;
-    constexpr double C = 13.0 / 3.0;
-    const double s_ab = (C * e_ab) * e_ab, s_bc = (C * e_bc) * e_bc, s_cm = (C * e_cm) * e_cm, s_mm = (C * e_mm) * e_mm;
-    auto isf = [](double sq, double t) { return __builtin_fma(t, t, sq); }; // (13 e^2 + 3 t^2)/3
-    const double IS0p = isf(s_ab, __builtin_fma(-3.0, bp, ap));
-    const double IS1p = isf(s_bc, bp + cp);
-    const double IS2p = isf(s_cm, __builtin_fma(3.0, cp, -bm));
-    const double IS0m = isf(s_mm, __builtin_fma(-3.0, bm, am));
-    const double IS1m = isf(s_cm, bm + cp);
-    const double IS2m = isf(s_bc, __builtin_fma(3.0, cp, -bp));
+    const double t0p = __builtin_fma(-3.0, bp, ap), t1p = bp + cp, t2p = __builtin_fma(3.0, cp, -bm);
+    const double t0m = __builtin_fma(-3.0, bm, am), t1m = bm + cp, t2m = __builtin_fma(3.0, cp, -bp);
 
-    // eps = 1e-6 max(p^2) + 1e-99 (subs.f90:533-534), in unscaled units and times 1/3 like the IS (floor2 is the
+    // eps = 1e-6 max(p^2) + 1e-99 (subs.f90:533-534), in unscaled units and times 1/3 like the IS below (floor2 is the
     // floor divided by 13: times 13/3 here); max of squares = square of the max magnitude (|x| is a free modifier)
     const double mid = __builtin_fmax(__builtin_fmax(__builtin_fabs(d1), __builtin_fabs(d2)),
                                       __builtin_fmax(__builtin_fabs(d3), __builtin_fabs(d4)));
     const double mp = yquirk ? mid : __builtin_fmax(mid, __builtin_fabs(d5));
     const double mm = __builtin_fmax(mid, __builtin_fabs(d0));
+    constexpr double C = 13.0 / 3.0;
     const double fl = C * floor2;
     const double epsp = __builtin_fma((1.E-6 / 3.0) * mp, mp, fl);
     const double epsm = __builtin_fma((1.E-6 / 3.0) * mm, mm, fl);
+
+    // q_k = (eps + IS_k) / 3 = t^2 + ((13/3) e^2 + eps/3): two FMAs per q on top of the four products (13/3) e
+    // (the squares e_bc^2 and e_cm^2 serve both sides, each with its own eps)
+    const double c_ab = C * e_ab, c_bc = C * e_bc, c_cm = C * e_cm, c_mm = C * e_mm;
+    const double q0p = __builtin_fma(t0p, t0p, __builtin_fma(c_ab, e_ab, epsp));
+    const double q1p = __builtin_fma(t1p, t1p, __builtin_fma(c_bc, e_bc, epsp));
+    const double q2p = __builtin_fma(t2p, t2p, __builtin_fma(c_cm, e_cm, epsp));
+    const double q0m = __builtin_fma(t0m, t0m, __builtin_fma(c_mm, e_mm, epsm));
+    const double q1m = __builtin_fma(t1m, t1m, __builtin_fma(c_cm, e_cm, epsm));
+    const double q2m = __builtin_fma(t2m, t2m, __builtin_fma(c_bc, e_bc, epsm));
 
     const double S0 = e_bc - e_cm;  // bp - 2cp + bm   (= b-2c+d on both sides)
     const double S12 = S0 * (1.0 / 12.0), S0h = S0 * 0.5;
@@ -183,8 +186,6 @@ __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2,
     // quarter-rate instruction).  Dp Dm underflows only where the stencil is flat to ~1e-30 relative, or exactly flat
     // (D = 0: eps is the floor); the clamp then turns both correction terms into -S0/12, the central candidate, which is
     // what every candidate equals there.
-    const double q0p = epsp + IS0p, q1p = epsp + IS1p, q2p = epsp + IS2p;
-    const double q0m = epsm + IS0m, q1m = epsm + IS1m, q2m = epsm + IS2m;
     const double t12p = q1p * q2p, t02p = q0p * q2p, t01p = q0p * q1p;
     const double t12m = q1m * q2m, t02m = q0m * q2m, t01m = q0m * q1m;
     const double n0p = t12p * t12p, n1p = t02p * t02p, m2p = t01p * t01p;

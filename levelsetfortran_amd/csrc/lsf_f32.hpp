@@ -69,16 +69,9 @@ __device__ __forceinline__ void weno_axis_f32(const f2 q[7], bool yquirk, f2& dm
     const f2 d3 = q[4] - q[3], d4 = q[5] - q[4], d5 = q[6] - q[5];
     const f2 am = d1 - d0, bm = d2 - d1, cp = d3 - d2, bp = d4 - d3, ap = d5 - d4;
     const f2 e_ab = ap - bp, e_bc = bp - cp, e_cm = cp - bm, e_mm = am - bm;
-    // squares carry 13/3 so that an indicator is one FMA: IS_k / 3 = (13/3) e^2 + t^2 (epsilon scaled alike)
     const f2 C = splat(13.0f / 3.0f), three = splat(3.0f);
-    const f2 s_ab = (C * e_ab) * e_ab, s_bc = (C * e_bc) * e_bc, s_cm = (C * e_cm) * e_cm, s_mm = (C * e_mm) * e_mm;
-    auto isf = [&](f2 sq, f2 t) { return fma2(t, t, sq); }; // (13 e^2 + 3 t^2)/3
-    const f2 IS0p = isf(s_ab, fma2(-three, bp, ap));
-    const f2 IS1p = isf(s_bc, bp + cp);
-    const f2 IS2p = isf(s_cm, fma2(three, cp, -bm));
-    const f2 IS0m = isf(s_mm, fma2(-three, bm, am));
-    const f2 IS1m = isf(s_cm, bm + cp);
-    const f2 IS2m = isf(s_bc, fma2(three, cp, -bp));
+    const f2 t0p = fma2(-three, bp, ap), t1p = bp + cp, t2p = fma2(three, cp, -bm);
+    const f2 t0m = fma2(-three, bm, am), t1m = bm + cp, t2m = fma2(three, cp, -bp);
 
     const f2 mid = max2(max2(abs2(d1), abs2(d2)), max2(abs2(d3), abs2(d4)));
     const f2 mp = yquirk ? mid : max2(mid, abs2(d5));
@@ -87,10 +80,17 @@ __device__ __forceinline__ void weno_axis_f32(const f2 q[7], bool yquirk, f2& dm
     const f2 epsp = fma2(E * mp, mp, fl);
     const f2 epsm = fma2(E * mm, mm, fl);
 
+    // q_k = (eps + IS_k) / 3 = t^2 + ((13/3) e^2 + eps/3), see weno_axis_fast
+    const f2 c_ab = C * e_ab, c_bc = C * e_bc, c_cm = C * e_cm, c_mm = C * e_mm;
+    const f2 q0p = fma2(t0p, t0p, fma2(c_ab, e_ab, epsp)), q1p = fma2(t1p, t1p, fma2(c_bc, e_bc, epsp)),
+             q2p = fma2(t2p, t2p, fma2(c_cm, e_cm, epsp));
+    const f2 q0m = fma2(t0m, t0m, fma2(c_mm, e_mm, epsm)), q1m = fma2(t1m, t1m, fma2(c_cm, e_cm, epsm)),
+             q2m = fma2(t2m, t2m, fma2(c_bc, e_bc, epsm));
+
     const f2 S0 = e_bc - e_cm;
     const f2 S12 = S0 * splat(1.0f / 12.0f), S0h = S0 * splat(0.5f);
-    const f2 PWp = weno_side_f32(epsp + IS0p, epsp + IS1p, epsp + IS2p, e_ab - e_bc, S0h, S12);
-    const f2 PWm = weno_side_f32(epsm + IS0m, epsm + IS1m, epsm + IS2m, e_mm + e_cm, S0h, S12);
+    const f2 PWp = weno_side_f32(q0p, q1p, q2p, e_ab - e_bc, S0h, S12);
+    const f2 PWm = weno_side_f32(q0m, q1m, q2m, e_mm + e_cm, S0h, S12);
     const f2 cen12 = fma2(splat(7.0f), d2 + d3, -(d1 + d4));
     dm = fma2(splat(1.0f / 12.0f), cen12, -PWm);
     dp = fma2(splat(1.0f / 12.0f), cen12, PWp);
