@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSF_VERSION 100 /* 0.1.0 */
+#define LSF_VERSION 101 /* 0.1.1: single-precision entry points added */
 
 /* ---- return codes ---------------------------------------------------------------------- */
 #define LSF_OK 0

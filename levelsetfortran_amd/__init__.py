@@ -6,4 +6,4 @@ from .levelset import (LsfError, LsfNaNError, SweepReport, advectNodes, minmaxFl
                        reinit)
 from . import fields  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.1.1"
