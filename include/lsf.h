@@ -170,6 +170,13 @@ int lsf_jacobi_sweep_box(const double *d_in, double *d_out, const double *d_phiS
 int lsf_bc_box(const double *d_in, double *d_out, const lsf_box *box, const int lo[3], const int hi[3],
                double dx, double *d_sumsq, void *stream);
 
+/* Optional bracket around the box calls of one sweep on one stream: between lsf_sumsq_begin and lsf_sumsq_end the
+ * calls above keep their partial sums and lsf_sumsq_end adds them to *d_sumsq in ONE fixed-order reduction (one
+ * launch instead of one per call; all bracketed calls must name the same d_sumsq, a call naming another one is reduced
+ * at once).  The value of *d_sumsq is complete after lsf_sumsq_end. */
+int lsf_sumsq_begin(void *stream);
+int lsf_sumsq_end(void *stream);
+
 /* Pack / unpack the local sub-box [lo,hi) to / from a contiguous buffer (i fastest). */
 int lsf_pack_box(const double *d_field, const lsf_box *box, const int lo[3], const int hi[3],
                  double *d_buf, void *stream);

@@ -69,6 +69,8 @@ SIGNATURES = {
                                      c_double, c_double, c_int, c_void_p, c_void_p]),
     "lsf_bc_box": (c_int, [c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_double, c_void_p,
                            c_void_p]),
+    "lsf_sumsq_begin": (c_int, [c_void_p]),
+    "lsf_sumsq_end": (c_int, [c_void_p]),
     "lsf_pack_box": (c_int, [c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_void_p, c_void_p]),
     "lsf_unpack_box": (c_int, [c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_void_p, c_void_p]),
     "lsf_reinit_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_int,

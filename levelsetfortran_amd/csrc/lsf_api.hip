@@ -111,9 +111,18 @@ struct BatchPlan {
 
 enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_PLANECNT, S_DBG, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_NSLOTS };
 
+// partial sums of the box calls issued on one stream; `deferred`: between lsf_sumsq_begin and lsf_sumsq_end the calls
+// append their partials instead of reducing them one by one
+struct StreamPart {
+    Buf buf;
+    bool deferred = false;
+    size_t used = 0;          // doubles appended so far
+    double* target = nullptr; // the d_sumsq of the deferred calls
+};
+
 struct Ctx {
     Buf slot[S_NSLOTS];
-    std::map<hipStream_t, Buf> part_by_stream;
+    std::map<hipStream_t, StreamPart> part_by_stream;
     std::map<uint64_t, TileList> tiles;
     std::map<uint64_t, TileList> skew_tiles;
     std::map<std::array<int, 6>, BatchPlan> plans; // dataflow schedule: batch plans per grid / raster phase / sweep count
@@ -1066,13 +1075,44 @@ int sweep_region_ok(const lsf_box* box, const int lo[3], const int hi[3])
     return LSF_OK;
 }
 
+int flush_partials(hipStream_t st, StreamPart& sp)
+{
+    if (sp.used > 0 && sp.target)
+        hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(RED_T), 0, st, (const double*)sp.buf.p, (long)sp.used, sp.target);
+    sp.used = 0;
+    HIPCHK(hipGetLastError());
+    return LSF_OK;
+}
+
 int stream_partials(hipStream_t st, size_t count, double** out)
 {
     Ctx& c = ctx();
-    Buf& b = c.part_by_stream[st];
-    int rc = ws(b, count * sizeof(double));
-    if (rc) return rc;
-    *out = (double*)b.p;
+    StreamPart& sp = c.part_by_stream[st];
+    const size_t at = sp.deferred ? sp.used : 0;
+    if ((at + count) * sizeof(double) > sp.buf.bytes) {
+        // growing replaces the buffer: reduce what the kernels in flight have written to it first
+        int rc = flush_partials(st, sp);
+        if (rc) return rc;
+        if (sp.deferred) HIPCHK(hipStreamSynchronize(st));
+        if ((rc = ws(sp.buf, std::max(count, (size_t)1 << 16) * 2 * sizeof(double)))) return rc;
+        *out = (double*)sp.buf.p;
+        return LSF_OK;
+    }
+    *out = (double*)sp.buf.p + at;
+    return LSF_OK;
+}
+
+// after the kernel of a box call has been launched: reduce its partials now, or leave them for lsf_sumsq_end
+int finish_partials(hipStream_t st, double* part, long np, double* d_sumsq)
+{
+    StreamPart& sp = ctx().part_by_stream[st];
+    if (sp.deferred && (sp.target == nullptr || sp.target == d_sumsq)) {
+        sp.target = d_sumsq;
+        sp.used = (size_t)(part - (double*)sp.buf.p) + (size_t)np;
+    } else {
+        hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(RED_T), 0, st, (const double*)part, np, d_sumsq);
+    }
+    HIPCHK(hipGetLastError());
     return LSF_OK;
 }
 
@@ -1093,9 +1133,7 @@ int bc_box_impl(const T* d_in, T* d_out, const lsf_box* box, const int lo[3], co
     const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
     hipLaunchKernelGGL(k_bc<T>, grid, dim3(64), 0, st, d_in, d_out, bx, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], (T)dx,
                        part, (const int*)nullptr, 0);
-    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(RED_T), 0, st, part, np, d_sumsq);
-    HIPCHK(hipGetLastError());
-    return LSF_OK;
+    return finish_partials(st, part, np, d_sumsq);
 }
 
 template <typename T>
@@ -1183,7 +1221,7 @@ int lsf_release_workspace(void)
         b = Buf{};
     }
     for (auto& kv : c.part_by_stream)
-        if (kv.second.p) HIPCHK(hipFree(kv.second.p));
+        if (kv.second.buf.p) HIPCHK(hipFree(kv.second.buf.p));
     c.part_by_stream.clear();
     for (auto& kv : c.plans) {
         if (kv.second.d_order) HIPCHK(hipFree(kv.second.d_order));
@@ -1461,9 +1499,29 @@ int lsf_jacobi_sweep_box(const double* d_in, double* d_out, const double* d_phiS
         else LSF_LAUNCH_JAC(false, false);
     }
 #undef LSF_LAUNCH_JAC
-    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(RED_T), 0, st, part, np, d_sumsq);
-    HIPCHK(hipGetLastError());
+    return finish_partials(st, part, np, d_sumsq);
+}
+
+int lsf_sumsq_begin(void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    StreamPart& sp = ctx().part_by_stream[(hipStream_t)stream];
+    if (sp.deferred) return fail(LSF_ERR_INVALID, "lsf_sumsq_begin: already open on this stream");
+    sp.deferred = true, sp.used = 0, sp.target = nullptr;
     return LSF_OK;
+}
+
+int lsf_sumsq_end(void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    StreamPart& sp = ctx().part_by_stream[(hipStream_t)stream];
+    if (!sp.deferred) return fail(LSF_ERR_INVALID, "lsf_sumsq_end without lsf_sumsq_begin on this stream");
+    sp.deferred = false;
+    rc = flush_partials((hipStream_t)stream, sp);
+    sp.target = nullptr;
+    return rc;
 }
 
 int lsf_bc_box(const double* d_in, double* d_out, const lsf_box* box, const int lo[3], const int hi[3],
@@ -1529,9 +1587,7 @@ int lsf_jacobi_sweep_box_f32(const float* d_in, float* d_out, const float* d_phi
     else
         hipLaunchKernelGGL((k_reinit_jacobi_f32<false>), grid, dim3(F32_BX, F32_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0],
                            lo[1], lo[2], hi[0], hi[1], hi[2], (float)dx, (float)h, part, (const int*)nullptr, 0);
-    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(RED_T), 0, st, part, np, d_sumsq);
-    HIPCHK(hipGetLastError());
-    return LSF_OK;
+    return finish_partials(st, part, np, d_sumsq);
 }
 
 int lsf_reinit_f32_device(float* d_phi, const float* d_phiS, int nx, int ny, int nz, int iter, double dx, double h,

@@ -241,6 +241,13 @@ class HipBackend:
         self.L.check(self._unpack(f.data_ptr(), ctypes.byref(self._box(b)), lo, hi, buf.data_ptr(),
                                              stream.cuda_stream))
 
+    def sumsq_begin(self, stream):
+        """bracket the box calls of a sweep: their partial sums are reduced once, by sumsq_end (include/lsf.h)"""
+        self.L.check(self.lib.lsf_sumsq_begin(stream.cuda_stream))
+
+    def sumsq_end(self, stream):
+        self.L.check(self.lib.lsf_sumsq_end(stream.cuda_stream))
+
     def stream_ctx(self, stream):
         return self.torch.cuda.stream(stream)
 
@@ -321,13 +328,20 @@ class DistributedReinit:
         be, b = self.be, self.b
         self.sumsq.zero_()
         self.exchange(a_in)  # ghosts of a_in (comm stream)
-        if _vol(self.core) > 0:
-            be.sweep(a_in, a_out, phiS, b, self.core, self.dx, self.h, self.sumsq, be.compute)  # overlaps the exchange
-        be.wait(be.compute, be.comm)
-        for r in self.rims:
-            if _vol(r) > 0:
-                be.sweep(a_in, a_out, phiS, b, r, self.dx, self.h, self.sumsq, be.compute)
-        be.bc(a_in, a_out, b, [tuple(r) for r in b.own_local], self.dx, self.sumsq, be.compute)
+        bracket = hasattr(be, "sumsq_begin")  # one reduction of the partial sums per sweep instead of one per region
+        if bracket:
+            be.sumsq_begin(be.compute)
+        try:
+            if _vol(self.core) > 0:
+                be.sweep(a_in, a_out, phiS, b, self.core, self.dx, self.h, self.sumsq, be.compute)  # overlaps the exchange
+            be.wait(be.compute, be.comm)
+            for r in self.rims:
+                if _vol(r) > 0:
+                    be.sweep(a_in, a_out, phiS, b, r, self.dx, self.h, self.sumsq, be.compute)
+            be.bc(a_in, a_out, b, [tuple(r) for r in b.own_local], self.dx, self.sumsq, be.compute)
+        finally:
+            if bracket:
+                be.sumsq_end(be.compute)
 
     def rms_async(self):
         """all_reduce of the sum of squares; returns a 1-element tensor holding the global sum."""
