@@ -112,3 +112,42 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 4 - cells) < 1e-6 * cells  # value = cells of ALL ranks / time
     jd = d["jacobi_decomposed"]
     assert jd["value"] > 0 and jd["global_grid"] == [192, 96, 96]
+
+
+def test_sumsq_bracket_equals_per_call_reduction():
+    """lsf_sumsq_begin / lsf_sumsq_end (include/lsf.h): the bracketed box calls leave the same field and, to rounding,
+    the same sum of squares as the calls reduced one by one; misuse is refused."""
+    import ctypes
+
+    from levelsetfortran_amd import _lib, distributed as D, fields
+
+    npts = (70, 41, 37)
+    n = tuple(v - 1 for v in npts)
+    b = D.make_block(0, (1, 1, 1), n)
+    dev = torch.device("cuda", 0)
+    be = D.HipBackend(dev, arith="strict")
+    phi_np, dx = fields.two_sphere_phi0(npts)
+    h = fields.reinit_step(dx)
+    a = be.from_numpy(phi_np)
+    regions = [[(1, 30), (1, 40), (1, 36)], [(30, 69), (1, 40), (1, 36)]]  # two halves of the interior
+    outs, sums = [], []
+    for bracket in (False, True):
+        out = a.clone()
+        ss = be.zeros(1)
+        if bracket:
+            be.sumsq_begin(be.compute)
+        for r in regions:
+            be.sweep(a, out, a, b, r, dx, h, ss, be.compute)
+        be.bc(a, out, b, [(0, npts[0]), (0, npts[1]), (0, npts[2])], dx, ss, be.compute)
+        if bracket:
+            be.sumsq_end(be.compute)
+        be.synchronize()
+        outs.append(out.cpu().numpy())
+        sums.append(float(ss.item()))
+    assert np.array_equal(outs[0], outs[1])
+    assert sums[0] > 0 and abs(sums[0] - sums[1]) <= 1e-13 * sums[0]
+    lib = _lib.load()
+    st = be.compute.cuda_stream
+    assert lib.lsf_sumsq_end(st) == _lib.LSF_ERR_INVALID
+    assert lib.lsf_sumsq_begin(st) == _lib.LSF_OK and lib.lsf_sumsq_begin(st) == _lib.LSF_ERR_INVALID
+    assert lib.lsf_sumsq_end(st) == _lib.LSF_OK
