@@ -6,7 +6,7 @@
  * The reference has no FFI: its seam is the Fortran module procedure `reinit`
  * (subs.f90:717-725, called at set3d.f90:308 and :582) and the min/max loop written inline in the
  * main program (set3d.f90:394-462).  Each entry point below names the reference interface it
- * replaces.  levelsetfortran_amd/fortran/lsf_set_subs.f90 is the iso_c_binding shim that gives
+ * replaces.  levelsetfortran_amd/fortran/lsf_hip.f90 is the iso_c_binding shim that gives
  * the reference host those procedures back under their original names.
  *
  * Conventions

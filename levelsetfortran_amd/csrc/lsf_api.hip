@@ -84,6 +84,18 @@ int gs_ny()
     const char* e = getenv("LSF_GS_NY");
     return (e && atoi(e) == 4) ? 4 : 5;
 }
+// dataflow launch: axis the tiles march along -- "y" (default; the kernel then runs on the x <-> y transposed field, see
+// k_transpose_xy) or "x" (the field as it is) -- and the number of field buffers in rotation (3 or 4)
+int gs_march()
+{
+    const char* e = getenv("LSF_GS_MARCH");
+    return (e && (e[0] == 'x' || e[0] == 'X')) ? 0 : 1;
+}
+int gs_nbuf()
+{
+    const char* e = getenv("LSF_GS_NBUF");
+    return (e && atoi(e) == 3) ? 3 : 4;
+}
 constexpr int MM_TA = 32;      // tile length along i of the exact-GS min/max kernel
 constexpr int CHECK_EVERY = 8; // sweeps between host reads of the device stop flag
 // fp32 sweep: the pure x-face wall points are written by the sweep kernel instead of k_bc (kernel argument `xwall`):
@@ -103,13 +115,15 @@ struct TileList {
 };
 
 // dataflow schedule of the exact ordering: tiles of a batch of sweeps in slot order, per-sweep table, hyperplane sizes
+// (small: the task list itself is rebuilt on the device for every launch, k_build_order)
 struct BatchPlan {
-    uint2* d_order = nullptr;
-    int* d_aux = nullptr; // [4 * DF_BATCH] {sign i, j, k, spacing} per sweep, then [np] tiles per hyperplane
-    long total = 0;
+    int* d_meta = nullptr; // [ns] start slot per sweep | [nslots + 1] first entry per slot | [4 * DF_BATCH] {sign i, j, k,
+                           // spacing} per sweep | [np] tiles per hyperplane | [np + 1] offsets of the hyperplanes in the tile list
+    long total = 0;        // entries of the task list
+    int nslots = 0;
 };
 
-enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_PLANECNT, S_DBG, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_NSLOTS };
+enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_PLANECNT, S_DBG, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_PONG3, S_PONG4, S_NSLOTS };
 
 // partial sums of the box calls issued on one stream; `deferred`: between lsf_sumsq_begin and lsf_sumsq_end the calls
 // append their partials instead of reducing them one by one
@@ -552,14 +566,6 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     Ctx& c = ctx();
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
     const int max_sweeps = iter + 1;
-    if ((rc = ws(c.slot[S_PONG], n * sizeof(double)))) return rc;
-    if ((rc = ws(c.slot[S_PONG2], n * sizeof(double)))) return rc;
-    const double* d_phiS = d_phiS_in;
-    if (!d_phiS) {
-        if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
-        HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        d_phiS = (const double*)c.slot[S_PHIS].p;
-    }
     const int ta = gs_ta();
     int nyc = gs_ny();
     int sched = gs_schedule();
@@ -568,39 +574,80 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     // launches on the box tiles of lsf_boxtile.hpp (`slots`): 256^3 0.97 / 1.24 / 1.75 ms, 512^3 3.25 / 4.61 / 6.83 ms,
     // 1024^3 24.7 / 25.2 / 38.0 ms.
     if (sched < 0) sched = 5;
-    const bool persist = sched == 5; // k_reinit_gs_persist
+    bool persist = sched == 5; // k_reinit_gs_persist
     if (persist) sched = 3;
     // skewed tiles need TA = 16, NY = 5 and at least two interior cells per axis
     const bool skew = sched == 3 && ta == 16 && nyc == 5 && nx >= 3 && ny >= 3 && nz >= 3;
+    persist = persist && skew;
     int wy = 1, wz = 1, nzc = 4;
     if (skew) {
         gs_skew_w(&wy, &wz);
         nyc = 5 * wy, nzc = 4 * wz; // rows of a tile in y and z
     }
+    // Dataflow launch: the kernel marches along ITS x axis; run it on the x <-> y transposed field so that the march axis
+    // is the reference's y, the axis the raster cycle flips in six of its eight transitions (a flip of the march axis
+    // spaces two sweeps by n / 16 time slots, a flip of a cross-section axis by n / 16 + its number of tiles: 70 instead of
+    // 95 slots per sweep at 512^3).  Costs nbuf + 1 work fields (none of them the caller's) and three transpositions per
+    // call; skipped when that does not fit.
+    int nbuf = persist ? gs_nbuf() : 3;
+    bool tr = persist && gs_march() == 1;
+    if (tr) {
+        size_t need = 0, fr = 0, tot = 0;
+        for (Slot q : {S_PONG, S_PONG2, S_PONG3, S_PONG4, S_PHIS})
+            if (q != S_PONG4 || nbuf == 4) need += c.slot[q].bytes >= n * sizeof(double) ? 0 : n * sizeof(double);
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        if (need + (2ull << 30) > fr) tr = false, nbuf = 3;
+    }
+    const int knx = tr ? ny : nx, kny = tr ? nx : ny; // the kernel's view of the grid
+    auto ksign = [&](int raster, int* out) {           // raster signs in the kernel's axis order
+        const int* r = RASTER_SIGN[raster & 7];
+        out[0] = tr ? r[1] : r[0], out[1] = tr ? r[0] : r[1], out[2] = r[2];
+    };
+    const Slot pong[4] = {S_PONG, S_PONG2, S_PONG3, S_PONG4};
+    for (int q = 0; q < (tr ? nbuf : nbuf - 1); ++q)
+        if ((rc = ws(c.slot[pong[q]], n * sizeof(double)))) return rc;
+    const double* d_phiS = d_phiS_in;
+    if (tr) {
+        if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
+        const dim3 tg(cdiv(nx + 1, 32), cdiv(ny + 1, 32), (unsigned)std::min(nz + 1, 1024));
+        hipLaunchKernelGGL(k_transpose_xy, tg, dim3(256), 0, st, (const double*)d_phi, (double*)c.slot[S_PONG].p, nx + 1, ny + 1,
+                           (long)(nz + 1));
+        hipLaunchKernelGGL(k_transpose_xy, tg, dim3(256), 0, st, d_phiS_in ? d_phiS_in : (const double*)d_phi,
+                           (double*)c.slot[S_PHIS].p, nx + 1, ny + 1, (long)(nz + 1)); // phiS = phi on entry, subs.f90:731
+        d_phiS = (const double*)c.slot[S_PHIS].p;
+    } else if (!d_phiS) {
+        if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
+        HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        d_phiS = (const double*)c.slot[S_PHIS].p;
+    }
     const bool overlap = sched != 0; // "planes": one sweep at a time (start[g+1] = start[g] + nPlanes)
-    const int nTi = cdiv(nx - 1, ta), nTj = cdiv(ny - 1, nyc), nTk = cdiv(nz - 1, nzc);
+    const int nTi = cdiv(knx - 1, ta), nTj = cdiv(kny - 1, nyc), nTk = cdiv(nz - 1, nzc);
     const int nT[3] = {nTi, nTj, nTk};
     TileList* tl = nullptr;
-    if (skew) rc = get_skew_tiles(nx - 1, nTj, nTk, ta, nyc, nzc, &tl);
+    if (skew) rc = get_skew_tiles(knx - 1, nTj, nTk, ta, nyc, nzc, &tl);
     else rc = get_tiles(nTi, nTj, nTk, &tl);
     if (rc) return rc;
     const int np = (int)tl->off.size() - 1;
     if ((rc = ws(c.slot[S_CTL], 64))) return rc;
     if ((rc = ws(c.slot[S_TRACE], (size_t)max_sweeps * sizeof(double)))) return rc;
-    if ((rc = ws(c.slot[S_COLSUM], (size_t)3 * nTj * nTk * sizeof(double)))) return rc;
+    if ((rc = ws(c.slot[S_COLSUM], (size_t)4 * nTj * nTk * sizeof(double)))) return rc;
     int* ctl = (int*)c.slot[S_CTL].p;
     HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
 
-    // Three field buffers in rotation: sweep g overwrites the result of sweep g-3, so it has to wait for the
-    // stop verdict of sweep g-3 only, and consecutive sweeps are spaced by the raster-flip rule alone.
+    // nbuf field buffers in rotation: sweep g overwrites the result of sweep g - nbuf, so it has to wait for the
+    // stop verdict of that sweep only, and consecutive sweeps are spaced by the raster-flip rule alone.
     GsArgs fa;
     std::memset(&fa, 0, sizeof fa);
-    fa.buf[0] = d_phi;
-    fa.buf[1] = (double*)c.slot[S_PONG].p;
-    fa.buf[2] = (double*)c.slot[S_PONG2].p;
-    fa.nbuf = 3;
+    if (tr) {
+        for (int q = 0; q < nbuf; ++q) fa.buf[q] = (double*)c.slot[pong[q]].p;
+    } else {
+        fa.buf[0] = d_phi;
+        for (int q = 1; q < nbuf; ++q) fa.buf[q] = (double*)c.slot[pong[q - 1]].p;
+    }
+    fa.nbuf = nbuf;
+    fa.quirk_axis = tr ? 0 : 1; // subs.f90:576 concerns the reference's y axis
     fa.phiS = d_phiS;
-    fa.nx = nx, fa.ny = ny, fa.nz = nz, fa.nTi = nTi, fa.nTj = nTj, fa.nTk = nTk;
+    fa.nx = knx, fa.ny = kny, fa.nz = nz, fa.nTi = nTi, fa.nTj = nTj, fa.nTk = nTk;
     fa.dx = dx, fa.h = h;
     fa.colsum = (double*)c.slot[S_COLSUM].p;
     fa.trace = (double*)c.slot[S_TRACE].p;
@@ -611,7 +658,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     fa.nTiles = (long)nTi * nTj * nTk;
     fa.last_packed = tl->last;
 
-    // start slot of sweep g, generated on demand
+    // start slot of sweep g, generated on demand (slot schedules; never transposed)
     std::vector<long> start{0};
     auto start_of = [&](int g) -> long {
         while ((int)start.size() <= g) {
@@ -631,21 +678,23 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     };
     int host_ctl[4] = {0, 0, 0, 0};
     prof_begin();
-    prof_mark(st);
     long launches = 0;
-    if (persist && skew) {
+    bool marked = false;
+    if (persist) {
         // Dataflow schedule (k_reinit_gs_persist): one launch per batch of up to DF_BATCH = 64 sweeps, one block per tile,
-        // dependencies resolved in the kernel.  The batch plan (tiles in slot order, spacing table) depends on the grid,
-        // the raster phase of the batch's first sweep and the number of sweeps only, and is cached on the device.
+        // dependencies resolved in the kernel.  What depends on the grid, the raster phase of the batch's first sweep and the
+        // number of sweeps (start slots, entries per slot, spacing table) is small and cached on the device; the task list
+        // itself is rebuilt by k_build_order in front of every launch.
         const long ntiles = tl->off[np];
         // sweeps per launch: 64 (a batch costs about one sweep time of fill and drain, measured 26.6 / 50.0 / 73.9 /
         // 97.4 ms for 8 / 16 / 24 / 32 sweeps at 512^3), fewer on very large grids so that the task list stays below
         // 512 MB; a multiple of 8 keeps the raster phase, hence the cached plan, the same
         const int BATCH = (int)std::max<long>(8, std::min<long>(DF_BATCH, (512L << 20) / (ntiles * 8) / 8 * 8));
-        const int nM = (nx - 2 + nyc * nTj - 1 + nzc * nTk - 1) / ta + 1; // m_max + 1 (get_skew_tiles)
+        const int nM = (knx - 2 + nyc * nTj - 1 + nzc * nTk - 1) / ta + 1; // m_max + 1 (get_skew_tiles)
         const size_t tile_flags = (size_t)BATCH * nM * nTj * nTk;
         if ((rc = ws(c.slot[S_PLANECNT], ((size_t)BATCH * np + BATCH + 16) * sizeof(int)))) return rc;
         if ((rc = ws(c.slot[S_BFLAG], tile_flags * sizeof(int)))) return rc;
+        if ((rc = ws(c.slot[S_ORDER], (size_t)std::min(BATCH, max_sweeps) * ntiles * sizeof(uint2)))) return rc;
         int* d_cnt = (int*)c.slot[S_PLANECNT].p;
         int* d_done = d_cnt + (size_t)BATCH * np;
         int* d_ticket = d_done + BATCH;
@@ -654,52 +703,69 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             if ((rc = ws(c.slot[S_DBG], 64))) return rc;
             d_dbg = (unsigned long long*)c.slot[S_DBG].p;
         }
+        if (c.plans.size() > 64) { // bounded: every earlier call has synchronised its stream before returning
+            for (auto& kv : c.plans)
+                if (kv.second.d_meta) HIPCHK(hipFree(kv.second.d_meta));
+            c.plans.clear();
+        }
         for (int g0 = 0; g0 < max_sweeps; g0 += BATCH) {
             const int ns = std::min(BATCH, max_sweeps - g0), phase = (first_raster + g0) & 7;
-            const std::array<int, 6> key{nx, ny, nz, phase, ns, wy * 16 + wz};
+            const std::array<int, 6> key{knx, kny, nz, phase, ns, wy * 16 + wz + 256 * (int)tr + 1024 * nbuf};
             auto it = c.plans.find(key);
             if (it == c.plans.end()) {
                 BatchPlan bp;
-                std::vector<uint32_t> h_tiles((size_t)ntiles);
-                HIPCHK(hipMemcpy(h_tiles.data(), tl->d, (size_t)ntiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                std::vector<int> h_aux(4 * DF_BATCH + np, 0); // sweep table, then tiles per hyperplane
-                std::vector<long> st0(ns, 0);
+                std::vector<int> st0(ns, 0), tab(4 * DF_BATCH, 0);
                 for (int q = 0; q < ns; ++q) {
-                    const int* db = RASTER_SIGN[(phase + q) & 7];
-                    for (int ax = 0; ax < 3; ++ax) h_aux[4 * q + ax] = db[ax];
+                    int da[3], db[3];
+                    ksign(phase + q, db);
+                    for (int ax = 0; ax < 3; ++ax) tab[4 * q + ax] = db[ax];
                     if (q == 0) continue;
-                    const long H = skew_spacing(RASTER_SIGN[(phase + q - 1) & 7], db, nx, ny, nz, ta, nyc, nzc);
-                    h_aux[4 * q + 3] = (int)H;
-                    st0[q] = st0[q - 1] + H;
-                    if (q >= 3) st0[q] = std::max(st0[q], st0[q - 3] + np + 1); // list order respects condition (c)
+                    ksign(phase + q - 1, da);
+                    const long H = skew_spacing(da, db, knx, kny, nz, ta, nyc, nzc);
+                    tab[4 * q + 3] = (int)H;
+                    long s0 = st0[q - 1] + H;
+                    if (q >= nbuf) s0 = std::max<long>(s0, st0[q - nbuf] + np + 1); // list order respects condition (c)
+                    st0[q] = (int)s0;
                 }
-                for (int P = 0; P < np; ++P) h_aux[4 * DF_BATCH + P] = tl->off[P + 1] - tl->off[P];
-                // the entries of the batch in slot order (what the slot schedule would launch, launch after launch)
-                std::vector<uint2> order;
-                order.reserve((size_t)ns * ntiles);
+                bp.nslots = st0[ns - 1] + np;
+                // entries per slot: hyperplane slot - st0[q] of every sweep q in flight
+                std::vector<unsigned> base((size_t)bp.nslots + 1, 0u);
                 int lo_s = 0;
-                for (long slot = 0; lo_s < ns; ++slot) {
+                for (int slot = 0; slot < bp.nslots; ++slot) {
+                    unsigned cnt = 0;
                     for (int q = lo_s; q < ns && st0[q] <= slot; ++q) {
-                        const long P = slot - st0[q];
-                        if (P >= np) continue;
-                        for (int i = tl->off[P]; i < tl->off[P + 1]; ++i)
-                            order.push_back(make_uint2(h_tiles[i], (unsigned)q | ((unsigned)P << DF_SWEEP_BITS)));
+                        const int P = slot - st0[q];
+                        if (P < np) cnt += (unsigned)(tl->off[P + 1] - tl->off[P]);
                     }
+                    base[slot + 1] = base[slot] + cnt;
                     while (lo_s < ns && st0[lo_s] + np <= slot + 1) ++lo_s;
                 }
-                bp.total = (long)order.size();
-                HIPCHK(hipMalloc((void**)&bp.d_order, order.size() * sizeof(uint2)));
-                HIPCHK(hipMalloc((void**)&bp.d_aux, h_aux.size() * sizeof(int)));
-                HIPCHK(hipMemcpy(bp.d_order, order.data(), order.size() * sizeof(uint2), hipMemcpyHostToDevice));
-                HIPCHK(hipMemcpy(bp.d_aux, h_aux.data(), h_aux.size() * sizeof(int), hipMemcpyHostToDevice));
+                bp.total = (long)base[bp.nslots];
+                if (bp.total != (long)ns * ntiles) return fail(LSF_ERR_HIP, "internal: batch plan does not cover every tile");
+                std::vector<int> meta;
+                meta.insert(meta.end(), st0.begin(), st0.end());
+                for (unsigned v : base) meta.push_back((int)v);
+                meta.insert(meta.end(), tab.begin(), tab.end());
+                for (int P = 0; P < np; ++P) meta.push_back(tl->off[P + 1] - tl->off[P]);
+                meta.insert(meta.end(), tl->off.begin(), tl->off.end());
+                HIPCHK(hipMalloc((void**)&bp.d_meta, meta.size() * sizeof(int)));
+                HIPCHK(hipMemcpy(bp.d_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
                 it = c.plans.emplace(key, bp).first;
             }
             const BatchPlan& bp = it->second;
+            const int* m_start = bp.d_meta;
+            const unsigned* m_base = (const unsigned*)(bp.d_meta + ns);
+            const int* m_tab = bp.d_meta + ns + bp.nslots + 1;
+            const int* m_psize = m_tab + 4 * DF_BATCH;
+            const int* m_poff = m_psize + np;
+            if (!marked) prof_mark(st), marked = true; // the timed region starts once the first plan exists
             HIPCHK(hipMemsetAsync(d_cnt, 0, ((size_t)BATCH * np + BATCH + 16) * sizeof(int), st)); // counters, ticket
             HIPCHK(hipMemsetAsync(c.slot[S_BFLAG].p, 0, (size_t)ns * nM * nTj * nTk * sizeof(int), st));
             if (d_dbg) HIPCHK(hipMemsetAsync(d_dbg, 0, 64, st));
-            fa.sweep_tab = bp.d_aux, fa.plane_size = bp.d_aux + 4 * DF_BATCH;
-            fa.order = bp.d_order, fa.total = bp.total;
+            hipLaunchKernelGGL(k_build_order, dim3(bp.nslots), dim3(256), 0, st, (uint2*)c.slot[S_ORDER].p, (const uint32_t*)tl->d,
+                               m_poff, m_start, m_base, ns, np);
+            fa.sweep_tab = m_tab, fa.plane_size = m_psize;
+            fa.order = (const uint2*)c.slot[S_ORDER].p, fa.total = bp.total;
             fa.nsweeps = ns, fa.g0 = g0, fa.np = np;
             fa.plane_cnt = d_cnt, fa.planes_done = d_done, fa.ticket = d_ticket;
             fa.tile_done = (int*)c.slot[S_BFLAG].p, fa.nM = nM;
@@ -737,7 +803,8 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             }
         }
     }
-    const bool slots_loop = !(persist && skew);
+    if (!marked) prof_mark(st);
+    const bool slots_loop = !persist;
     auto launch_tiles = [&](int grid, hipStream_t s_) {
         if (skew) {
 #define LSF_LAUNCH_SKEW(WY_, WZ_)                                                                                          \
@@ -824,20 +891,14 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         g_prof.sweep_launches = launches;
         g_prof.kernel = !slots_loop ? "k_reinit_gs_persist" : (skew ? "k_reinit_gs_skew" : "k_reinit_gs_box");
     }
-    if (fa.buf[nsw % 3] != d_phi)
-        HIPCHK(hipMemcpyAsync(d_phi, fa.buf[nsw % 3], n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (rms_trace && trace_cap > 0 && nsw > 0)
-        HIPCHK(hipMemcpyAsync(rms_trace, c.slot[S_TRACE].p, sizeof(double) * (size_t)std::min(nsw, trace_cap),
-                              hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (sweeps_done) *sweeps_done = nsw;
     if (host_ctl[2] == 2) {
         // A block of the dataflow launch waited 4 s for a predecessor: never observed, but the launch relies on
-        // nothing else going wrong with the device.  When the call's input is still around (phiS was copied from it
-        // on entry) repeat the call on the slot schedule, whose dependencies are launch boundaries.
-        if (!d_phiS_in && g_schedule_override == -2) {
+        // nothing else going wrong with the device.  When the call's input is still around (the transposed launch never
+        // touches the caller's field; otherwise phiS was copied from it on entry) repeat the call on the slot schedule,
+        // whose dependencies are launch boundaries.
+        if ((tr || !d_phiS_in) && g_schedule_override == -2) {
             fprintf(stderr, "[lsf] dataflow launch timed out; repeating the call with slot launches\n");
-            HIPCHK(hipMemcpyAsync(d_phi, c.slot[S_PHIS].p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if (!tr) HIPCHK(hipMemcpyAsync(d_phi, c.slot[S_PHIS].p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
             g_schedule_override = 3;
             rc = reinit_slot_core(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done, rms_trace,
                                   trace_cap, st);
@@ -846,6 +907,17 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         }
         return fail(LSF_ERR_HIP, "exact-GS dataflow schedule timed out waiting for a tile");
     }
+    if (tr) { // back to the caller's layout: the kernel's field has extents (ny + 1, nx + 1, nz + 1)
+        const dim3 tg(cdiv(ny + 1, 32), cdiv(nx + 1, 32), (unsigned)std::min(nz + 1, 1024));
+        hipLaunchKernelGGL(k_transpose_xy, tg, dim3(256), 0, st, (const double*)fa.buf[nsw % nbuf], d_phi, ny + 1, nx + 1,
+                           (long)(nz + 1));
+    } else if (fa.buf[nsw % nbuf] != d_phi)
+        HIPCHK(hipMemcpyAsync(d_phi, fa.buf[nsw % nbuf], n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (rms_trace && trace_cap > 0 && nsw > 0)
+        HIPCHK(hipMemcpyAsync(rms_trace, c.slot[S_TRACE].p, sizeof(double) * (size_t)std::min(nsw, trace_cap),
+                              hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (sweeps_done) *sweeps_done = nsw;
     if (host_ctl[2] == 1) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, subs.f90:926)");
     return LSF_OK;
 }
@@ -1224,8 +1296,7 @@ int lsf_release_workspace(void)
         if (kv.second.buf.p) HIPCHK(hipFree(kv.second.buf.p));
     c.part_by_stream.clear();
     for (auto& kv : c.plans) {
-        if (kv.second.d_order) HIPCHK(hipFree(kv.second.d_order));
-        if (kv.second.d_aux) HIPCHK(hipFree(kv.second.d_aux));
+        if (kv.second.d_meta) HIPCHK(hipFree(kv.second.d_meta));
     }
     c.plans.clear();
     for (auto* lists : {&c.tiles, &c.skew_tiles}) {

@@ -26,8 +26,10 @@ namespace lsf {
 constexpr int DF_SWEEP_BITS = 6, DF_BATCH = 1 << DF_SWEEP_BITS;
 
 struct GsArgs {
-    double* buf[3];     // sweep g reads buf[g % nbuf] and writes buf[(g + 1) % nbuf]
-    int nbuf;           // 3: three sweeps in flight (reinit_slot_core)
+    double* buf[4];     // sweep g reads buf[g % nbuf] and writes buf[(g + 1) % nbuf]
+    int nbuf;           // 3 or 4 buffers in rotation: sweep g overwrites the result of sweep g - nbuf (reinit_slot_core)
+    int quirk_axis;     // kernel axis that carries the reference's p5 = 0 quirk (subs.f90:576): 1 (y), or 0 when the
+                        // library runs the sweep on the x <-> y transposed field (lsf_skew.hpp, "march axis")
     const double* phiS;
     int nx, ny, nz, nTi, nTj, nTk;
     double dx, h;

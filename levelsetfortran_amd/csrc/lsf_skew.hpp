@@ -226,7 +226,7 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
     // ---- per-lane constants ---------------------------------------------------------------------------------
     const int gj = j_lo + (sj > 0 ? bc : nj - 1 - bc), gk = k_lo + (sk > 0 ? cc : nk - 1 - cc);
     const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
-    const bool yquirk = axis == 1;
+    const bool yquirk = axis == a.quirk_axis;
     const int row_core = (cc * NYT + bc) * RA + 3;
     auto row_at = [](int r) { return r < T::NCORE ? r * RA : T::NCORE * RA + (r - T::NCORE) * T::RH - (r < T::YD0 ? 0 : 4); };
     int off[7];
@@ -346,6 +346,61 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Helpers of the dataflow launch
+// ---------------------------------------------------------------------------------------------------------------------
+// x <-> y transposition of a field: dst(j, i, k) = src(i, j, k); src has extents (ex, ey, ez), i unit stride; dst has
+// extents (ey, ex, ez), j unit stride.  The dataflow launch marches its tiles along the axis the raster cycle of the
+// reference flips most often (y: six of the eight transitions, subs.f90:740-855), because a flip of the MARCH axis costs
+// only n / TA time slots of spacing between two sweeps whereas a flip of a cross-section axis costs n / TA + its number of
+// tiles; the kernel marches along its unit-stride axis, so the library runs it on the transposed field (reinit_slot_core).
+__global__ __launch_bounds__(256) void k_transpose_xy(const double* __restrict__ src, double* __restrict__ dst, int ex, int ey,
+                                                      long planes)
+{
+    __shared__ double t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const long pl = (long)ex * ey;
+    for (long k = blockIdx.z; k < planes; k += gridDim.z) {
+        const double* s = src + k * pl;
+        double* d = dst + k * pl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + ty + 8 * r, i = i0 + tx;
+            if (i < ex && j < ey) t[ty + 8 * r][tx] = s[i + (long)ex * j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + ty + 8 * r, j = j0 + tx;
+            if (i < ex && j < ey) d[j + (long)ey * i] = t[tx][ty + 8 * r];
+        }
+        __syncthreads();
+    }
+}
+
+// Task list of a batch, built on the device (the list of a 64-sweep batch at 512^3 is 53 MB: building it on the host and
+// copying it took longer than several sweeps and landed inside the first call that used a new sweep count).  One block
+// per time slot; slot_base[slot] = index of the slot's first entry; the slot holds hyperplane P = slot - start[q] of
+// every sweep q of the batch with 0 <= P < np, in increasing q (exactly what the slot schedule launches, launch after
+// launch).
+__global__ __launch_bounds__(256) void k_build_order(uint2* __restrict__ order, const uint32_t* __restrict__ tiles,
+                                                     const int* __restrict__ plane_off, const int* __restrict__ start,
+                                                     const unsigned* __restrict__ slot_base, int ns, int np)
+{
+    const int slot = blockIdx.x;
+    unsigned base = slot_base[slot];
+    for (int q = 0; q < ns; ++q) {
+        const int P = slot - start[q];
+        if (P < 0) break; // start[] is increasing
+        if (P >= np) continue;
+        const int o = plane_off[P], cnt = plane_off[P + 1] - o;
+        const unsigned tag = (unsigned)q | ((unsigned)P << DF_SWEEP_BITS);
+        for (int i = threadIdx.x; i < cnt; i += 256) order[base + i] = make_uint2(tiles[o + i], tag);
+        base += (unsigned)cnt;
+    }
+}
+
 // Slot schedule: one launch per time slot, one block per tile of the slot (dependencies resolved by launch order).
 template <int TA, int WY, int WZ, bool STRICT>
 __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY == 2 && WZ == 2 ? 5 : 1))) void k_reinit_gs_skew(GsArgs a)
@@ -362,7 +417,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
 // starts (blocks are not assumed to start in index order) and waits until
 //   (a) its up to three upstream tiles of the same sweep are done                  tile_done[s][(m-1,B,C)], ...
 //   (b) sweep s-1 has completed the hyperplanes within stencil reach of this one   planes_done[s-1] >= min(P + H[s], np)
-//   (c) sweep s-3, whose result this sweep overwrites, has its stop verdict        planes_done[s-3] == np + 1
+//   (c) sweep s-nbuf, whose result this sweep overwrites, has its stop verdict     planes_done[s-nbuf] == np + 1 (np + 2: stop)
 // Every entry a block waits for precedes it in the list and was taken by a block that is running or done, so there
 // is no deadlock whatever the dispatch order or the number of resident blocks; every spin is bounded (ctl[2] = 2 on
 // time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
@@ -394,12 +449,12 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
                 const int* w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : nullptr;
                 const int* pd = a.planes_done;
                 const int need1 = s == 0 ? 0 : min(P + a.sweep_tab[4 * s + 3], np);
-                const int need3 = s < 3 ? 0 : np + 1;
+                const int need3 = s < a.nbuf ? 0 : np + 1;
                 // absent conditions point at a word that always passes (the stop flag's neighbour ctl[1] >= 0)
                 const int* always = a.ctl + 1;
                 const int* p0 = w0 ? w0 : nullptr;
                 const int* p3 = s == 0 ? always : pd + s - 1;
-                const int* p4 = s < 3 ? always : pd + s - 3;
+                const int* p4 = s < a.nbuf ? always : pd + s - a.nbuf;
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 go = 1;
                 for (;;) {
@@ -413,7 +468,17 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
                         break;
                     }
                     const bool ok = (v0 != 0) & (v1 != 0) & (v2 != 0) & (v3 >= need1) & (v4 >= need3);
-                    if (ok) break;
+                    if (ok) {
+                        // The verdict of the sweep whose result this one overwrites travels IN the word that releases
+                        // it (np + 2 = that sweep, or an earlier one, raised the stop flag), so it cannot be missed by
+                        // a stop-flag load that was issued before the epilogue's store and a planes_done load that was
+                        // issued after it (the five loads above are independent and relaxed).
+                        if (s >= a.nbuf && v4 == np + 2) {
+                            go = 2;
+                            __hip_atomic_fetch_max(a.ticket, (int)a.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        break;
+                    }
                     if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
                         st_flag(a.ctl + 2, 2);
                         st_flag(a.ctl + 0, 1);
@@ -451,9 +516,13 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
                 for (;;) {
                     int lead = ld_flag(a.planes_done + s);
                     if (lead >= np || ld_flag(a.plane_cnt + s * np + lead) < a.plane_size[lead]) break;
-                    // the tile that completes the last hyperplane has run the sweep epilogue before counting itself
-                    __hip_atomic_compare_exchange_strong(a.planes_done + s, &lead, lead + 1 == np ? np + 1 : lead + 1,
-                                                         __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // the tile that completes the last hyperplane has run the sweep epilogue (stop flag stored and
+                    // drained) before counting itself, and this thread has seen that count: the flag read here is final
+                    // for this sweep.  np + 1 = finished, go on; np + 2 = finished, stop (condition (c) of the waiters).
+                    int next = lead + 1;
+                    if (next == np) next = np + 1 + (ld_flag(a.ctl + 0) != 0 ? 1 : 0);
+                    __hip_atomic_compare_exchange_strong(a.planes_done + s, &lead, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             if (a.dbg) {

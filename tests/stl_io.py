@@ -38,6 +38,15 @@ def grid_from_surface(surfX, dx=0.05, dd=10):
     return n, xLo, mn, mx
 
 
+def grid_from_surface_pads(surfX, dx, pad_lo, pad_hi):
+    """set3d.f90:90-157 with the per-axis pad cells of host edit E4b: n = ceil(extent/dx) + 1 +
+    pad_lo + pad_hi, xLo = min - pad_lo*dx.  pad_lo = pad_hi = (dd, dd, dd) is the reference as shipped."""
+    mn, mx = surfX.min(axis=0), surfX.max(axis=0)
+    n = [int(np.ceil((mx[a] - mn[a]) / dx)) + 1 + int(pad_lo[a]) + int(pad_hi[a]) for a in range(3)]
+    xLo = mn - np.asarray(pad_lo, dtype=np.float64) * dx
+    return n, xLo, mn, mx
+
+
 def stl_write(path, surfX, surfElem):
     """Binary STL from nodes + 1-based connectivity (normals zero: the reference reader ignores them)."""
     tri = np.asarray(surfX, dtype=np.float32)[np.asarray(surfElem) - 1]  # (ntri,3,3)

@@ -382,6 +382,77 @@ def test_reinit_alternative_schedules(lsf, synth, cube40, monkeypatch, schedule)
     assert rep.count == rep2.count and 1 < rep.count < 200 and rep.converged and np.array_equal(phi, phi2)
 
 
+@pytest.mark.parametrize("march,nbuf", [("x", "3"), ("x", "4"), ("y", "3"), ("y", "4")])
+def test_dataflow_march_axis_and_buffer_count(lsf, oracle, synth, cube40, monkeypatch, march, nbuf):
+    """The dataflow launch marches its tiles along the reference's y axis by default (the kernel runs on the x <-> y
+    transposed field: the p5 = 0 quirk of subs.f90:576 moves to the kernel's x lanes, raster signs and extents swap) with
+    four field buffers in rotation; LSF_GS_MARCH=x / LSF_GS_NBUF=3 are the round-1 configuration.  All bit-identical to the
+    reference, including non-cubic grids with partial tiles and the stop sweep."""
+    from levelsetfortran_amd import fields
+
+    monkeypatch.setenv("LSF_GS_MARCH", march)
+    monkeypatch.setenv("LSF_GS_NBUF", nbuf)
+    nx, ny, nz = _n(synth)
+    phi = F(synth["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, 15, float(synth["dx"]), float(synth["h"]), arith="strict")
+    assert rep.count == 16 and np.array_equal(phi, synth["phi_16"])
+    assert np.allclose(rep.rms, synth["rms"], rtol=1e-11, atol=0)
+    for npts in ((6, 10, 8), (34, 13, 11), (10, 42, 14), (65, 8, 30), (23, 23, 5), (70, 21, 45)):
+        phi0, dx = fields.two_sphere_phi0(npts)
+        nx, ny, nz = (v - 1 for v in npts)
+        h = fields.reinit_step(dx)
+        ref = phi0.copy(order="F")
+        _, n_ref, tr_ref = oracle.reinit(ref, nx, ny, nz, 10, dx, h, tol=0.0)
+        t, sgn = _dev(phi0), _dev(phi0)
+        rep = lsf.reinit(t, None, None, nx, ny, nz, 10, dx, h, tol=0.0, arith="strict", phiS=sgn)  # caller's phiS
+        assert rep.count == n_ref == 11, npts
+        assert np.array_equal(_host(t, phi0.shape), ref), npts
+        assert np.array_equal(_host(sgn, phi0.shape), phi0), npts  # the caller's sign field is never written
+        assert np.allclose(rep.rms, tr_ref[:11], rtol=1e-9, atol=0), npts
+    nx, ny, nz = _n(cube40)
+    phi = F(cube40["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, 63, float(cube40["dx"]), float(cube40["h"]), arith="strict")
+    assert rep.count == 64 and sha(phi) == str(cube40["re64_sha"])
+
+
+def test_stop_verdict_at_many_different_sweeps(lsf):
+    """A converged sweep's result must survive the sweeps still in flight behind it: the sweep that would overwrite its
+    buffer learns the verdict from the very word that releases it (planes_done = np + 2), so a stop at ANY sweep index --
+    every position in the buffer rotation, every raster phase -- leaves exactly the field of that sweep.  The tolerance
+    is placed between consecutive running minima of the RMS trace to choose the stop sweep; the same field must come out
+    of a run with that fixed sweep count (same arithmetic, deterministic), for both buffer counts."""
+    import os
+
+    from levelsetfortran_amd import fields
+
+    npts = (88, 75, 66)
+    phi0, dx = fields.two_sphere_phi0(npts)
+    nx, ny, nz = (v - 1 for v in npts)
+    h = fields.reinit_step(dx)
+    t = _dev(phi0)
+    rep = lsf.reinit(t, None, None, nx, ny, nz, 99, dx, h, tol=0.0, arith="fast")
+    tr = np.asarray(rep.rms)
+    assert rep.count == 100
+    ks = [k for k in range(2, 100) if tr[k] < tr[:k].min()]  # sweeps that set a new minimum of the trace
+    assert len(ks) >= 12, len(ks)  # sweeps 2..17 on this field: every residue mod 3, 4 and 8
+    tested = 0
+    for nbuf in ("4", "3"):
+        os.environ["LSF_GS_NBUF"] = nbuf
+        try:
+            for k in ks:
+                tol = 0.5 * (tr[k] + tr[:k].min())
+                a = _dev(phi0)
+                ra = lsf.reinit(a, None, None, nx, ny, nz, 99, dx, h, tol=tol, arith="fast")
+                b = _dev(phi0)
+                rb = lsf.reinit(b, None, None, nx, ny, nz, k, dx, h, tol=0.0, arith="fast")
+                assert ra.converged and ra.count == k + 1 == rb.count, (nbuf, k, ra.count)
+                assert bool((a == b).all()), (nbuf, k)
+                tested += 1
+        finally:
+            del os.environ["LSF_GS_NBUF"]
+    assert tested >= 24
+
+
 # ---------------------------------------------------------------------------------- advection (SURVEY.md 8f rank 3)
 def test_node_advection_matches_reference(lsf, cube40):
     """set3d.f90:464-501 on the GPU: bit-identical advected nodes (host and device seam)."""
