@@ -361,6 +361,77 @@ int check_dims(int nx, int ny, int nz)
     return LSF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// One fp64 Jacobi sweep over the cells [lo, hi) of a box: picks the kernel and its launch geometry.
+//   STRICT            k_reinit_jacobi<true>  (per-cell arithmetic of the reference)
+//   FAST              k_reinit_jacobi_sh<WX, BY> (WENO interfaces shared along x and z); WX = wavefronts a block
+//                     spans along x, chosen so that the 64 WX - 1 cells of a block tile the row with the fewest wavefronts
+//   3-cell x rims     k_reinit_jacobi<., true> (lanes along y)
+// LSF_JAC_SH = 0 forces the per-cell kernel, "WXxBY" a block shape (measurement aids; all FAST choices are bit-identical).
+struct JacPlan {
+    int kind = 0; // 0 per-cell kernel, 1 per-cell THINX, 2 shared-interface kernel
+    dim3 grid;
+    int wx = 1, by = 4, nbx = 0, nby = 0, nbz = 0;
+    long nparts = 0; // partial sums the launch writes
+};
+JacPlan jacobi_plan(const int lo[3], const int hi[3], bool strict)
+{
+    JacPlan p;
+    const int cx = hi[0] - lo[0], cy = hi[1] - lo[1], cz = hi[2] - lo[2];
+    const bool thinx = cx <= 8 && cy >= 32;
+    const char* env = getenv("LSF_JAC_SH");
+    int fwx = 0, fby = 0;
+    const bool off = env && env[0] == '0' && env[1] == 0;
+    if (env && !off && sscanf(env, "%dx%d", &fwx, &fby) != 2) fwx = fby = 0;
+    if (strict || thinx || off) {
+        p.kind = thinx ? 1 : 0;
+        p.grid = thinx ? dim3(cdiv(cy, JAC_BX), cdiv(cx, JAC_BY), cdiv(cz, JAC_KC)) : dim3(cdiv(cx, JAC_BX), cdiv(cy, JAC_BY), cdiv(cz, JAC_KC));
+        p.nparts = (long)p.grid.x * p.grid.y * p.grid.z;
+        return p;
+    }
+    p.kind = 2;
+    int best = 1 << 30;
+    for (int wx : {1, 2, 4, 8}) {
+        const int waves = wx * cdiv(cx, 64 * wx - 1);
+        if (waves < best) best = waves, p.wx = wx;
+    }
+    p.by = p.wx == 1 ? 4 : (p.wx == 2 ? 2 : 1);
+    static const int shapes[][2] = {{1, 4}, {2, 2}, {4, 1}, {4, 2}, {8, 1}};
+    for (auto& sh : shapes)
+        if (sh[0] == fwx && sh[1] == fby) p.wx = fwx, p.by = fby;
+    p.nbx = cdiv(cx, 64 * p.wx - 1), p.nby = cdiv(cy, p.by), p.nbz = cdiv(cz, JAC_KC);
+    const long nblk = (long)p.nbx * p.nby * p.nbz;
+    p.nparts = (nblk + 7) / 8 * 8; // the launch is padded to a multiple of the 8 XCDs (k_reinit_jacobi_sh)
+    p.grid = dim3((unsigned)p.nparts);
+    return p;
+}
+void jacobi_launch(const JacPlan& p, bool strict, const double* A, double* B, const double* phiS, const Box& bx, const int lo[3],
+                   const int hi[3], double dx, double h, double* part, const int* done, hipStream_t st)
+{
+#define LSF_JAC_OLD(ST_, TX_)                                                                                               \
+    hipLaunchKernelGGL((k_reinit_jacobi<ST_, TX_>), p.grid, dim3(JAC_BX, JAC_BY), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], \
+                       hi[0], hi[1], hi[2], dx, h, part, done)
+#define LSF_JAC_SH(WX_, BY_)                                                                                                   \
+    hipLaunchKernelGGL((k_reinit_jacobi_sh<WX_, BY_>), p.grid, dim3(64 * WX_ * BY_), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], \
+                       hi[0], hi[1], hi[2], dx, h, part, done, p.nbx, p.nby, p.nbz)
+    if (p.kind == 2) {
+        const int sh = p.wx * 16 + p.by;
+        if (sh == 0x14) LSF_JAC_SH(1, 4);
+        else if (sh == 0x22) LSF_JAC_SH(2, 2);
+        else if (sh == 0x41) LSF_JAC_SH(4, 1);
+        else if (sh == 0x42) LSF_JAC_SH(4, 2);
+        else LSF_JAC_SH(8, 1);
+    } else if (strict) {
+        if (p.kind == 1) LSF_JAC_OLD(true, true);
+        else LSF_JAC_OLD(true, false);
+    } else {
+        if (p.kind == 1) LSF_JAC_OLD(false, true);
+        else LSF_JAC_OLD(false, false);
+    }
+#undef LSF_JAC_OLD
+#undef LSF_JAC_SH
+}
+
 int gs_schedule();
 int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
                      double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace, int trace_cap,
@@ -400,8 +471,9 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
 
     // sweep geometry (Jacobi only from here on; the exact ordering returned above)
-    const dim3 jgrid(cdiv(nx - 1, JAC_BX), cdiv(ny - 1, JAC_BY), cdiv(nz - 1, JAC_KC));
-    const long n_sweep_part = (long)jgrid.x * jgrid.y * jgrid.z;
+    const int jlo[3] = {1, 1, 1}, jhi[3] = {nx, ny, nz};
+    const JacPlan jp = jacobi_plan(jlo, jhi, strict);
+    const long n_sweep_part = jp.nparts;
     const dim3 bgrid = bc_grid(nx + 1, ny + 1, nz + 1);
     const long n_bc_part = (long)bgrid.x * bgrid.y * bgrid.z;
     const long n_part = n_sweep_part + n_bc_part;
@@ -418,12 +490,7 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
         const double* A = bufs[s & 1];
         double* B = bufs[(s + 1) & 1];
         prof_mark(st);
-        if (strict)
-            hipLaunchKernelGGL((k_reinit_jacobi<true>), jgrid, dim3(JAC_BX, JAC_BY), 0, st, A, B, d_phiS, bx, 1, 1, 1,
-                               nx, ny, nz, dx, h, part, ctl);
-        else
-            hipLaunchKernelGGL((k_reinit_jacobi<false>), jgrid, dim3(JAC_BX, JAC_BY), 0, st, A, B, d_phiS, bx, 1, 1, 1,
-                               nx, ny, nz, dx, h, part, ctl);
+        jacobi_launch(jp, strict, A, B, d_phiS, bx, jlo, jhi, dx, h, part, ctl, st);
         prof_mark(st);
         hipLaunchKernelGGL(k_bc<double>, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, dx,
                            part + n_sweep_part, ctl, 0);
@@ -442,7 +509,7 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     const int nsw = host_ctl[1];
     prof_end(nsw);
     g_prof.sweep_launches = launches_per_sweep * g_prof.sweeps;
-    g_prof.kernel = "k_reinit_jacobi";
+    g_prof.kernel = jp.kind == 2 ? "k_reinit_jacobi_sh" : "k_reinit_jacobi";
     if (bufs[nsw & 1] != d_phi)
         HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (rms_trace && trace_cap > 0 && nsw > 0)
@@ -1551,25 +1618,14 @@ int lsf_jacobi_sweep_box(const double* d_in, double* d_out, const double* d_phiS
     if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) return LSF_OK; // empty region
     if ((rc = sweep_region_ok(box, lo, hi))) return rc;
     hipStream_t st = (hipStream_t)stream;
-    // regions a few cells wide in x (the x rim of a decomposed sweep) run with the lanes along y
-    const bool thinx = hi[0] - lo[0] <= 8 && hi[1] - lo[1] >= 32;
-    const dim3 grid = thinx ? dim3(cdiv(hi[1] - lo[1], JAC_BX), cdiv(hi[0] - lo[0], JAC_BY), cdiv(hi[2] - lo[2], JAC_KC))
-                            : dim3(cdiv(hi[0] - lo[0], JAC_BX), cdiv(hi[1] - lo[1], JAC_BY), cdiv(hi[2] - lo[2], JAC_KC));
-    const long np = (long)grid.x * grid.y * grid.z;
+    // regions a few cells wide in x (the x rim of a decomposed sweep) run with the lanes along y (jacobi_plan)
+    const bool strict = (mode & LSF_ARITH_STRICT) != 0;
+    const JacPlan jp = jacobi_plan(lo, hi, strict);
+    const long np = jp.nparts;
     double* part = nullptr;
     if ((rc = stream_partials(st, (size_t)np, &part))) return rc;
     const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
-#define LSF_LAUNCH_JAC(ST_, TX_)                                                                                      \
-    hipLaunchKernelGGL((k_reinit_jacobi<ST_, TX_>), grid, dim3(JAC_BX, JAC_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0], \
-                       lo[1], lo[2], hi[0], hi[1], hi[2], dx, h, part, (const int*)nullptr)
-    if (mode & LSF_ARITH_STRICT) {
-        if (thinx) LSF_LAUNCH_JAC(true, true);
-        else LSF_LAUNCH_JAC(true, false);
-    } else {
-        if (thinx) LSF_LAUNCH_JAC(false, true);
-        else LSF_LAUNCH_JAC(false, false);
-    }
-#undef LSF_LAUNCH_JAC
+    jacobi_launch(jp, strict, d_in, d_out, d_phiS, bx, lo, hi, dx, h, part, nullptr, st);
     return finish_partials(st, part, np, d_sumsq);
 }
 

@@ -203,6 +203,60 @@ __device__ __forceinline__ void weno_axis_fast(const double q[7], double floor2,
     dp = __builtin_fma(1.0 / 12.0, cen12, PWp);
 }
 
+// ---------------------------------------------------------------------------------------------
+// FAST, interface form (Jacobi ordering only).  In a double-buffered sweep D+ of cell i and D- of cell i+1 are
+// built from the SAME six points phi(i-2..i+3): the three smoothness indicators (subs.f90:518-523; IS0p(i) =
+// IS2m(i+1), IS1p(i) = IS1m(i+1), IS2p(i) = IS0m(i+1)), the epsilon (the five first differences of :533 for cell i
+// are those of :534 for cell i+1) and the products of the weights are shared; only the two normalisations and
+// corrections differ.  One interface costs 61 operations for two one-sided corrections where the per-cell form
+// (weno_axis_fast) spends 90 on the two sides of one cell.  (Not valid in the reference's in-place ordering: there
+// the centre value differs between the two uses.  Not bit-compatible with the reference either -- the second
+// differences are associated differently on the two sides of a cell, subs.f90:509-513 -- hence FAST only.)
+//
+// v[0..5] = phi(i-2 .. i+3).  Unscaled like weno_axis_fast (the caller multiplies by 1/dx once):
+//     D+_i * dx     = cen12_i / 12 + pwp          cen12 = -d1 + 7 d2 + 7 d3 - d4 of cell i
+//     D-_{i+1} * dx = cen12_{i+1} / 12 - pwm
+// The y axis (p5 = 0 in eps+ only, subs.f90:576) keeps the per-cell form.
+__device__ __forceinline__ void weno_iface_fast(const double v[6], double floor2, double& pwp, double& pwm, double& cen12)
+{
+#pragma clang fp contract(off) // every fused operation is written out: the same bits in every kernel that calls this
+    const double d1 = v[1] - v[0], d2 = v[2] - v[1], d3 = v[3] - v[2], d4 = v[4] - v[3], d5 = v[5] - v[4];
+    const double um = d2 - d1, u0 = d3 - d2, u1 = d4 - d3, u2 = d5 - d4; // second differences at i-1 .. i+2
+    const double e_ab = u2 - u1, e_bc = u1 - u0, e_cm = u0 - um;
+    const double t0 = __builtin_fma(-3.0, u1, u2), t1 = u1 + u0, t2 = __builtin_fma(3.0, u0, -um);
+    const double mx = __builtin_fmax(__builtin_fmax(__builtin_fmax(__builtin_fabs(d1), __builtin_fabs(d2)),
+                                                    __builtin_fmax(__builtin_fabs(d3), __builtin_fabs(d4))),
+                                     __builtin_fabs(d5));
+    constexpr double C = 13.0 / 3.0;
+    const double eps = __builtin_fma((1.E-6 / 3.0) * mx, mx, C * floor2);
+    const double q0 = __builtin_fma(t0, t0, __builtin_fma(C * e_ab, e_ab, eps));
+    const double q1 = __builtin_fma(t1, t1, __builtin_fma(C * e_bc, e_bc, eps));
+    const double q2 = __builtin_fma(t2, t2, __builtin_fma(C * e_cm, e_cm, eps));
+    const double t12 = q1 * q2, t02 = q0 * q2, t01 = q0 * q1;
+    const double n0 = t12 * t12, n1 = t02 * t02, m2 = t01 * t01;
+    const double Dp = __builtin_fma(3.0, m2, __builtin_fma(6.0, n1, n0)); // plus side of cell i:    1, 6, 3
+    const double Dm = __builtin_fma(3.0, n0, __builtin_fma(6.0, n1, m2)); // minus side of cell i+1: mirrored
+    const double R = rcp_nr(__builtin_fmax(Dp * Dm, 1e-300));
+    const double rp = Dm * R, rm = Dp * R;
+    const double Sa = e_ab - e_bc, S0 = e_bc - e_cm;
+    pwp = __builtin_fma(rp, __builtin_fma(n0 * (1.0 / 3.0), Sa, m2 * (0.5 * S0)), -(S0 * (1.0 / 12.0)));
+    pwm = __builtin_fma(rm, __builtin_fma(m2 * (1.0 / 3.0), S0, n0 * (0.5 * Sa)), -(Sa * (1.0 / 12.0)));
+    cen12 = __builtin_fma(7.0, d2 + d3, -(d1 + d4));
+}
+
+// the two one-sided differences of ONE cell from its two interfaces (q[0..6] = -3..+3): what a kernel that cannot
+// share interfaces between lanes (thin rims of a block-decomposed sweep) uses, so that every fp64 Jacobi kernel of the
+// library returns the same bits for the same cell
+__device__ __forceinline__ void weno_axis_from_ifaces(const double q[7], double floor2, double& dm, double& dp)
+{
+#pragma clang fp contract(off)
+    double pwp_l, pwm_c, cen_l, pwp_c, pwm_r, cen_c;
+    weno_iface_fast(q, floor2, pwp_l, pwm_c, cen_l);
+    weno_iface_fast(q + 1, floor2, pwp_c, pwm_r, cen_c);
+    dm = __builtin_fma(1.0 / 12.0, cen_c, -pwm_c);
+    dp = __builtin_fma(1.0 / 12.0, cen_c, pwp_c);
+}
+
 template <bool STRICT>
 __device__ __forceinline__ void axis_pair(const double q[7], bool weno_ok, bool yquirk, double dx, double floor2,
                                           double& dm, double& dp);
@@ -217,9 +271,16 @@ __device__ __forceinline__ double cell_update_fast(const double qx[7], const dou
                                                    double inv_dx, double floor2, double h)
 {
     double a, b, c, d, e, f; // unscaled one-sided differences (true value * dx)
-    axis_pair<false>(qx, weno_ok, false, dx, floor2, a, b);
+    // x and z in the interface form (the arithmetic of k_reinit_jacobi_sh, which shares each interface between two
+    // cells), y in the per-cell form
+    if (weno_ok) {
+        weno_axis_from_ifaces(qx, floor2, a, b);
+        weno_axis_from_ifaces(qz, floor2, e, f);
+    } else {
+        a = qx[3] - qx[2], b = qx[4] - qx[3];
+        e = qz[3] - qz[2], f = qz[4] - qz[3];
+    }
     axis_pair<false>(qy, weno_ok, true, dx, floor2, c, d);
-    axis_pair<false>(qz, weno_ok, false, dx, floor2, e, f);
     const double phic = qx[3];
     return finish_update<false>(phic, axis_godunov<false>(phic, a, b), axis_godunov<false>(phic, c, d),
                                 axis_godunov<false>(phic, e, f), pS, dx, inv_dx, h);

@@ -23,6 +23,14 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// lane l receives the value of lane l - 1 of the wavefront (lane 0: undefined), DPP wave_shr:1
+__device__ __forceinline__ double dpp_shr1(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // =============================================================================================
 // Reinit, Jacobi ordering on a box region.  Thread (i,j) marches KC cells in k with a 7-deep
 // register window; x/y neighbours come through the vector L1/L2.
@@ -128,6 +136,155 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi
         double t = 0.0;
         for (int w = 0; w < JAC_BX * JAC_BY / 64; ++w) t += red[w];
         partials[blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)] = t;
+    }
+}
+
+// =============================================================================================
+// Reinit, Jacobi ordering, FAST arithmetic, WENO interfaces SHARED between neighbouring cells along x and z
+// (lsf_cell.hpp: weno_iface_fast).  SURVEY.md section 0 fact 5: the sweep is bound by the fp64 vector unit, and the
+// lever is to compute every quadratic form once -- D+ of cell i and D- of cell i+1 are the two outputs of ONE
+// interface evaluation.
+//   z (march axis): the interface k+1/2 evaluated at step k leaves D- of cell k+1 in a register for step k+1.
+//   x (lanes):      lane i evaluates the interface i+1/2 and hands the D- correction to lane i+1 with one DPP
+//                   wave_shr:1; the first lane of a wavefront takes it from the last lane of the wavefront to its left
+//                   through LDS (double-buffered, one workgroup barrier per step).  A block spans 64 WX lanes along x;
+//                   its first lane is a helper (it only evaluates an interface), so a block covers 64 WX - 1 cells:
+//                   510 = 2 x 255 at 512^3 with WX = 4, 254 = 2 x 127 at 256^3 with WX = 2, 1022 = 2 x 511 with WX = 8.
+//   y:              per-cell form (the p5 = 0 quirk of subs.f90:576 makes the two sides of a y interface differ; the rows
+//                   of a block are BY apart wavefronts).
+// Blocks are numbered so that the blocks an XCD receives (every 8th of the launch order) cover a contiguous range of rows:
+// the y neighbours a block loads are then in its own L2.
+// 66 + 66 + 90 operations for the three axes instead of 3 x 90.  Bit-identical to k_reinit_jacobi<false> (whose FAST
+// arithmetic evaluates the same interfaces twice per cell), which stays for the 3-cell x rims (THINX).
+// =============================================================================================
+template <int WX, int BY>
+__global__ __launch_bounds__(64 * WX * BY) __attribute__((amdgpu_waves_per_eu(5))) void k_reinit_jacobi_sh(const double* __restrict__ A, double* __restrict__ Bout,
+                                                                     const double* __restrict__ phiS, Box bx, int lo0, int lo1,
+                                                                     int lo2, int hi0, int hi1, int hi2, double dx, double h,
+                                                                     double* __restrict__ partials, const int* __restrict__ done,
+                                                                     int nbx, int nby, int nbz)
+{
+    constexpr int NW = WX * BY;
+    __shared__ double red[NW];
+    __shared__ double xch[2][BY][WX];
+    if (done && *done) return;
+    // XCD-aware numbering: launch index id -> logical block L; the 8 XCDs take ids round robin, XCD x gets the logical
+    // blocks [x * per, (x + 1) * per)
+    const unsigned per = gridDim.x >> 3;
+    const unsigned L = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const unsigned nblk = (unsigned)nbx * nby * nbz;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wx = wave % WX, ry = wave / WX;
+    double acc = 0.0;
+    if (L < nblk) {
+        const int bxi = (int)(L % (unsigned)nbx), byi = (int)((L / (unsigned)nbx) % (unsigned)nby), bzi = (int)(L / ((unsigned)nbx * nby));
+        const int xl = 64 * wx + lane;                         // lane position inside the block, 0 = helper
+        const int li = lo0 - 1 + bxi * (64 * WX - 1) + xl;     // local x index of the lane's point (>= 0: lo0 >= 1)
+        const int lj = lo1 + byi * BY + ry;
+        const int k0 = lo2 + bzi * JAC_KC, k1 = min(k0 + JAC_KC, hi2);
+        const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
+        const bool cell = xl >= 1 && li < hi0 && lj < hi1;     // the lane owns a cell of this launch
+        const int gi = li + bx.gx0, gj = lj + bx.gy0;
+        const bool ij_weno = gi > 3 && gi < bx.nx - 4 && gj > 3 && gj < bx.ny - 4;
+        const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
+        // Addressing: one buffer descriptor per k-plane (rebuilt on the scalar unit every step, base = the plane) + 32-bit
+        // byte offsets inside the plane that do not change along the march.  No load of the loop sits behind a branch:
+        //   x: the six points li-2 .. li+3 are `colx` + immediates; the offset may leave the row or wrap below zero near a
+        //      wall -- the range check of the descriptor then returns 0 (below the plane / beyond it) or the value of a
+        //      neighbouring row, and neither is used: a WENO cell has all six points in its row, a first-order cell reads
+        //      li +- 1 only, which always exist;
+        //   y: six offsets with the row clamped into the plane (same argument).
+        const unsigned plane_bytes = 8u * (unsigned)sxy;
+        const int lic = min(li, bx.lx - 1), ljc = min(lj, bx.ly - 1);
+        const unsigned col = 8u * (unsigned)(lic + sx * ljc);
+        const unsigned colx = col - 16u;
+        unsigned oy[7];
+#pragma unroll
+        for (int m = 0; m < 7; ++m) oy[m] = 8u * (unsigned)(lic + sx * min(max(ljc - 3 + m, 0), bx.ly - 1));
+        auto desc = [&](const double* base) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, (int)plane_bytes, 0x00020000);
+        };
+        auto at = [](__amdgpu_buffer_rsrc_t r, unsigned boff) -> double {
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, boff, 0, 0);
+            return __hiloint2double((int)v.y, (int)v.x);
+        };
+        auto ldz = [&](int k) -> double { return at(desc(A + sxy * min(max(k, 0), bx.lz - 1)), col); };
+        double qz[7];
+#pragma unroll
+        for (int m = 0; m < 7; ++m) qz[m] = ldz(k0 - 4 + m); // shifted by one: the loop shifts before it uses the window
+        // D- correction of the first cell of the chunk: interface k0 - 1/2, points k0-3 .. k0+2 (consumed by WENO cells
+        // only, whose window is real data)
+        double pwm_z;
+        {
+            double t0_, t1_;
+            weno_iface_fast(qz + 1, floor2, t0_, pwm_z, t1_);
+        }
+        int pb = 0;
+        for (int k = k0; k < k1; ++k) {
+            const auto P = desc(A + sxy * k);
+            // ---- x and z loads, z interface k + 1/2, then the y loads (in flight during the x interface)
+            double vx[6], qy[7];
+#pragma unroll
+            for (int m = 0; m < 6; ++m)
+                if (m != 2) vx[m] = at(P, colx + 8u * (unsigned)m);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) qz[m] = qz[m + 1];
+            qz[6] = ldz(k + 3);
+            const double phic = qz[3];
+            vx[2] = phic;
+            const int gk = k + bx.gz0;
+            const bool weno_ok = ij_weno && gk > 3 && gk < bx.nz - 4;
+            double pwp_z, pwm_z_next, cen_z, pwp_x, pwm_x, cen_x;
+            weno_iface_fast(qz + 1, floor2, pwp_z, pwm_z_next, cen_z);
+#pragma unroll
+            for (int m = 0; m < 7; ++m)
+                if (m != 3) qy[m] = at(P, oy[m]);
+            qy[3] = phic;
+            const double pS = at(desc(phiS + sxy * k), col);
+            weno_iface_fast(vx, floor2, pwp_x, pwm_x, cen_x);
+            // hand the D- correction to the lane on the right
+            double pwm_l = dpp_shr1(pwm_x);
+            if (WX > 1) {
+                if (lane == 63) xch[pb][ry][wx] = pwm_x;
+                // LDS hand-off only: no global access has to be visible across the barrier, so do not drain the loads
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (lane == 0 && wx > 0) pwm_l = xch[pb][ry][wx - 1];
+                pb ^= 1;
+            }
+            // ---- y (per-cell form), Godunov, sign, Euler step
+            double a, b, c, d, e, f;
+            if (weno_ok) {
+                a = __builtin_fma(1.0 / 12.0, cen_x, -pwm_l);
+                b = __builtin_fma(1.0 / 12.0, cen_x, pwp_x);
+                e = __builtin_fma(1.0 / 12.0, cen_z, -pwm_z);
+                f = __builtin_fma(1.0 / 12.0, cen_z, pwp_z);
+            } else {
+                a = phic - vx[1], b = vx[3] - phic;
+                e = phic - qz[2], f = qz[4] - phic;
+            }
+            axis_pair<false>(qy, weno_ok, true, dx, floor2, c, d);
+            const double newv = finish_update<false>(phic, axis_godunov<false>(phic, a, b), axis_godunov<false>(phic, c, d),
+                                                     axis_godunov<false>(phic, e, f), pS, dx, inv_dx, h);
+            if (cell) {
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                u2 w;
+                w.x = (unsigned)__double2loint(newv);
+                w.y = (unsigned)__double2hiint(newv);
+                __builtin_amdgcn_raw_buffer_store_b64(w, desc(Bout + sxy * k), col, 0, 0);
+                const double dlt = newv - phic;
+                acc = __builtin_fma(dlt, dlt, acc);
+            }
+            pwm_z = pwm_z_next;
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NW; ++w) t += red[w];
+        partials[L] = t;
     }
 }
 

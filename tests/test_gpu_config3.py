@@ -1,0 +1,124 @@
+"""BASELINE config 3 at its stated size: twoCube10.stl on a CUBIC 512^3 grid (per-axis pad cells, host edit E4b),
+WENO5 reinit at a fixed sweep count (the surface diverges later in the reference itself) + 200
+min/max-flow iterations.  Fixtures: tests/golden/make_golden_c3_cubic.py (phi0 by the pinned oracle, the sweeps by the
+reference's OWN `reinit`, min/max by the pinned oracle; SHA-256 of every full field + strided samples).
+
+Two routes: the device seam of the C ABI, stage by stage (phi0 search, reinit, narrowBand, min/max flow in both exact
+executors), and the reference's Fortran host through the drop-in executable, parameters from a namelist file."""
+import hashlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "build", "dropin", "set3d_hip.exec")
+
+
+def _fixture(sweeps):
+    path = os.path.join(GOLDEN, f"twocube10_512cubed_s{sweeps}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not generated")
+    return np.load(path)
+
+
+def _sha_t(t):
+    return hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
+
+
+def _smp(t, shape):
+    return t.cpu().numpy().reshape(shape, order="F")[::16, ::8, ::8]
+
+
+@pytest.mark.parametrize("sweeps", [16, 128])
+def test_config3_cubic_512_stage_by_stage_on_the_device(sweeps, monkeypatch):
+    import torch
+
+    import levelsetfortran_amd as lsf
+    import stl_io
+
+    g = _fixture(sweeps)
+    s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    X, E = s["twocube10_surfX"].astype(np.float64), s["twocube10_surfElem"]
+    dx = float(g["dx"])
+    n, xLo, mn, mx = stl_io.grid_from_surface_pads(X, dx, g["pad_lo"], g["pad_hi"])
+    assert tuple(n) == tuple(int(v) for v in g["n"]) == (511, 511, 511)
+    nx, ny, nz = n
+    shape = (nx + 1, ny + 1, nz + 1)
+    npts = shape[0] * shape[1] * shape[2]
+    # phi0: inside/outside search (set3d.f90:196-268) on the device
+    phi = torch.ones(npts, dtype=torch.float64, device="cuda")
+    lsf.phi0Init(phi, nx, ny, nz, dx, xLo, mn, mx, X, E)
+    assert _sha_t(phi) == str(g["phi0_sha"])
+    # reinit: the reference's raster order, STRICT arithmetic == the reference's own reinit
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, sweeps - 1, dx, float(g["h"]), arith="strict")
+    assert rep.count == sweeps and not rep.converged
+    assert np.array_equal(_smp(phi, shape), g["reinit_sample"])
+    assert _sha_t(phi) == str(g["reinit_sha"])
+    assert np.allclose(rep.rms, g["rms"], rtol=1e-7, atol=0)  # sequential sum of 1.3e8 squares vs tree
+    # narrowBand
+    nb = torch.zeros(npts, dtype=torch.int32, device="cuda")
+    sb = torch.zeros(npts, dtype=torch.int32, device="cuda")
+    lsf.narrowBand(nx, ny, nz, dx, phi, nb, sb)
+    assert _sha_t(nb) == str(g["NB0_sha"]) and _sha_t(sb) == str(g["SB0_sha"])
+    # min/max flow, 200 iterations: fixed-point executor (default) and tile-hyperplane executor
+    for tiles in (False, True):
+        if tiles:
+            monkeypatch.setenv("LSF_MINMAX_TILES", "1")
+        p2, nb2, sb2 = phi.clone(), nb.clone(), sb.clone()
+        rm = lsf.minmaxFlow(p2, nb2, sb2, nx, ny, nz, 200, dx, float(g["h1"]))
+        assert rm.count == int(g["mm_iters"]), (tiles, rm.count)
+        assert np.array_equal(_smp(p2, shape), g["minmax_sample"]), tiles
+        assert _sha_t(p2) == str(g["minmax_sha"]), tiles
+        assert _sha_t(nb2) == str(g["NB_sha"]) and _sha_t(sb2) == str(g["SB_sha"]), tiles
+        assert np.allclose(rm.rms, g["rms_minmax"], rtol=1e-7, atol=0), tiles
+        del p2, nb2, sb2
+    # FAST arithmetic against the reference's field (north_star: 1e-10 RMS, inside/outside exact)
+    ref = phi.clone()
+    lsf.phi0Init(phi, nx, ny, nz, dx, xLo, mn, mx, X, E)
+    lsf.reinit(phi, None, None, nx, ny, nz, sweeps - 1, dx, float(g["h"]), arith="fast")
+    d = phi - ref
+    assert float(torch.sqrt(torch.mean(d * d))) < 1e-12
+    # phi0 has exact zeros (grid points in a triangle's plane): compare the classification
+    assert bool(((phi < 0) == (ref < 0)).all())
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="drop-in executable not built")
+def test_config3_cubic_512_through_the_fortran_host_with_a_namelist(tmp_path):
+    """The reference's own main program at 512^3: parameters from &lsf_inputs (the namelist the reference's README
+    announces), per-axis pad cells, 128 sweeps + 200 min/max iterations; both .vti payloads == the fixtures."""
+    import stl_io
+
+    g = _fixture(128)
+    s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    stl_io.stl_write(tmp_path / "twoCube10.stl", s["twocube10_surfX"], s["twocube10_surfElem"])
+    lo, hi = g["pad_lo"], g["pad_hi"]
+    (tmp_path / "config3.nml").write_text(
+        "&lsf_inputs\n"
+        f"  dx = {float(g['dx'])!r}\n"
+        f"  dd_lo = {int(lo[0])}, {int(lo[1])}, {int(lo[2])}\n"
+        f"  dd_hi = {int(hi[0])}, {int(hi[1])}, {int(hi[2])}\n"
+        f"  reinit_iter = {int(g['sweeps']) - 1}\n"
+        "  minmax_iter = 200\n"
+        "  reinit2_iter = 0\n"
+        "  arith = 'strict'\n"
+        "/\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LSF_")}
+    p = subprocess.run(f"ulimit -s unlimited; cd {tmp_path}; {EXE} twoCube10.stl config3.nml", shell=True, env=env, text=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800)
+    out = p.stdout
+    assert p.returncode == 0, out[-3000:]
+    assert "Run parameters read from config3.nml" in out
+    assert "Grid Size: nx = 511 , ny = 511 ,nz = 511" in out
+    its = [int(x) for x in re.findall(r"Iteration:\s+(\d+)", out)]
+    assert its[:128] == list(range(128)) and its[128:328] == list(range(1, 201))
+    shape = (512, 512, 512)
+    for name, key in (("signedDistanceFunction.vti", "reinit"), ("smoothedDistanceFunction.vti", "minmax")):
+        a = stl_io.vti_read_phi(tmp_path / name, shape)
+        assert np.array_equal(a[::16, ::8, ::8], g[key + "_sample"]), name
+        assert hashlib.sha256(np.ascontiguousarray(a.ravel(order="F")).tobytes()).hexdigest() == str(g[key + "_sha"]), name
+        del a

@@ -145,6 +145,61 @@ def test_reinit_jacobi_matches_oracle_jacobi(lsf, oracle, synth):
     assert _rms(phi, ref) < FAST_RMS_TOL
 
 
+@pytest.mark.parametrize("shape", ["1x4", "2x2", "4x1", "4x2", "8x1", None])
+def test_jacobi_shared_interface_kernel_equals_per_cell_kernel(lsf, oracle, monkeypatch, shape):
+    """FAST Jacobi sweeps run k_reinit_jacobi_sh (WENO interfaces shared along x and z, lsf_cell.hpp) in one of five
+    block shapes (auto-selected from the row length unless LSF_JAC_SH says otherwise).  Every shape must return the bits
+    of the per-cell kernel (LSF_JAC_SH=0, which evaluates the same interfaces twice per cell) -- on grids whose rows
+    need helper lanes in the middle (130 and 300 cells per row), that end exactly at a block boundary (64, 128), that
+    are shorter than one block, with partial rows of blocks in y and partial chunks in z -- and stay within the FAST
+    tolerance of the oracle's Jacobi sweep."""
+    from levelsetfortran_amd import fields
+
+    for npts in ((24, 24, 24), (66, 21, 37), (130, 11, 9), (132, 18, 35), (302, 9, 12), (35, 70, 40)):
+        phi0, dx = fields.two_sphere_phi0(npts)
+        nx, ny, nz = (v - 1 for v in npts)
+        h = fields.reinit_step(dx)
+        monkeypatch.setenv("LSF_JAC_SH", "0")
+        base = _dev(phi0)
+        r0 = lsf.reinit(base, None, None, nx, ny, nz, 4, dx, h, tol=0.0, order="jacobi", arith="fast")
+        if shape:
+            monkeypatch.setenv("LSF_JAC_SH", shape)
+        else:
+            monkeypatch.delenv("LSF_JAC_SH")
+        t = _dev(phi0)
+        r1 = lsf.reinit(t, None, None, nx, ny, nz, 4, dx, h, tol=0.0, order="jacobi", arith="fast")
+        assert r0.count == r1.count == 5
+        assert bool((t == base).all()), (shape, npts, float((t - base).abs().max()))
+        assert np.allclose(r0.rms, r1.rms, rtol=1e-12, atol=0)
+        ref = phi0.copy(order="F")
+        oracle.reinit(ref, nx, ny, nz, 4, dx, h, tol=0.0, order=oracle.JACOBI)
+        assert _rms(_host(t, phi0.shape), ref) < FAST_RMS_TOL, (shape, npts)
+
+
+def test_jacobi_fast_decomposed_equals_single_domain_bitwise(lsf, monkeypatch):
+    """The block-decomposed sweep (core through the shared-interface kernel, 3-cell x rims through the per-cell THINX
+    kernel, y and z rims as thin shared-interface launches) returns the bits of the single-domain FAST sweep."""
+    import torch
+
+    from levelsetfortran_amd import distributed as D
+    from levelsetfortran_amd import fields
+
+    npts = (140, 45, 38)
+    phi0, dx = fields.two_sphere_phi0(npts)
+    nx, ny, nz = (v - 1 for v in npts)
+    h = fields.reinit_step(dx)
+    whole = _dev(phi0)
+    lsf.reinit(whole, None, None, nx, ny, nz, 2, dx, h, tol=0.0, order="jacobi", arith="fast")
+    be = D.HipBackend(torch.device("cuda", 0), arith="fast")
+    b = D.make_block(0, (1, 1, 1), (nx, ny, nz))
+    dr = D.DistributedReinit(be, b, dx, h)
+    fake = D.Block((3, 3, 3), (1, 1, 1), b.n, b.own, b.g0, b.ext)
+    dr.core, dr.rims = D.sweep_regions(fake)
+    assert len(dr.rims) == 6
+    out, nsw, _ = dr.run(be.from_numpy(phi0), 2, tol=0.0)
+    assert nsw == 3 and np.array_equal(be.to_numpy(out, b.ext), _host(whole, phi0.shape))
+
+
 def test_box_building_blocks_single_rank(lsf, oracle, synth):
     """lsf_jacobi_sweep_box + lsf_bc_box + pack/unpack (the multi-GPU pieces) on one GPU, split into
     core + rims exactly as a rank of a 2x2x2 decomposition would."""
