@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSF_VERSION 101 /* 0.1.1: single-precision entry points added */
+#define LSF_VERSION 102 /* 0.1.2: device-resident chain (lsf_mirror, lsf_write_vti, ...) */
 
 /* ---- return codes ---------------------------------------------------------------------- */
 #define LSF_OK 0
@@ -143,6 +143,34 @@ int lsf_advect_nodes(const double *phi, const int32_t *phiSB, int nx, int ny, in
                      const double xLo[3], double *surfXX, int nSurfNode, int iters);
 int lsf_advect_nodes_device(const double *d_phi, const int32_t *d_phiSB, int nx, int ny, int nz, double dx,
                             const double xLo[3], double *surfXX, int nSurfNode, int iters, void *stream);
+
+/* ---- device-resident chain behind the host seams -----------------
+ * The reference's main program hands the same arrays from seam to seam (set3d.f90:196-582: inside/outside search ->
+ * reinit #1 -> narrowBand -> min/max flow -> node advection -> reinit #2) and never changes them in between.  The
+ * host-pointer entry points above keep the device copies of phi / phiNB / phiSB they worked on ("twins", tagged with the
+ * host address and size).  lsf_mirror() lets a host that knows its own data flow use them:
+ *   LSF_MIRROR_TRUST  a seam call whose host pointer and size match a current twin skips the host-to-device copy
+ *                     (promise: the host has not written the array since the last seam call);
+ *   LSF_MIRROR_LAZY   seam calls do not copy results back (promise: the host does not READ phi / phiNB / phiSB until it
+ *                     has called lsf_mirror_sync on them); implies LSF_MIRROR_TRUST.
+ * With both set the whole chain crosses PCIe once per array at most.  Default 0: every call copies in and out.
+ * What the reference host does with phi between the seams has twins too:
+ *   lsf_snapshot     phiO = phi                                   (set3d.f90:311)
+ *   lsf_sumsq_diff   sum((phi - phiO)^2) over all points          (set3d.f90:505-516, the "Asymptotic Error")
+ *   lsf_write_vti    the VTK ImageData writers                    (set3d.f90:319-351, :538-569)
+ * Each works on the twins when they are current and on the host arrays otherwise.  */
+#define LSF_MIRROR_TRUST 1
+#define LSF_MIRROR_LAZY 2
+int lsf_mirror(int flags);
+/* copies the twin of `host` (phi, phiNB or phiSB of an earlier seam call) back if the host copy is stale */
+int lsf_mirror_sync(void *host);
+int lsf_snapshot(const double *phi, double *phiO, int nx, int ny, int nz);
+int lsf_sumsq_diff(const double *phi, const double *phiO, int nx, int ny, int nz, double *sum);
+/* Writes `phi` as VTK ImageData (raw appended Float64, i fastest) with the reference's header text.  The reference
+ * writes an INTEGER*4 byte count that is 3 x too large and overflows at >= 448^3 points (set3d.f90:330); this writer
+ * stores the true count, as UInt32 when it fits and with header_type="UInt64" otherwise.  The payload streams from the
+ * device twin through two pinned staging buffers (copy of chunk n + 1 overlaps the write of chunk n). */
+int lsf_write_vti(const char *path, const double *phi, int nx, int ny, int nz, double dx, const double xLo[3]);
 
 /* ---- block-decomposed building blocks (multi-GPU Jacobi; one process per GPU) -------------
  * A rank holds a box of the global field: local extents (lx,ly,lz), whose element (0,0,0) is the

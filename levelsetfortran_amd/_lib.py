@@ -19,6 +19,9 @@ LSF_ORDER_GS, LSF_ORDER_JACOBI = 0, 1
 LSF_ARITH_FAST, LSF_ARITH_STRICT = 0x000, 0x100
 
 
+LSF_MIRROR_TRUST, LSF_MIRROR_LAZY = 1, 2  # include/lsf.h: lsf_mirror flags
+
+
 class LsfBox(ctypes.Structure):
     """struct lsf_box (include/lsf.h)."""
 
@@ -65,6 +68,11 @@ SIGNATURES = {
     "lsf_advect_nodes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_int, c_int]),
     "lsf_advect_nodes_device": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_int,
                                         c_int, c_void_p]),
+    "lsf_mirror": (c_int, [c_int]),
+    "lsf_mirror_sync": (c_int, [c_void_p]),
+    "lsf_snapshot": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int]),
+    "lsf_sumsq_diff": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_double)]),
+    "lsf_write_vti": (c_int, [ctypes.c_char_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p]),
     "lsf_jacobi_sweep_box": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3,
                                      c_double, c_double, c_int, c_void_p, c_void_p]),
     "lsf_bc_box": (c_int, [c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_double, c_void_p,

@@ -123,7 +123,7 @@ struct BatchPlan {
     int nslots = 0;
 };
 
-enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_PLANECNT, S_DBG, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_PONG3, S_PONG4, S_NSLOTS };
+enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_PLANECNT, S_DBG, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_PONG3, S_PONG4, S_SNAP, S_NSLOTS };
 
 // partial sums of the box calls issued on one stream; `deferred`: between lsf_sumsq_begin and lsf_sumsq_end the calls
 // append their partials instead of reducing them one by one
@@ -134,8 +134,18 @@ struct StreamPart {
     double* target = nullptr; // the d_sumsq of the deferred calls
 };
 
+// device twin of a host array handed through the host seams (lsf_mirror)
+struct Twin {
+    const void* host = nullptr;
+    size_t bytes = 0;
+    bool current = false;    // the device copy holds the latest content
+    bool host_stale = false; // ... and the host copy does not (LSF_MIRROR_LAZY)
+};
+
 struct Ctx {
     Buf slot[S_NSLOTS];
+    Twin twin_phi, twin_nb, twin_sb, twin_snap; // S_HPHI, S_HNB, S_HSB, S_SNAP
+    int mirror = 0;
     std::map<hipStream_t, StreamPart> part_by_stream;
     std::map<uint64_t, TileList> tiles;
     std::map<uint64_t, TileList> skew_tiles;
@@ -1306,6 +1316,69 @@ int f32_mode_ok(int mode)
 } // namespace
 
 // =============================================================================================
+
+// ---- twins of the host seams (include/lsf.h: lsf_mirror) ---------------------------------------
+// bring the host array into its device slot unless the twin is current and may be trusted
+int twin_in(Ctx& c, Twin& t, Slot slot, const void* host, size_t bytes)
+{
+    int rc = ws(c.slot[slot], bytes);
+    if (rc) return rc;
+    const bool hit = (c.mirror & (LSF_MIRROR_TRUST | LSF_MIRROR_LAZY)) && t.current && t.host == host && t.bytes == bytes;
+    if (!hit) {
+        if (t.host_stale && t.host && t.host != host) // another array's lazy result would be lost
+            HIPCHK(hipMemcpy(const_cast<void*>(t.host), c.slot[slot].p, t.bytes, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c.slot[slot].p, host, bytes, hipMemcpyHostToDevice));
+        t.host_stale = false;
+    }
+    t.host = host, t.bytes = bytes, t.current = true;
+    return LSF_OK;
+}
+// the device slot now holds a result for `host`: copy it back unless the host asked for lazy twins
+int twin_out(Ctx& c, Twin& t, Slot slot, void* host, size_t bytes)
+{
+    t.host = host, t.bytes = bytes, t.current = true;
+    if (c.mirror & LSF_MIRROR_LAZY) {
+        t.host_stale = true;
+        return LSF_OK;
+    }
+    HIPCHK(hipMemcpy(host, c.slot[slot].p, bytes, hipMemcpyDeviceToHost));
+    t.host_stale = false;
+    return LSF_OK;
+}
+// device pointer of the current twin of `host`, or nullptr
+const void* twin_of(Ctx& c, const void* host, size_t bytes, Twin** which = nullptr, Slot* slot = nullptr)
+{
+    struct { Twin* t; Slot s; } all[] = {{&c.twin_phi, S_HPHI}, {&c.twin_nb, S_HNB}, {&c.twin_sb, S_HSB}, {&c.twin_snap, S_SNAP}};
+    for (auto& e : all)
+        if (e.t->current && e.t->host == host && (bytes == 0 || e.t->bytes == bytes) && c.slot[e.s].p) {
+            if (which) *which = e.t;
+            if (slot) *slot = e.s;
+            return c.slot[e.s].p;
+        }
+    return nullptr;
+}
+
+__global__ __launch_bounds__(256) void k_sumsq_diff(const double* __restrict__ a, const double* __restrict__ b, long n,
+                                                    double* __restrict__ partials)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < n; p += (long)gridDim.x * 256) {
+        const double d = a[p] - b[p];
+        acc = __builtin_fma(d, d, acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(RED_T) void k_sum_partials(const double* __restrict__ partials, long nPart, double* __restrict__ out)
+{
+    __shared__ double red[RED_T];
+    const double tot = block_sum(partials, nPart, red);
+    if (threadIdx.x == 0) *out = tot;
+}
+
 extern "C" {
 
 int lsf_version(void) { return LSF_VERSION; }
@@ -1355,6 +1428,14 @@ int lsf_release_workspace(void)
     if (rc) return rc;
     Ctx& c = ctx();
     HIPCHK(hipDeviceSynchronize());
+    {   // lazy twins: the host copies they stand for are brought up to date before the device copies go
+        struct { Twin* t; Slot s; } all[] = {{&c.twin_phi, S_HPHI}, {&c.twin_nb, S_HNB}, {&c.twin_sb, S_HSB}, {&c.twin_snap, S_SNAP}};
+        for (auto& e : all) {
+            if (e.t->host_stale && e.t->host && c.slot[e.s].p)
+                HIPCHK(hipMemcpy(const_cast<void*>(e.t->host), c.slot[e.s].p, e.t->bytes, hipMemcpyDeviceToHost));
+            *e.t = Twin{};
+        }
+    }
     for (auto& b : c.slot) {
         if (b.p) HIPCHK(hipFree(b.p));
         b = Buf{};
@@ -1395,15 +1476,16 @@ int lsf_reinit(double* phi, int nx, int ny, int nz, int iter, double dx, double 
     if (!phi) return fail(LSF_ERR_INVALID, "phi is NULL");
     Ctx& c = ctx();
     const size_t bytes = (size_t)(nx + 1) * (ny + 1) * (nz + 1) * sizeof(double);
-    if ((rc = ws(c.slot[S_HPHI], bytes))) return rc;
+    if ((rc = twin_in(c, c.twin_phi, S_HPHI, phi, bytes))) return rc;
     double* d = (double*)c.slot[S_HPHI].p;
-    HIPCHK(hipMemcpy(d, phi, bytes, hipMemcpyHostToDevice));
     rc = reinit_core(d, nullptr, nx, ny, nz, iter, dx, h, tol, mode, 0, sweeps_done, rms_trace, trace_cap, nullptr);
     if (rc == LSF_OK || rc == LSF_ERR_NAN) {
         const std::string keep = g_err;
-        HIPCHK(hipMemcpy(phi, d, bytes, hipMemcpyDeviceToHost));
+        const int rc2 = twin_out(c, c.twin_phi, S_HPHI, phi, bytes);
+        if (rc2) return rc2;
         g_err = keep;
-    }
+    } else
+        c.twin_phi.current = false;
     return rc;
 }
 
@@ -1428,23 +1510,22 @@ int lsf_minmax(double* phi, int32_t* phiNB, int32_t* phiSB, int nx, int ny, int 
     if (!phi || !phiNB || !phiSB) return fail(LSF_ERR_INVALID, "NULL field");
     Ctx& c = ctx();
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
-    if ((rc = ws(c.slot[S_HPHI], n * sizeof(double)))) return rc;
-    if ((rc = ws(c.slot[S_HNB], n * sizeof(int32_t)))) return rc;
-    if ((rc = ws(c.slot[S_HSB], n * sizeof(int32_t)))) return rc;
+    if ((rc = twin_in(c, c.twin_phi, S_HPHI, phi, n * sizeof(double)))) return rc;
+    if ((rc = twin_in(c, c.twin_nb, S_HNB, phiNB, n * sizeof(int32_t)))) return rc;
+    if ((rc = twin_in(c, c.twin_sb, S_HSB, phiSB, n * sizeof(int32_t)))) return rc;
     double* d = (double*)c.slot[S_HPHI].p;
     int32_t* dnb = (int32_t*)c.slot[S_HNB].p;
     int32_t* dsb = (int32_t*)c.slot[S_HSB].p;
-    HIPCHK(hipMemcpy(d, phi, n * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dnb, phiNB, n * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dsb, phiSB, n * sizeof(int32_t), hipMemcpyHostToDevice));
     rc = minmax_core(d, dnb, dsb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap, nullptr);
     if (rc == LSF_OK || rc == LSF_ERR_NAN) {
         const std::string keep = g_err;
-        HIPCHK(hipMemcpy(phi, d, n * sizeof(double), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(phiNB, dnb, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(phiSB, dsb, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        int rc2 = twin_out(c, c.twin_phi, S_HPHI, phi, n * sizeof(double));
+        if (!rc2) rc2 = twin_out(c, c.twin_nb, S_HNB, phiNB, n * sizeof(int32_t));
+        if (!rc2) rc2 = twin_out(c, c.twin_sb, S_HSB, phiSB, n * sizeof(int32_t));
+        if (rc2) return rc2;
         g_err = keep;
-    }
+    } else
+        c.twin_phi.current = c.twin_nb.current = c.twin_sb.current = false;
     return rc;
 }
 
@@ -1471,16 +1552,17 @@ int lsf_narrowband(const double* phi, int32_t* phiNB, int32_t* phiSB, int nx, in
     if (!phi || !phiNB || !phiSB) return fail(LSF_ERR_INVALID, "NULL field");
     Ctx& c = ctx();
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
-    if ((rc = ws(c.slot[S_HPHI], n * sizeof(double)))) return rc;
+    if ((rc = twin_in(c, c.twin_phi, S_HPHI, phi, n * sizeof(double)))) return rc;
     if ((rc = ws(c.slot[S_HNB], n * sizeof(int32_t)))) return rc;
     if ((rc = ws(c.slot[S_HSB], n * sizeof(int32_t)))) return rc;
-    HIPCHK(hipMemcpy(c.slot[S_HPHI].p, phi, n * sizeof(double), hipMemcpyHostToDevice));
+    c.twin_nb.current = c.twin_sb.current = false; // overwritten below (a lazy older result of another array is dropped:
+                                                   // the masks are outputs here)
     if ((rc = narrowband_core((const double*)c.slot[S_HPHI].p, (int32_t*)c.slot[S_HNB].p, (int32_t*)c.slot[S_HSB].p, n,
                               dx, nullptr)))
         return rc;
-    HIPCHK(hipMemcpy(phiNB, c.slot[S_HNB].p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(phiSB, c.slot[S_HSB].p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    return LSF_OK;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    if ((rc = twin_out(c, c.twin_nb, S_HNB, phiNB, n * sizeof(int32_t)))) return rc;
+    return twin_out(c, c.twin_sb, S_HSB, phiSB, n * sizeof(int32_t));
 }
 
 int lsf_phi0_device(double* d_phi, int nx, int ny, int nz, double dx, const double xLo[3], const double minX[3],
@@ -1547,11 +1629,11 @@ int lsf_phi0(double* phi, int nx, int ny, int nz, double dx, const double xLo[3]
     Ctx& c = ctx();
     const size_t bytes = (size_t)(nx + 1) * (ny + 1) * (nz + 1) * sizeof(double);
     if ((rc = ws(c.slot[S_HPHI], bytes))) return rc;
+    c.twin_phi.current = false; // phi is an output here
     rc = lsf_phi0_device((double*)c.slot[S_HPHI].p, nx, ny, nz, dx, xLo, minX, maxX, surfX, nSurfNode, surfElem,
                          nSurfElem, nullptr);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(phi, c.slot[S_HPHI].p, bytes, hipMemcpyDeviceToHost));
-    return LSF_OK;
+    return twin_out(c, c.twin_phi, S_HPHI, phi, bytes);
 }
 
 int lsf_advect_nodes_device(const double* d_phi, const int32_t* d_phiSB, int nx, int ny, int nz, double dx,
@@ -1599,12 +1681,159 @@ int lsf_advect_nodes(const double* phi, const int32_t* phiSB, int nx, int ny, in
     if (!phi || !phiSB) return fail(LSF_ERR_INVALID, "NULL field");
     Ctx& c = ctx();
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
-    if ((rc = ws(c.slot[S_HPHI], n * sizeof(double)))) return rc;
-    if ((rc = ws(c.slot[S_HSB], n * sizeof(int32_t)))) return rc;
-    HIPCHK(hipMemcpy(c.slot[S_HPHI].p, phi, n * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c.slot[S_HSB].p, phiSB, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    if ((rc = twin_in(c, c.twin_phi, S_HPHI, phi, n * sizeof(double)))) return rc;
+    if ((rc = twin_in(c, c.twin_sb, S_HSB, phiSB, n * sizeof(int32_t)))) return rc;
     return lsf_advect_nodes_device((const double*)c.slot[S_HPHI].p, (const int32_t*)c.slot[S_HSB].p, nx, ny, nz, dx, xLo,
                                    surfXX, nSurfNode, iters, nullptr);
+}
+
+// ---- device-resident chain (include/lsf.h) -------------------------------------------------------
+int lsf_mirror(int flags)
+{
+    if (flags & ~(LSF_MIRROR_TRUST | LSF_MIRROR_LAZY)) return fail(LSF_ERR_INVALID, "unknown mirror flag");
+    int rc = ensure_device();
+    if (rc) return rc;
+    Ctx& c = ctx();
+    if ((c.mirror & LSF_MIRROR_LAZY) && !(flags & LSF_MIRROR_LAZY)) {
+        // leaving the lazy mode: bring every stale host array up to date
+        struct { Twin* t; Slot s; } all[] = {{&c.twin_phi, S_HPHI}, {&c.twin_nb, S_HNB}, {&c.twin_sb, S_HSB}, {&c.twin_snap, S_SNAP}};
+        for (auto& e : all)
+            if (e.t->host_stale && e.t->host) {
+                HIPCHK(hipMemcpy(const_cast<void*>(e.t->host), c.slot[e.s].p, e.t->bytes, hipMemcpyDeviceToHost));
+                e.t->host_stale = false;
+            }
+    }
+    c.mirror = flags;
+    return LSF_OK;
+}
+
+int lsf_mirror_sync(void* host)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!host) return fail(LSF_ERR_INVALID, "NULL pointer");
+    Ctx& c = ctx();
+    Twin* t = nullptr;
+    Slot s = S_HPHI;
+    if (!twin_of(c, host, 0, &t, &s)) return LSF_OK; // no twin: the host copy is the only one
+    if (t->host_stale) {
+        HIPCHK(hipMemcpy(host, c.slot[s].p, t->bytes, hipMemcpyDeviceToHost));
+        t->host_stale = false;
+    }
+    return LSF_OK;
+}
+
+int lsf_snapshot(const double* phi, double* phiO, int nx, int ny, int nz)
+{
+    Trace trace_("lsf_snapshot");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = check_dims(nx, ny, nz))) return rc;
+    if (!phi || !phiO) return fail(LSF_ERR_INVALID, "NULL field");
+    Ctx& c = ctx();
+    const size_t bytes = (size_t)(nx + 1) * (ny + 1) * (nz + 1) * sizeof(double);
+    const void* d = (c.mirror & (LSF_MIRROR_TRUST | LSF_MIRROR_LAZY)) ? twin_of(c, phi, bytes) : nullptr;
+    if (!d) { // no usable twin: the plain host copy of set3d.f90:311
+        std::memcpy(phiO, phi, bytes);
+        c.twin_snap.current = false;
+        return LSF_OK;
+    }
+    if ((rc = ws(c.slot[S_SNAP], bytes))) return rc;
+    HIPCHK(hipMemcpy(c.slot[S_SNAP].p, d, bytes, hipMemcpyDeviceToDevice));
+    return twin_out(c, c.twin_snap, S_SNAP, phiO, bytes);
+}
+
+int lsf_sumsq_diff(const double* phi, const double* phiO, int nx, int ny, int nz, double* sum)
+{
+    Trace trace_("lsf_sumsq_diff");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = check_dims(nx, ny, nz))) return rc;
+    if (!phi || !phiO || !sum) return fail(LSF_ERR_INVALID, "NULL pointer");
+    Ctx& c = ctx();
+    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    if ((rc = twin_in(c, c.twin_phi, S_HPHI, phi, n * sizeof(double)))) return rc;
+    if ((rc = twin_in(c, c.twin_snap, S_SNAP, phiO, n * sizeof(double)))) return rc;
+    const int grid = 2048;
+    if ((rc = ws(c.slot[S_PART2], (grid + 1) * sizeof(double)))) return rc;
+    double* part = (double*)c.slot[S_PART2].p;
+    hipLaunchKernelGGL(k_sumsq_diff, dim3(grid), dim3(256), 0, nullptr, (const double*)c.slot[S_HPHI].p,
+                       (const double*)c.slot[S_SNAP].p, (long)n, part);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(RED_T), 0, nullptr, (const double*)part, (long)grid, part + grid);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(sum, part + grid, sizeof(double), hipMemcpyDeviceToHost));
+    return LSF_OK;
+}
+
+int lsf_write_vti(const char* path, const double* phi, int nx, int ny, int nz, double dx, const double xLo[3])
+{
+    Trace trace_("lsf_write_vti");
+    if (!path || !phi || !xLo) return fail(LSF_ERR_INVALID, "NULL pointer");
+    int rc = check_dims(nx, ny, nz);
+    if (rc) return rc;
+    const size_t npts = (size_t)(nx + 1) * (ny + 1) * (nz + 1), bytes = npts * sizeof(double);
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(LSF_ERR_INVALID, std::string("cannot open ") + path);
+    // header: the reference's text (set3d.f90:324-345): extent '(3(A3,I6))', origin and spacing '(3(F20.8,A1))' TRIMmed
+    char extent[96], origin[96], spacing[96];
+    snprintf(extent, sizeof extent, " 0 %6d 0 %6d 0 %6d", nx, ny, nz);
+    snprintf(origin, sizeof origin, "%20.8f %20.8f %20.8f", xLo[0], xLo[1], xLo[2]);
+    snprintf(spacing, sizeof spacing, "%20.8f %20.8f %20.8f", dx, dx, dx);
+    const bool wide = bytes > 0xffffffffull;
+    fprintf(f, "<?xml version=\"1.0\"?>\n");
+    fprintf(f, "<VTKFile type=\"ImageData\" version=\"0.1\" byte_order=\"LittleEndian\"%s>\n", wide ? " header_type=\"UInt64\"" : "");
+    fprintf(f, "<ImageData WholeExtent=\"%s\" Origin=\"%s\" Spacing=\"%s\">\n", extent, origin, spacing);
+    fprintf(f, "<Piece Extent=\"%s\">\n<PointData Scalars=\"phi\">\n", extent);
+    fprintf(f, "<DataArray type=\"Float64\" Name=\"phi\" format=\"appended\" offset=\"%16d\"/>\n", 0);
+    fprintf(f, "</PointData>\n</Piece>\n</ImageData>\n<AppendedData encoding=\"raw\">\n_");
+    if (wide) {
+        const uint64_t cnt = bytes;
+        fwrite(&cnt, sizeof cnt, 1, f);
+    } else {
+        const uint32_t cnt = (uint32_t)bytes;
+        fwrite(&cnt, sizeof cnt, 1, f);
+    }
+    bool ok = true;
+    const void* d = nullptr;
+    if (hipGetDeviceCount(&rc) == hipSuccess && rc > 0 && ensure_device() == LSF_OK) d = twin_of(ctx(), phi, bytes);
+    (void)hipGetLastError();
+    if (d) {
+        // stream from the device twin: chunk n + 1 is copied into one pinned buffer while chunk n is written from the other
+        const size_t CH = 64u << 20;
+        void* pin[2] = {nullptr, nullptr};
+        hipStream_t st = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        if (hipHostMalloc(&pin[0], CH, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&pin[1], CH, hipHostMallocDefault) != hipSuccess ||
+            hipStreamCreate(&st) != hipSuccess || hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) {
+            ok = false;
+        } else {
+            const size_t nch = (bytes + CH - 1) / CH;
+            auto issue = [&](size_t q) {
+                const size_t off = q * CH, len = std::min(CH, bytes - off);
+                return hipMemcpyAsync(pin[q & 1], (const char*)d + off, len, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                       hipEventRecord(ev[q & 1], st) == hipSuccess;
+            };
+            ok = issue(0);
+            for (size_t q = 0; q < nch && ok; ++q) {
+                if (q + 1 < nch) ok = issue(q + 1);
+                ok = ok && hipEventSynchronize(ev[q & 1]) == hipSuccess;
+                const size_t len = std::min(CH, bytes - q * CH);
+                ok = ok && fwrite(pin[q & 1], 1, len, f) == len;
+            }
+        }
+        if (st) (void)hipStreamSynchronize(st);
+        for (int q = 0; q < 2; ++q) {
+            if (ev[q]) (void)hipEventDestroy(ev[q]);
+            if (pin[q]) (void)hipHostFree(pin[q]);
+        }
+        if (st) (void)hipStreamDestroy(st);
+    } else {
+        ok = fwrite(phi, 1, bytes, f) == bytes;
+    }
+    fprintf(f, "\n</AppendedData>\n</VTKFile>\n");
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return fail(LSF_ERR_HIP, std::string("writing ") + path + " failed");
+    return LSF_OK;
 }
 
 int lsf_jacobi_sweep_box(const double* d_in, double* d_out, const double* d_phiS, const lsf_box* box,

@@ -37,11 +37,15 @@
 !     reinit2_iter = 2000       ! cap of reinit #2                     (set3d.f90:576)
 !     order = 'gs'              ! 'gs' (the reference's raster order, exact) | 'jacobi'
 !     arith = 'fast'            ! 'fast' | 'strict' (bit-identical to the reference)
+!     resident = 2              ! 0: every seam copies its arrays in and out (default of the C ABI)
+!                               ! 1: skip the host-to-device copy of an array the last seam left on the device
+!                               ! 2: (default here) ... and leave results on the device until the host needs them:
+!                               !    phi, phiNB, phiSB cross PCIe once (lsf_mirror, include/lsf.h)
 !   /
 !
 ! Every entry is optional; environment variables of the same meaning (LSF_DX, LSF_DD,
 ! LSF_DD_{X,Y,Z}_{LO,HI}, LSF_REINIT_ITER, LSF_MINMAX_ITER, LSF_REINIT2_ITER, LSF_ORDER,
-! LSF_ARITH) override the namelist.
+! LSF_ARITH, LSF_RESIDENT) override the namelist.
 !*************************************************************************************!
 MODULE lsf_hip
 
@@ -49,6 +53,7 @@ USE, INTRINSIC :: iso_c_binding
 IMPLICIT NONE
 PRIVATE
 PUBLIC :: reinit, narrowBand, minmaxFlow, phi0Init, advectNodes, lsf_env_real, lsf_env_int, lsf_pad_cells
+PUBLIC :: writeVti, snapshotPhi, sumSqDiff, syncHost, syncHostInt
 
 INTEGER(c_int), PARAMETER :: LSF_OK = 0, LSF_ERR_NAN = 1
 INTEGER(c_int), PARAMETER :: LSF_ORDER_JACOBI = 1, LSF_ARITH_STRICT = 256
@@ -59,6 +64,8 @@ REAL, SAVE :: nml_dx = -1.
 INTEGER, SAVE :: nml_dd = -1, nml_dd_lo(3) = -1, nml_dd_hi(3) = -1
 INTEGER, SAVE :: nml_reinit_iter = -1, nml_minmax_iter = -1, nml_reinit2_iter = -1
 CHARACTER(LEN=16), SAVE :: nml_order = ' ', nml_arith = ' '
+INTEGER, SAVE :: nml_resident = -1
+LOGICAL, SAVE :: mirror_set = .FALSE.
 
 INTERFACE
    ! int lsf_reinit(double*,int,int,int,int,double,double,double,int,int*,double*,int)
@@ -111,6 +118,38 @@ INTERFACE
       REAL(c_double), INTENT(INOUT) :: surfXX(*)
       INTEGER(c_int) :: rc
    END FUNCTION lsf_advect_nodes
+   FUNCTION lsf_mirror(flags) BIND(C,NAME='lsf_mirror') RESULT(rc)
+      IMPORT :: c_int
+      INTEGER(c_int), VALUE :: flags
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_mirror
+   FUNCTION lsf_mirror_sync(host) BIND(C,NAME='lsf_mirror_sync') RESULT(rc)
+      IMPORT :: c_int, c_ptr
+      TYPE(c_ptr), VALUE :: host
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_mirror_sync
+   FUNCTION lsf_snapshot(phi,phiO,nx,ny,nz) BIND(C,NAME='lsf_snapshot') RESULT(rc)
+      IMPORT :: c_int, c_double
+      REAL(c_double), INTENT(IN) :: phi(*)
+      REAL(c_double), INTENT(INOUT) :: phiO(*)
+      INTEGER(c_int), VALUE :: nx,ny,nz
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_snapshot
+   FUNCTION lsf_sumsq_diff(phi,phiO,nx,ny,nz,s) BIND(C,NAME='lsf_sumsq_diff') RESULT(rc)
+      IMPORT :: c_int, c_double
+      REAL(c_double), INTENT(IN) :: phi(*),phiO(*)
+      INTEGER(c_int), VALUE :: nx,ny,nz
+      REAL(c_double), INTENT(OUT) :: s
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_sumsq_diff
+   FUNCTION lsf_write_vti(path,phi,nx,ny,nz,dx,xLo) BIND(C,NAME='lsf_write_vti') RESULT(rc)
+      IMPORT :: c_int, c_double, c_char
+      CHARACTER(KIND=c_char), INTENT(IN) :: path(*)
+      REAL(c_double), INTENT(IN) :: phi(*),xLo(3)
+      INTEGER(c_int), VALUE :: nx,ny,nz
+      REAL(c_double), VALUE :: dx
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_write_vti
    FUNCTION lsf_last_error() BIND(C,NAME='lsf_last_error') RESULT(p)
       IMPORT :: c_ptr
       TYPE(c_ptr) :: p
@@ -132,6 +171,7 @@ INTEGER(c_int) :: mode
 CHARACTER(LEN=32) :: v
 INTEGER :: st
 CALL lsf_load_inputs()
+CALL lsf_set_mirror()
 mode = 0
 v = nml_order
 CALL get_environment_variable('LSF_ORDER',v,STATUS=st)
@@ -147,11 +187,11 @@ END FUNCTION lsf_mode
 !*************************************************************************************!
 SUBROUTINE lsf_load_inputs()
 REAL :: dx
-INTEGER :: dd,dd_lo(3),dd_hi(3),reinit_iter,minmax_iter,reinit2_iter,ios,u
+INTEGER :: dd,dd_lo(3),dd_hi(3),reinit_iter,minmax_iter,reinit2_iter,ios,u,resident
 CHARACTER(LEN=16) :: order,arith
 CHARACTER(LEN=1024) :: path
 LOGICAL :: there
-NAMELIST /lsf_inputs/ dx,dd,dd_lo,dd_hi,reinit_iter,minmax_iter,reinit2_iter,order,arith
+NAMELIST /lsf_inputs/ dx,dd,dd_lo,dd_hi,reinit_iter,minmax_iter,reinit2_iter,order,arith,resident
 IF (nml_loaded) RETURN
 nml_loaded = .TRUE.
 path = ' '
@@ -167,7 +207,7 @@ IF (.NOT. there) THEN
 END IF
 dx = nml_dx; dd = nml_dd; dd_lo = nml_dd_lo; dd_hi = nml_dd_hi
 reinit_iter = nml_reinit_iter; minmax_iter = nml_minmax_iter; reinit2_iter = nml_reinit2_iter
-order = nml_order; arith = nml_arith
+order = nml_order; arith = nml_arith; resident = nml_resident
 u = 47
 OPEN(UNIT=u,FILE=TRIM(path),STATUS='old',ACTION='read',IOSTAT=ios)
 IF (ios == 0) READ(u,NML=lsf_inputs,IOSTAT=ios)
@@ -178,7 +218,7 @@ END IF
 CLOSE(u)
 nml_dx = dx; nml_dd = dd; nml_dd_lo = dd_lo; nml_dd_hi = dd_hi
 nml_reinit_iter = reinit_iter; nml_minmax_iter = minmax_iter; nml_reinit2_iter = reinit2_iter
-nml_order = order; nml_arith = arith
+nml_order = order; nml_arith = arith; nml_resident = resident
 PRINT*, " Run parameters read from ",TRIM(path)
 END SUBROUTINE lsf_load_inputs
 
@@ -248,6 +288,7 @@ REAL,DIMENSION(0:nx,0:ny,0:nz),INTENT(IN) :: phi
 INTEGER,DIMENSION(0:nx,0:ny,0:nz),INTENT(INOUT) :: phiNB,phiSB
 INTEGER(c_int) :: rc
 
+CALL lsf_set_mirror()
 rc = lsf_narrowband(phi,phiNB,phiSB,nx,ny,nz,dx)
 IF (rc /= LSF_OK) CALL lsf_fail('lsf_narrowband',rc)
 
@@ -298,6 +339,7 @@ REAL,INTENT(IN) :: surfX(nSurfNode,3)
 INTEGER*4,INTENT(IN) :: surfElem(nSurfElem,3)
 INTEGER(c_int) :: rc
 
+CALL lsf_set_mirror()
 rc = lsf_phi0(phi,nx,ny,nz,dx,xLo,xMin,xMax,surfX,nSurfNode,surfElem,nSurfElem)
 IF (rc /= LSF_OK) CALL lsf_fail('lsf_phi0',rc)
 
@@ -317,6 +359,7 @@ INTEGER,DIMENSION(0:nx,0:ny,0:nz),INTENT(IN) :: phiSB
 REAL,INTENT(INOUT) :: surfXX(nSurfNode,3)
 INTEGER(c_int) :: rc
 
+CALL lsf_set_mirror()
 rc = lsf_advect_nodes(phi,phiSB,nx,ny,nz,dx,xLo,surfXX,nSurfNode,iter)
 IF (rc /= LSF_OK) CALL lsf_fail('lsf_advect_nodes',rc)
 
@@ -389,5 +432,87 @@ DO a = 1,3
    CALL lsf_env_int('LSF_DD_'//ax(a)//'_HI',ddHi(a))
 END DO
 END SUBROUTINE lsf_pad_cells
+
+!*************************************************************************************!
+! Device-resident chain (include/lsf.h: lsf_mirror).  The host program hands the same
+! arrays from seam to seam and never changes them in between; with resident = 2 the
+! library keeps them on the device and the four places where the host itself reads phi
+! between the seams go through the library as well (host edits E8, E9):
+!   snapshotPhi   phiO = phi                        set3d.f90:311
+!   sumSqDiff     the asymptotic-error loop         set3d.f90:510-516
+!   writeVti      the two VTK writers               set3d.f90:336-351, :554-569
+!   syncHost      brings a host array up to date (after the last seam)
+!*************************************************************************************!
+SUBROUTINE lsf_set_mirror()
+INTEGER :: resident,st,ios,t
+INTEGER(c_int) :: rc
+CHARACTER(LEN=64) :: v
+IF (mirror_set) RETURN
+mirror_set = .TRUE.
+CALL lsf_load_inputs()
+resident = 2
+IF (nml_resident >= 0) resident = nml_resident
+CALL get_environment_variable('LSF_RESIDENT',v,STATUS=st)
+IF (st == 0) THEN
+   READ(v,*,IOSTAT=ios) t
+   IF (ios == 0) resident = t
+END IF
+rc = 0
+IF (resident == 1) rc = lsf_mirror(1_c_int)
+IF (resident >= 2) rc = lsf_mirror(3_c_int)
+IF (rc /= LSF_OK) CALL lsf_fail('lsf_mirror',rc)
+END SUBROUTINE lsf_set_mirror
+
+SUBROUTINE snapshotPhi(phi,phiO,nx,ny,nz)
+INTEGER, INTENT(IN) :: nx,ny,nz
+REAL, INTENT(IN) :: phi(0:nx,0:ny,0:nz)
+REAL, INTENT(INOUT) :: phiO(0:nx,0:ny,0:nz)
+INTEGER(c_int) :: rc
+CALL lsf_set_mirror()
+rc = lsf_snapshot(phi,phiO,nx,ny,nz)
+IF (rc /= LSF_OK) CALL lsf_fail('lsf_snapshot',rc)
+END SUBROUTINE snapshotPhi
+
+SUBROUTINE sumSqDiff(phi,phiO,nx,ny,nz,s)
+INTEGER, INTENT(IN) :: nx,ny,nz
+REAL, INTENT(IN) :: phi(0:nx,0:ny,0:nz),phiO(0:nx,0:ny,0:nz)
+REAL, INTENT(INOUT) :: s
+REAL(c_double) :: t
+INTEGER(c_int) :: rc
+CALL lsf_set_mirror()
+rc = lsf_sumsq_diff(phi,phiO,nx,ny,nz,t)
+IF (rc /= LSF_OK) CALL lsf_fail('lsf_sumsq_diff',rc)
+s = s + t
+END SUBROUTINE sumSqDiff
+
+SUBROUTINE writeVti(name,phi,nx,ny,nz,dx,xLo)
+CHARACTER(LEN=*), INTENT(IN) :: name
+INTEGER, INTENT(IN) :: nx,ny,nz
+REAL, INTENT(IN) :: phi(0:nx,0:ny,0:nz),dx,xLo(3)
+INTEGER(c_int) :: rc
+CHARACTER(KIND=c_char) :: cname(LEN_TRIM(name)+1)
+INTEGER :: i
+CALL lsf_set_mirror()
+DO i = 1,LEN_TRIM(name)
+   cname(i) = name(i:i)
+END DO
+cname(LEN_TRIM(name)+1) = c_null_char
+rc = lsf_write_vti(cname,phi,nx,ny,nz,dx,xLo)
+IF (rc /= LSF_OK) CALL lsf_fail('lsf_write_vti',rc)
+END SUBROUTINE writeVti
+
+SUBROUTINE syncHost(a)
+REAL, INTENT(INOUT), TARGET :: a(*)
+INTEGER(c_int) :: rc
+rc = lsf_mirror_sync(c_loc(a))
+IF (rc /= LSF_OK) CALL lsf_fail('lsf_mirror_sync',rc)
+END SUBROUTINE syncHost
+
+SUBROUTINE syncHostInt(a)
+INTEGER, INTENT(INOUT), TARGET :: a(*)
+INTEGER(c_int) :: rc
+rc = lsf_mirror_sync(c_loc(a))
+IF (rc /= LSF_OK) CALL lsf_fail('lsf_mirror_sync',rc)
+END SUBROUTINE syncHostInt
 
 END MODULE lsf_hip

@@ -59,9 +59,24 @@ def stl_write(path, surfX, surfElem):
 
 
 def vti_read_phi(path, shape):
-    """Payload of the reference's .vti writer (set3d.f90:336-351): '_' + int32 + raw Float64, i fastest."""
-    raw = open(path, "rb").read()
-    k = raw.index(b'<AppendedData encoding="raw">') + len(b'<AppendedData encoding="raw">') + 1  # + lf
-    assert raw[k:k + 1] == b"_"
+    """Payload of a .vti file as the reference's writer lays it out (set3d.f90:336-351): '_' + byte count + raw
+    Float64, i fastest.  The count is an int32 in the reference (a wrong one: 3 x too large, overflowing at >= 448^3)
+    and the true UInt32 / UInt64 (header_type="UInt64") count in lsf_write_vti's files; it is returned for inspection
+    by vti_header_count, never trusted here."""
+    raw = np.memmap(path, dtype=np.uint8, mode="r")
+    head = bytes(raw[:4096])
+    tag = b'<AppendedData encoding="raw">'
+    k = head.index(tag) + len(tag) + 1  # + lf
+    assert head[k:k + 1] == b"_"
+    wide = b'header_type="UInt64"' in head
     n = int(np.prod(shape))
-    return np.frombuffer(raw, dtype="<f8", count=n, offset=k + 1 + 4).reshape(shape, order="F")
+    return np.frombuffer(raw, dtype="<f8", count=n, offset=k + 1 + (8 if wide else 4)).reshape(shape, order="F")
+
+
+def vti_header_count(path):
+    """(byte count stored in front of the payload, True if it is a UInt64)"""
+    head = open(path, "rb").read(4096)
+    tag = b'<AppendedData encoding="raw">'
+    k = head.index(tag) + len(tag) + 2
+    wide = b'header_type="UInt64"' in head
+    return int(np.frombuffer(head, dtype="<u8" if wide else "<u4", count=1, offset=k)[0]), wide

@@ -15,12 +15,15 @@ EXE = os.path.join(ROOT, "build", "dropin", "set3d_hip.exec")
 
 
 @pytest.mark.skipif(not os.path.exists(EXE), reason="drop-in executable not built")
-def test_cube40_as_shipped_through_the_fortran_host(tmp_path, cube40):
+@pytest.mark.parametrize("resident", ["2", "1", "0"])
+def test_cube40_as_shipped_through_the_fortran_host(tmp_path, cube40, resident):
+    """resident = 2 (default): phi, phiNB, phiSB stay on the device from the inside/outside search to the end, the .vti
+    files stream from the device copy (host edits E8, E9); 0: every seam copies in and out, as in round 1."""
     import stl_io
 
     s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
     stl_io.stl_write(tmp_path / "cube40.stl", s["cube40_surfX"], s["cube40_surfElem"])
-    env = dict(os.environ, LSF_ARITH="strict", LSF_REINIT2_ITER="0")
+    env = dict(os.environ, LSF_ARITH="strict", LSF_REINIT2_ITER="0", LSF_RESIDENT=resident)
     p = subprocess.run(f"ulimit -s unlimited; cd {tmp_path}; {EXE} cube40.stl", shell=True, env=env, text=True,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = p.stdout
@@ -36,6 +39,7 @@ def test_cube40_as_shipped_through_the_fortran_host(tmp_path, cube40):
     shape = (62, 62, 62)
     assert np.array_equal(stl_io.vti_read_phi(tmp_path / "signedDistanceFunction.vti", shape), cube40["phi_reinit"])
     assert np.array_equal(stl_io.vti_read_phi(tmp_path / "smoothedDistanceFunction.vti", shape), cube40["phi_minmax"])
+    assert stl_io.vti_header_count(tmp_path / "smoothedDistanceFunction.vti") == (8 * 62 ** 3, False)  # true byte count
     # the .s3d mesh (set3d.f90:601-612) carries the surface nodes advected on the GPU (advectNodes)
     lines = open(tmp_path / "cube40.s3d").read().split("\n")
     nelem, nnode = (int(v) for v in lines[0].split()[:2])

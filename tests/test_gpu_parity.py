@@ -508,6 +508,65 @@ def test_stop_verdict_at_many_different_sweeps(lsf):
     assert tested >= 24
 
 
+# ---------------------------------------------------------------------------------- device-resident chain
+def test_host_seams_with_device_twins(lsf, cube40, tmp_path):
+    """lsf_mirror (include/lsf.h): the host-pointer seams keep phi / phiNB / phiSB on the device
+    between calls.  TRUST skips the copy in of an array the previous seam left there; LAZY also leaves the results
+    there until lsf_mirror_sync.  The chain reinit -> snapshot -> narrowBand -> min/max -> sum((phi - phiO)^2) -> .vti
+    gives the reference's fields in every mode, and in LAZY mode the host arrays stay untouched until they are synced."""
+    import ctypes
+
+    import stl_io
+    from levelsetfortran_amd import _lib
+
+    lib = _lib.load()
+    nx, ny, nz = _n(cube40)
+    dx, h = float(cube40["dx"]), float(cube40["h"])
+    shape = (nx + 1, ny + 1, nz + 1)
+    want_re, want_mm = cube40["phi_reinit"], cube40["phi_minmax"]
+    want_sum = float(np.sum((want_mm - want_re) ** 2))
+    xlo = np.array([-1.5, -1.5, -1.5])
+    try:
+        for flags in (0, _lib.LSF_MIRROR_TRUST, _lib.LSF_MIRROR_TRUST | _lib.LSF_MIRROR_LAZY):
+            _lib.check(lib.lsf_mirror(flags))
+            lazy = bool(flags & _lib.LSF_MIRROR_LAZY)
+            phi = F(cube40["phi0"])
+            phiO = np.zeros(shape, order="F")
+            nb = np.zeros(shape, dtype=np.int32, order="F")
+            sb = np.zeros(shape, dtype=np.int32, order="F")
+            rep = lsf.reinit(phi, None, None, nx, ny, nz, int(cube40["iter_reinit"]), dx, h, arith="strict")
+            assert rep.count == 2155
+            if lazy:
+                assert np.array_equal(phi, cube40["phi0"])  # the result is on the device only
+            else:
+                assert np.array_equal(phi, want_re)
+            _lib.check(lib.lsf_snapshot(phi.ctypes.data, phiO.ctypes.data, nx, ny, nz))
+            f1 = str(tmp_path / f"signed_{flags}.vti").encode()
+            _lib.check(lib.lsf_write_vti(f1, phi.ctypes.data, nx, ny, nz, dx, xlo.ctypes.data))
+            assert np.array_equal(stl_io.vti_read_phi(f1.decode(), shape), want_re)
+            assert stl_io.vti_header_count(f1.decode()) == (8 * phi.size, False)
+            lsf.narrowBand(nx, ny, nz, dx, phi, nb, sb)
+            rm = lsf.minmaxFlow(phi, nb, sb, nx, ny, nz, 10000, dx, float(cube40["h1"]))
+            assert rm.count == 406
+            tot = ctypes.c_double(0.0)
+            _lib.check(lib.lsf_sumsq_diff(phi.ctypes.data, phiO.ctypes.data, nx, ny, nz, ctypes.byref(tot)))
+            assert abs(tot.value - want_sum) <= 1e-12 * want_sum
+            if lazy:
+                assert np.array_equal(phi, cube40["phi0"]) and not nb.any() and not phiO.any()
+                for a in (phi, nb, sb, phiO):
+                    _lib.check(lib.lsf_mirror_sync(a.ctypes.data))
+            assert np.array_equal(phi, want_mm) and np.array_equal(phiO, want_re)
+            assert np.array_equal(nb, cube40["NBfinal"].astype(np.int32)) and np.array_equal(sb, cube40["SBfinal"].astype(np.int32))
+            # a host array the caller DID change is copied in again when its twin cannot be trusted ...
+            if not flags:
+                phi[...] = cube40["phi0"]
+                rep = lsf.reinit(phi, None, None, nx, ny, nz, 7, dx, h, arith="strict")
+                assert sha(phi) == str(cube40["re8_sha"])
+    finally:
+        _lib.check(lib.lsf_mirror(0))
+        _lib.check(lib.lsf_release_workspace())
+
+
 # ---------------------------------------------------------------------------------- advection (SURVEY.md 8f rank 3)
 def test_node_advection_matches_reference(lsf, cube40):
     """set3d.f90:464-501 on the GPU: bit-identical advected nodes (host and device seam)."""
