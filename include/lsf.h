@@ -176,8 +176,11 @@ int lsf_write_vti(const char *path, const double *phi, int nx, int ny, int nz, d
  * A rank holds a box of the global field: local extents (lx,ly,lz), whose element (0,0,0) is the
  * global point (gx0,gy0,gz0); global extents are (nx+1,ny+1,nz+1).  The box includes ghost layers
  * (3 points towards each neighbouring rank) and the physical wall points it owns.  All calls are
- * asynchronous on `stream` (no synchronisation, no allocation: graph-capturable).
+ * asynchronous on `stream`.  The sweep and BC calls keep their partial sums in a per-stream buffer that grows on demand
+ * (an allocation, and inside a lsf_sumsq bracket a flush of what has been summed so far); lsf_box_reserve sizes it up
+ * front, after which the calls neither allocate nor synchronise.
  */
+int lsf_box_reserve(void *stream, size_t max_partials);
 typedef struct lsf_box {
     int lx, ly, lz;    /* local allocation extents (points)                          */
     int gx0, gy0, gz0; /* global index of local point (0,0,0)                        */
@@ -210,6 +213,33 @@ int lsf_pack_box(const double *d_field, const lsf_box *box, const int lo[3], con
                  double *d_buf, void *stream);
 int lsf_unpack_box(double *d_field, const lsf_box *box, const int lo[3], const int hi[3],
                    const double *d_buf, void *stream);
+
+/* ---- one process, every GPU of the node (replaces the call site set3d.f90:308 for a host that wants them all) --------
+ * lsf_reinit_multi has lsf_reinit's arguments plus a device list.  The field is split into dims[0] x dims[1] x dims[2]
+ * blocks (dims NULL: 2x1x1, 2x2x1, 2x2x2 for 2, 4, 8 devices -- BASELINE configurations 4 and 5 -- otherwise the prime
+ * factors dealt to x, y, z), one block per entry of `devices`; the library runs the Jacobi sweep (LSF_ORDER_JACOBI only:
+ * the reference's in-place ordering does not shard) with 3-cell face halos copied peer to peer
+ * over xGMI on a communication stream per device while the interior cells are updated on the compute stream, and one
+ * host thread per device that only enqueues; the RMS of sweep s is judged while sweep s + 1 runs.  The result is bit-
+ * identical to lsf_reinit with the same mode on one device.  `devices` may name a device more than once (several blocks
+ * share it): that is how the path is tested on a one-GPU machine.  The lsf_multi_* calls are the same thing in pieces,
+ * for callers that keep the blocks resident (bench.py). */
+typedef struct lsf_multi lsf_multi;
+int lsf_reinit_multi(double *phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,
+                     const int *devices, int ndev, const int dims[3], int *sweeps_done, double *rms_trace, int trace_cap);
+int lsf_reinit_multi_f32(float *phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,
+                         const int *devices, int ndev, const int dims[3], int *sweeps_done, double *rms_trace,
+                         int trace_cap);
+/* f32 != 0: float fields.  Allocates two field buffers, the sign field and the halo buffers of every block. */
+int lsf_multi_create(int nx, int ny, int nz, const int *devices, int ndev, const int dims[3], int f32, lsf_multi **out);
+int lsf_multi_destroy(lsf_multi *m);
+/* geometry of block r: global index of its local point 0, local extents (ghost layers included), owned global range */
+int lsf_multi_block(const lsf_multi *m, int r, int g0[3], int ext[3], int own_lo[3], int own_hi[3], int *device);
+int lsf_multi_scatter(lsf_multi *m, const void *host_phi);              /* host field -> blocks (ghosts included) */
+int lsf_multi_upload_block(lsf_multi *m, int r, const void *d_block);   /* device pointer on block r's device     */
+int lsf_multi_run(lsf_multi *m, int iter, double dx, double h, double tol, int mode, int *sweeps_done, double *rms_trace,
+                  int trace_cap);                                       /* continues from the current block fields */
+int lsf_multi_gather(lsf_multi *m, void *host_phi);                     /* owned points of every block -> host     */
 
 /* ---- single precision (BASELINE.json configuration 5: 1536^3 fp32 on 2x2x2 GPUs) -------------------
  * The reference is fp64 only (Makefile:4, -fdefault-real-8): there is no fp32 field to be identical to,

@@ -3,7 +3,7 @@ WENO5 Hamilton-Jacobi signed-distance reinitialisation and min/max-flow smoothin
 grid, behind the reference's own procedure interface (see levelset.py, include/lsf.h).
 """
 from .levelset import (LsfError, LsfNaNError, SweepReport, advectNodes, minmaxFlow, mode_word, narrowBand, phi0Init,  # noqa: F401
-                       reinit)
+                       reinit, reinit_multi)
 from . import fields  # noqa: F401
 
-__version__ = "0.1.1"
+__version__ = "0.1.2"

@@ -73,6 +73,18 @@ SIGNATURES = {
     "lsf_snapshot": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int]),
     "lsf_sumsq_diff": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_double)]),
     "lsf_write_vti": (c_int, [ctypes.c_char_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p]),
+    "lsf_box_reserve": (c_int, [c_void_p, ctypes.c_size_t]),
+    "lsf_reinit_multi": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_int, c_void_p, c_int,
+                                 c_void_p, POINTER(c_int), c_void_p, c_int]),
+    "lsf_reinit_multi_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_int, c_void_p,
+                                     c_int, c_void_p, POINTER(c_int), c_void_p, c_int]),
+    "lsf_multi_create": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, POINTER(c_void_p)]),
+    "lsf_multi_destroy": (c_int, [c_void_p]),
+    "lsf_multi_block": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
+    "lsf_multi_scatter": (c_int, [c_void_p, c_void_p]),
+    "lsf_multi_upload_block": (c_int, [c_void_p, c_int, c_void_p]),
+    "lsf_multi_run": (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_int, POINTER(c_int), c_void_p, c_int]),
+    "lsf_multi_gather": (c_int, [c_void_p, c_void_p]),
     "lsf_jacobi_sweep_box": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3,
                                      c_double, c_double, c_int, c_void_p, c_void_p]),
     "lsf_bc_box": (c_int, [c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_double, c_void_p,

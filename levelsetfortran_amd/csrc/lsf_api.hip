@@ -1980,4 +1980,199 @@ int lsf_reinit_f32(float* phi, int nx, int ny, int nz, int iter, double dx, doub
     return rc;
 }
 
+// ---- lsf_box_reserve --------------------------------------------------------------------------------
+int lsf_box_reserve(void* stream, size_t max_partials)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    StreamPart& sp = ctx().part_by_stream[(hipStream_t)stream];
+    if (sp.deferred) return fail(LSF_ERR_INVALID, "lsf_box_reserve inside a lsf_sumsq bracket");
+    if (max_partials * sizeof(double) > sp.buf.bytes) {
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        if ((rc = ws(sp.buf, max_partials * sizeof(double)))) return rc;
+    }
+    return LSF_OK;
+}
+
+} // extern "C"
+
+// ---- one process, every GPU: lsf_multi_* / lsf_reinit_multi (lsf_multi.hpp) ------------------------------
+#include "lsf_multi.hpp"
+
+extern "C" {
+
+int lsf_multi_create(int nx, int ny, int nz, const int* devices, int ndev, const int dims_in[3], int f32, lsf_multi** out)
+{
+    Trace trace_("lsf_multi_create");
+    if (!out) return fail(LSF_ERR_INVALID, "NULL pointer");
+    *out = nullptr;
+    int rc = check_dims(nx, ny, nz);
+    if (rc) return rc;
+    if (ndev < 1 || ndev > 64 || !devices) return fail(LSF_ERR_INVALID, "device list must hold 1..64 entries");
+    int ndevs = 0;
+    if (hipGetDeviceCount(&ndevs) != hipSuccess || ndevs <= 0) {
+        (void)hipGetLastError();
+        return fail(LSF_ERR_NO_DEVICE, "no HIP device visible: liblsf_hip has no CPU fallback");
+    }
+    for (int r = 0; r < ndev; ++r)
+        if (devices[r] < 0 || devices[r] >= ndevs) return fail(LSF_ERR_NO_DEVICE, "device index out of range");
+    int dims[3];
+    if (dims_in) {
+        for (int a = 0; a < 3; ++a) dims[a] = dims_in[a];
+        if (dims[0] < 1 || dims[1] < 1 || dims[2] < 1 || dims[0] * dims[1] * dims[2] != ndev)
+            return fail(LSF_ERR_INVALID, "dims must multiply to the number of devices");
+    } else
+        lsfm::default_dims(ndev, dims);
+    lsf_multi* M = new lsf_multi(ndev);
+    M->nx = nx, M->ny = ny, M->nz = nz, M->f32 = f32 ? 1 : 0;
+    for (int a = 0; a < 3; ++a) M->dims[a] = dims[a];
+    M->devs.assign(devices, devices + ndev);
+    const int n[3] = {nx, ny, nz};
+    std::string err;
+    auto build = [&](auto& ranks) -> int {
+        ranks.resize(ndev);
+        for (int r = 0; r < ndev; ++r) {
+            ranks[r].dev = devices[r];
+            if (!lsfm::make_geom(r, dims, n, &ranks[r].g, &err)) return fail(LSF_ERR_INVALID, err);
+            if ((double)ranks[r].g.ext[0] * ranks[r].g.ext[1] * 8.0 > 2.0e9) return fail(LSF_ERR_INVALID, "a k-plane of a block exceeds 2 GB");
+        }
+        // direct peer copies between distinct devices (already-enabled is not an error)
+        for (int a = 0; a < ndev; ++a)
+            for (int b = 0; b < ndev; ++b)
+                if (devices[a] != devices[b]) {
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can && hipSetDevice(devices[a]) == hipSuccess)
+                        (void)hipDeviceEnablePeerAccess(devices[b], 0);
+                    (void)hipGetLastError();
+                }
+        for (int r = 0; r < ndev; ++r) {
+            lsfm::alloc_rank(ranks[r]);
+            if (ranks[r].rc) return fail(ranks[r].rc, ranks[r].err);
+        }
+        return LSF_OK;
+    };
+    rc = f32 ? build(M->r32) : build(M->r64);
+    if (rc) {
+        const std::string keep = g_err;
+        lsf_multi_destroy(M);
+        g_err = keep;
+        return rc;
+    }
+    *out = M;
+    return LSF_OK;
+}
+
+int lsf_multi_destroy(lsf_multi* M)
+{
+    if (!M) return LSF_OK;
+    for (auto& R : M->r64) lsfm::free_rank(R);
+    for (auto& R : M->r32) lsfm::free_rank(R);
+    delete M;
+    return LSF_OK;
+}
+
+int lsf_multi_block(const lsf_multi* M, int r, int g0[3], int ext[3], int own_lo[3], int own_hi[3], int* device)
+{
+    if (!M || r < 0 || r >= M->ndev) return fail(LSF_ERR_INVALID, "bad block index");
+    const lsfm::Geom& g = M->f32 ? M->r32[r].g : M->r64[r].g;
+    for (int a = 0; a < 3; ++a) {
+        if (g0) g0[a] = g.g0[a];
+        if (ext) ext[a] = g.ext[a];
+        if (own_lo) own_lo[a] = g.own[a][0];
+        if (own_hi) own_hi[a] = g.own[a][1];
+    }
+    if (device) *device = M->devs[r];
+    return LSF_OK;
+}
+
+int lsf_multi_scatter(lsf_multi* M, const void* host_phi)
+{
+    if (!M || !host_phi) return fail(LSF_ERR_INVALID, "NULL pointer");
+    std::string err;
+    const int rc = M->f32 ? lsfm::scatter(M->r32, (const float*)host_phi, M->nx, M->ny, &err)
+                          : lsfm::scatter(M->r64, (const double*)host_phi, M->nx, M->ny, &err);
+    M->result_parity = 0;
+    return rc ? fail(rc, err) : LSF_OK;
+}
+
+int lsf_multi_upload_block(lsf_multi* M, int r, const void* d_block)
+{
+    if (!M || !d_block || r < 0 || r >= M->ndev) return fail(LSF_ERR_INVALID, "bad block index / NULL pointer");
+    HIPCHK(hipSetDevice(M->devs[r]));
+    if (M->f32) HIPCHK(hipMemcpy(M->r32[r].buf[0], d_block, M->r32[r].g.npoints() * sizeof(float), hipMemcpyDeviceToDevice));
+    else HIPCHK(hipMemcpy(M->r64[r].buf[0], d_block, M->r64[r].g.npoints() * sizeof(double), hipMemcpyDeviceToDevice));
+    M->result_parity = 0;
+    return LSF_OK;
+}
+
+int lsf_multi_run(lsf_multi* M, int iter, double dx, double h, double tol, int mode, int* sweeps_done, double* rms_trace, int trace_cap)
+{
+    Trace trace_("lsf_multi_run");
+    if (!M) return fail(LSF_ERR_INVALID, "NULL pointer");
+    if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
+    if ((mode & LSF_ORDER_MASK) != LSF_ORDER_JACOBI)
+        return fail(LSF_ERR_INVALID, "lsf_multi: LSF_ORDER_JACOBI only (the reference's in-place ordering does not shard)");
+    if (M->f32) {
+        const int rc = f32_mode_ok(mode);
+        if (rc) return rc;
+    }
+    // the sweeps start from buf[0]: bring the latest field there if the previous run ended on the other buffer
+    if (M->result_parity) {
+        for (int r = 0; r < M->ndev; ++r) {
+            HIPCHK(hipSetDevice(M->devs[r]));
+            if (M->f32) std::swap(M->r32[r].buf[0], M->r32[r].buf[1]);
+            else std::swap(M->r64[r].buf[0], M->r64[r].buf[1]);
+        }
+        M->result_parity = 0;
+    }
+    std::string err;
+    const int rc = M->f32 ? lsfm::run(M, M->r32, iter, dx, h, tol, mode, sweeps_done, rms_trace, trace_cap, &err)
+                          : lsfm::run(M, M->r64, iter, dx, h, tol, mode, sweeps_done, rms_trace, trace_cap, &err);
+    return rc ? fail(rc, err) : LSF_OK;
+}
+
+int lsf_multi_gather(lsf_multi* M, void* host_phi)
+{
+    if (!M || !host_phi) return fail(LSF_ERR_INVALID, "NULL pointer");
+    std::string err;
+    const int rc = M->f32 ? lsfm::gather(M->r32, M->result_parity, (float*)host_phi, M->nx, M->ny, &err)
+                          : lsfm::gather(M->r64, M->result_parity, (double*)host_phi, M->nx, M->ny, &err);
+    return rc ? fail(rc, err) : LSF_OK;
+}
+
+static int reinit_multi_any(void* phi, int f32, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,
+                            const int* devices, int ndev, const int dims[3], int* sweeps_done, double* rms_trace, int trace_cap)
+{
+    if (!phi) return fail(LSF_ERR_INVALID, "phi is NULL");
+    lsf_multi* M = nullptr;
+    int rc = lsf_multi_create(nx, ny, nz, devices, ndev, dims, f32, &M);
+    if (rc) return rc;
+    rc = lsf_multi_scatter(M, phi);
+    if (!rc) rc = lsf_multi_run(M, iter, dx, h, tol, mode, sweeps_done, rms_trace, trace_cap);
+    if (rc == LSF_OK || rc == LSF_ERR_NAN) {
+        const std::string keep = g_err;
+        const int rc2 = lsf_multi_gather(M, phi);
+        if (rc2) rc = rc2;
+        else g_err = keep;
+    }
+    const std::string keep = g_err;
+    lsf_multi_destroy(M);
+    g_err = keep;
+    return rc;
+}
+
+int lsf_reinit_multi(double* phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode, const int* devices,
+                     int ndev, const int dims[3], int* sweeps_done, double* rms_trace, int trace_cap)
+{
+    Trace trace_("lsf_reinit_multi");
+    return reinit_multi_any(phi, 0, nx, ny, nz, iter, dx, h, tol, mode, devices, ndev, dims, sweeps_done, rms_trace, trace_cap);
+}
+
+int lsf_reinit_multi_f32(float* phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode, const int* devices,
+                         int ndev, const int dims[3], int* sweeps_done, double* rms_trace, int trace_cap)
+{
+    Trace trace_("lsf_reinit_multi_f32");
+    return reinit_multi_any(phi, 1, nx, ny, nz, iter, dx, h, tol, mode, devices, ndev, dims, sweeps_done, rms_trace, trace_cap);
+}
+
 } // extern "C"

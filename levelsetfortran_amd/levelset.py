@@ -261,3 +261,27 @@ def advectNodes(phi, phiSB, nx: int, ny: int, nz: int, dx: float, xLo, surfXX, i
                                   _host_ptr(phiSB, np.int32, nx, ny, nz, "phiSB"), nx, ny, nz, float(dx),
                                   lo.ctypes.data, surfXX.ctypes.data, surfXX.shape[0], int(iter))
     _lib.check(rc)
+
+
+def reinit_multi(phi, nx: int, ny: int, nz: int, iter: int, dx: float, h: float, devices, *, dims=None,
+                 tol: float = REINIT_TOL, arith: str = "fast") -> SweepReport:
+    """reinit on every device of `devices` from ONE process (include/lsf.h: lsf_reinit_multi; the call site
+    set3d.f90:308 for a host that wants all the GPUs of the node).  phi: Fortran-ordered numpy array, float64 or
+    float32, updated in place.  Jacobi ordering (the ordering that shards); the result is bit-identical to
+    reinit(..., order="jacobi") on one device.  A device may be named more than once (several blocks share it)."""
+    lib = _lib.load()
+    cap = int(iter) + 1
+    trace = np.zeros(max(cap, 1), dtype=np.float64)
+    done = ctypes.c_int(0)
+    mode = mode_word("jacobi", arith)
+    devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+    dm = (ctypes.c_int * 3)(*[int(d) for d in dims]) if dims is not None else None
+    f32 = isinstance(phi, np.ndarray) and phi.dtype == np.float32
+    p = _host_ptr(phi, np.float32 if f32 else np.float64, nx, ny, nz, "phi")
+    fn = lib.lsf_reinit_multi_f32 if f32 else lib.lsf_reinit_multi
+    rc = fn(p, nx, ny, nz, int(iter), float(dx), float(h), float(tol), mode, devs, len(devices), dm, ctypes.byref(done),
+            trace.ctypes.data, cap)
+    n = done.value
+    rep = SweepReport(n, [float(v) for v in trace[:n]], bool(n and trace[n - 1] < tol))
+    _lib.check(rc)
+    return rep

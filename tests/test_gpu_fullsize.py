@@ -143,8 +143,8 @@ def test_full_size_field_equals_the_reference_itself(n):
 @pytest.mark.parametrize("arith", ["strict", "fast"])
 def test_dataflow_launch_equals_slot_launches_over_many_sweeps(arith, monkeypatch):
     """70 sweeps on a 300 x 250 x 200 grid (partial tiles on every axis, three batches' worth of raster phases, up to
-    three sweeps in flight): the dataflow launch (in-kernel dependencies) and the slot launches (dependencies = launch
-    boundaries) must produce the same bits, the same sweep count and the same RMS trace."""
+    four sweeps in flight): the dataflow launch (in-kernel dependencies, tiles marching along y) and the slot launches
+    (dependencies = launch boundaries, tiles marching along x) must produce the same bits and the same sweep count."""
     import torch
 
     import levelsetfortran_amd as lsf
@@ -162,4 +162,6 @@ def test_dataflow_launch_equals_slot_launches_over_many_sweeps(arith, monkeypatc
         res[schedule] = (rep.count, phi.cpu().numpy(), np.array(rep.rms))
     assert res["dataflow"][0] == res["skew"][0] == sweeps
     assert np.array_equal(res["dataflow"][1], res["skew"][1])
-    assert np.array_equal(res["dataflow"][2], res["skew"][2])
+    # the dataflow launch sums the squared changes by tile columns of the x <-> y transposed field, the slot launches by
+    # tile columns of the field as it is: same values, different (fixed) orders of the additions
+    assert np.allclose(res["dataflow"][2], res["skew"][2], rtol=1e-12, atol=0)
