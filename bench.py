@@ -17,10 +17,17 @@ measured in the same run and reported under "jacobi".
 the headline line is the default fp64 run.
 
 N > 1 is launched by torch.distributed.run, one rank per GPU:
-  mode gs      exact ordering does not shard: N independent replicas, weak scaling
-  mode jacobi  3-D block decomposition, 3-cell halos over RCCL, local block = --size^3, weak scaling
+  mode gs      exact ordering does not shard: `value` = N independent replicas ("scaling": "weak"),
+               and, in the same job, the path that DOES shard -- the block-decomposed Jacobi sweep, 3-cell halos over RCCL
+               -- on FIXED global grids (256^3, 512^3, 1024^3 fp64: "strong") and on N blocks of --size^3 ("weak"), plus
+               the one-process C-ABI driver (lsf_multi_*) run by rank 0 on 1, 2, 4, ... N devices: all under "decomposed",
+               each entry stating its own scaling, so that replica scaling is never read as halo-path scaling
+  mode jacobi  the decomposed sweep is the headline: --global G fixes the global grid at G^3 points ("strong": BASELINE
+               configuration 4 = --gpus 4 --global 1024, configuration 5 = --gpus 8 --global 1536 --dtype f32); without
+               --global every rank owns a --size^3 block ("weak")
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Exit status is non-zero when a requested decomposed measurement failed or timed out
+(the headline line is still printed first).
 """
 from __future__ import annotations
 
@@ -133,13 +140,16 @@ def main() -> None:
     ap.add_argument("--mode", choices=("gs", "jacobi"), default="gs")
     ap.add_argument("--arith", choices=("fast", "strict"), default="fast")
     ap.add_argument("--size", type=int, default=512, help="points per axis (per GPU)")
+    ap.add_argument("--global", dest="global_size", type=int, default=0,
+                    help="N > 1, mode jacobi: points per axis of the FIXED global grid (strong scaling); 0 = weak scaling, "
+                         "every rank owns a --size^3 block")
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
                     help="f32 = single-precision Jacobi path (BASELINE configuration 5); implies --mode jacobi")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary-ordering measurement")
     ap.add_argument("--no-decomposed", action="store_true",
                     help="N > 1, mode gs: skip the block-decomposed Jacobi sweep (RCCL halo exchange) that is otherwise "
-                         "timed after the headline measurement and attached as \"jacobi_decomposed\"")
+                         "timed after the headline measurement and attached as \"decomposed\"")
     ap.add_argument("--force-decomposed", action="store_true", help="run that measurement at N = 1 too (test aid)")
     ap.add_argument("--decomposed-timeout", type=float, default=240.0,
                     help="seconds the decomposed measurement may take before the headline line is printed without it")
@@ -195,10 +205,17 @@ def main() -> None:
     K, W = args.steps, args.warmup
     out = {}
 
+    scaling = "weak"
+    res = None
     if args.mode == "jacobi" and world > 1:
         from levelsetfortran_amd import distributed as lsd
 
-        res = lsd.bench_weak_scaling(N, K, W, dev, arith=args.arith, dtype=args.dtype, shared_gpu=shared_gpu)
+        if args.global_size:
+            G = args.global_size
+            res = lsd.bench_decomposed((G, G, G), K, W, dev, arith=args.arith, dtype=args.dtype, shared_gpu=shared_gpu)
+            scaling = "strong"
+        else:
+            res = lsd.bench_weak_scaling(N, K, W, dev, arith=args.arith, dtype=args.dtype, shared_gpu=shared_gpu)
         cells_total, seconds, prof, parallelism = res["cells_total"], res["seconds"], res["prof"], res["parallelism"]
         order = "jacobi"
     else:
@@ -248,9 +265,9 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seconds = float(t.item())
     # N > 1, exact ordering: the headline is N replicas.  The path that really shards -- the block-decomposed Jacobi
-    # sweep with its RCCL halo exchange -- is measured afterwards in the same job and attached as
-    # "jacobi_decomposed".  It runs under a watchdog: whatever happens in there (an exception on one rank, a
-    # stuck collective), rank 0 still prints the headline line and every rank leaves with exit code 0.
+    # sweep with its halo exchange -- is measured afterwards in the same job and attached as "decomposed".  It runs
+    # under a watchdog: whatever happens in there (an exception on one rank, a stuck collective), rank 0 still prints
+    # the headline line first; the job then ends with a non-zero exit status.
     decomposed = None
     state = {"emitted": False}
     watchdog = None
@@ -260,9 +277,9 @@ def main() -> None:
         def _bail():
             if rank == 0 and not state["emitted"] and state.get("line") is not None:
                 line = dict(state["line"])
-                line["jacobi_decomposed"] = {"value": None, "error": f"no result within {args.decomposed_timeout} s"}
+                line["decomposed"] = {"entries": state.get("entries", []), "error": f"not finished within {args.decomposed_timeout} s"}
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(3)
 
         watchdog = threading.Timer(args.decomposed_timeout, _bail)
         watchdog.daemon = True
@@ -303,14 +320,17 @@ def main() -> None:
         "warmup": W,
         "ms_per_step": seconds / K * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
         "config": {
-            "workload": f"WENO5 HJ reinit sweep (weno+Godunov+Euler, BC, RMS), {N}^3 {'fp32' if f32 else 'fp64'} per GPU, synthetic two-sphere "
-                        f"phi0 (SURVEY.md 8d), HBM-resident",
-            "grid": [N, N, N],
+            "workload": (f"WENO5 HJ reinit sweep (weno+Godunov+Euler, BC, RMS), global grid {res['global_grid']} {'fp32' if f32 else 'fp64'} "
+                         f"split {res['dims']}, local block {res['local_block']} points, synthetic two-sphere phi0 (SURVEY.md 8d), "
+                         f"HBM-resident") if res else
+                        (f"WENO5 HJ reinit sweep (weno+Godunov+Euler, BC, RMS), {N}^3 {'fp32' if f32 else 'fp64'} per GPU, synthetic "
+                         f"two-sphere phi0 (SURVEY.md 8d), HBM-resident"),
+            "grid": res["global_grid"] if res else [N, N, N],
             "ordering": "exact Gauss-Seidel raster order of the reference (tiled hyperplane wavefront)" if order == "gs"
                         else "Jacobi (double-buffered; not reference-equal)",
             "arithmetic": args.arith,
@@ -349,6 +369,7 @@ def main() -> None:
         # min/max-flow sweep (set3d.f90:394-462) on the same grid: 16 B per grid point per iteration
         # (SURVEY.md 8d); input = exact two-sphere distance so that the narrow band is a thin shell
         del phi, phi0, phiS
+        state["freed"] = True
         x, y, z, dxm = fields.grid_axes((N, N, N))
         dmin = None
         for c in ((-0.6, 0.0, 0.0), (0.6, 0.0, 0.0)):
@@ -377,26 +398,62 @@ def main() -> None:
                       "gs = the reference's (+,+,+) raster order reproduced exactly, jacobi = double-buffered")
         out["minmax"] = mm
 
+    failed = False
     if state["run_decomposed"]:
         from levelsetfortran_amd import distributed as lsd
 
         state["line"] = out
+        state["entries"] = entries = []
         watchdog.start()
         try:
-            del phi, phi0, phiS
-            r = lsd.bench_weak_scaling(N, K, W, dev, arith=args.arith, shared_gpu=shared_gpu)
-            t = torch.tensor([r["seconds"]], device=dev, dtype=torch.float64)
+            if not state.get("freed"):
+                del phi, phi0, phiS
+                state["freed"] = True
+            torch.cuda.empty_cache()
+            lib.lsf_release_workspace()
+
+            def one(gpts, kind, note):
+                r = lsd.bench_decomposed(gpts, K, W, dev, arith=args.arith, shared_gpu=shared_gpu)
+                t = torch.tensor([r["seconds"]], device=dev, dtype=torch.float64)
+                if world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sec = float(t.item())
+                entries.append({"path": "one process per GPU, torch.distributed (RCCL)", "ordering": "jacobi", "dtype": "f64",
+                                "scaling": kind, "global_grid": r["global_grid"], "dims": r["dims"], "local_block": r["local_block"],
+                                "n_gpus": world, "value": r["cells_total"] / sec, "unit": "cell-updates/s",
+                                "ms_per_step": sec / K * 1e3, "note": note})
+                torch.cuda.empty_cache()
+
+            dims = lsd.default_dims(world)
+            one(tuple(d * N for d in dims), "weak", f"every rank owns a {N}^3-point block")
+            for G in ((96,) if N < 128 else (256, 512, 1024)):  # north_star: fixed 256^3, 512^3, 1024^3 at 1, 2, 4, 8 GPUs
+                if all(G // d >= 12 for d in dims):
+                    one((G, G, G), "strong", "fixed global grid: compare with the same entry of the runs at other N")
+            # the one-process C-ABI driver (include/lsf.h: lsf_multi_*): rank 0 drives 1, 2, 4, ... N devices, the other
+            # ranks wait.  Needs every GPU of the job visible to rank 0 (torch.distributed.run does not hide them).
             if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            decomposed = {"value": r["cells_total"] / float(t.item()), "unit": "cell-updates/s",
-                          "ms_per_step": float(t.item()) / K * 1e3, "parallelism": r["parallelism"],
-                          "global_grid": r["global_grid"], "scaling": "weak",
-                          "note": "Jacobi ordering (not reference-equal), whole-job aggregate over all ranks; same K "
-                                  "sweeps after W warm-up sweeps, barrier + synchronize on both sides, max over ranks"}
+                sp = []
+                if rank == 0 and not shared_gpu and torch.cuda.device_count() >= world:
+                    try:
+                        sp = _single_process_entries(lib, world, 64 if N < 128 else 512, K, W, args.arith)
+                    except Exception as e:  # noqa: BLE001
+                        sp = [{"path": "one process, lsf_multi", "value": None, "error": repr(e)[:300]}]
+                        failed = True
+                entries.extend(sp)
+                if shared_gpu:
+                    dist.barrier()
+                else:
+                    dist.barrier(device_ids=[local_rank])
+            decomposed = {"entries": entries,
+                          "note": "Jacobi ordering (not reference-equal; bit-identical to the single-GPU Jacobi sweep), whole-job "
+                                  "aggregates; same K sweeps after W warm-up sweeps, barrier + synchronize on both sides, max over "
+                                  "ranks.  The driver's scaling efficiency over `value` describes replicas; halo-path scaling is the "
+                                  "ratio of equal-grid \"strong\" entries across runs (or across n_gpus inside the lsf_multi block)."}
         except Exception as e:  # noqa: BLE001
-            decomposed = {"value": None, "error": repr(e)[:300]}
+            decomposed = {"entries": entries, "error": repr(e)[:300]}
+            failed = True
     if decomposed is not None:
-        out["jacobi_decomposed"] = decomposed
+        out["decomposed"] = decomposed
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N)
@@ -406,6 +463,60 @@ def main() -> None:
         dist.destroy_process_group()
     if watchdog is not None:
         watchdog.cancel()
+    if failed:
+        sys.exit(3)
+
+
+def _single_process_entries(lib, world, G, K, W, arith):
+    """rank 0 only: the block-decomposed sweep through lsf_multi_* on 1, 2, 4, ... `world` devices, fixed G^3 grid."""
+    import numpy as np
+    import torch
+
+    from levelsetfortran_amd import _lib, fields
+
+    out = []
+    nd = 1
+    counts = []
+    while nd <= world:
+        counts.append(nd)
+        nd *= 2
+    if counts[-1] != world:
+        counts.append(world)
+    n = G - 1
+    mode = _lib.LSF_ORDER_JACOBI | (_lib.LSF_ARITH_STRICT if arith == "strict" else _lib.LSF_ARITH_FAST)
+    for nd in counts:
+        devs = (ctypes.c_int * nd)(*range(nd))
+        M = ctypes.c_void_p()
+        _lib.check(lib.lsf_multi_create(n, n, n, devs, nd, None, 0, ctypes.byref(M)))
+        try:
+            dx = h = None
+            for r in range(nd):
+                g0, ext = (ctypes.c_int * 3)(), (ctypes.c_int * 3)()
+                dv = ctypes.c_int(0)
+                _lib.check(lib.lsf_multi_block(M, r, g0, ext, None, None, ctypes.byref(dv)))
+                d = torch.device("cuda", dv.value)
+                rng = tuple((int(a), int(a) + int(e)) for a, e in zip(g0, ext))
+                blk, dx = fields.two_sphere_phi0_device((G, G, G), d, ranges=rng)
+                torch.cuda.synchronize(d)
+                _lib.check(lib.lsf_multi_upload_block(M, r, blk.data_ptr()))
+                del blk
+            h = fields.reinit_step(dx)
+            done = ctypes.c_int(0)
+            if W > 0:
+                _lib.check(lib.lsf_multi_run(M, W - 1, dx, h, 0.0, mode, ctypes.byref(done), None, 0))
+            t0 = time.perf_counter()
+            _lib.check(lib.lsf_multi_run(M, K - 1, dx, h, 0.0, mode, ctypes.byref(done), None, 0))
+            sec = time.perf_counter() - t0
+            assert done.value == K, (done.value, K)
+            dims = [1, 1, 1]
+            out.append({"path": "one process, lsf_multi (C ABI): thread + 2 streams per device, peer-copied halos", "ordering": "jacobi",
+                        "dtype": "f64", "scaling": "strong", "global_grid": [G, G, G], "n_gpus": nd,
+                        "value": float(n - 1) ** 3 * K / sec, "unit": "cell-updates/s", "ms_per_step": sec / K * 1e3,
+                        "note": "the call returns after the last sweep has finished on every device (the run includes its own "
+                                "thread start-up and final synchronisation)"})
+        finally:
+            _lib.check(lib.lsf_multi_destroy(M))
+    return out
 
 
 if __name__ == "__main__":

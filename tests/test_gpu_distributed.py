@@ -110,8 +110,31 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
     cells = 2 * 4 * 94.0 ** 3
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 4 - cells) < 1e-6 * cells  # value = cells of ALL ranks / time
-    jd = d["jacobi_decomposed"]
-    assert jd["value"] > 0 and jd["global_grid"] == [192, 96, 96]
+    ent = d["decomposed"]["entries"]
+    weak = [e for e in ent if e["scaling"] == "weak"]
+    strong = [e for e in ent if e["scaling"] == "strong"]
+    assert len(weak) == 1 and weak[0]["value"] > 0 and weak[0]["global_grid"] == [192, 96, 96] and weak[0]["dims"] == [2, 1, 1]
+    # fixed global grid split over the ranks: non-cubic local blocks (48 owned + 3 ghost points along x)
+    assert len(strong) == 1 and strong[0]["global_grid"] == [96, 96, 96] and strong[0]["local_block"] == [51, 96, 96]
+    assert strong[0]["value"] > 0 and "error" not in d["decomposed"]
+
+
+def test_bench_strong_scaling_headline_on_one_gpu():
+    """bench.py --mode jacobi --global G: the decomposed sweep on a FIXED global grid is the headline ("strong"); BASELINE
+    configuration 4 is `--gpus 4 --global 1024`, rehearsed here as 4 ranks sharing the GPU on a 64^3 grid (2x2x1)."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, LSF_BENCH_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--mode", "jacobi", "--global", "64",
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["grid"] == [64, 64, 64]
+    cells = 3 * 62.0 ** 3
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 3 - cells) < 1e-6 * cells
 
 
 def test_sumsq_bracket_equals_per_call_reduction():

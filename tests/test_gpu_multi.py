@@ -119,3 +119,18 @@ def test_multi_resident_pieces_and_refusals(lsf):
     assert lib.lsf_multi_create(n[0], n[1], n[2], bad, 2, None, 0, ctypes.byref(M)) == _lib.LSF_ERR_NO_DEVICE
     three = (ctypes.c_int * 3)(2, 2, 2)
     assert lib.lsf_multi_create(n[0], n[1], n[2], devs, 4, three, 0, ctypes.byref(M)) == _lib.LSF_ERR_INVALID
+
+
+def test_bench_single_process_entries_helper(lsf):
+    """bench.py's rank-0 measurement of the lsf_multi driver (run on 1, 2, 4, ... N devices at N > 1) with one device."""
+    import importlib.util
+    import os
+
+    from conftest import ROOT
+    from levelsetfortran_amd import _lib
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ent = bench._single_process_entries(_lib.load(), 1, 64, 3, 1, "fast")
+    assert len(ent) == 1 and ent[0]["n_gpus"] == 1 and ent[0]["global_grid"] == [64, 64, 64] and ent[0]["value"] > 0
