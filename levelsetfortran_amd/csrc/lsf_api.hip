@@ -149,6 +149,7 @@ struct Ctx {
     std::map<hipStream_t, StreamPart> part_by_stream;
     std::map<uint64_t, TileList> tiles;
     std::map<uint64_t, TileList> skew_tiles;
+    std::map<int, uint32_t*> sk_tables;            // skewed tiles: lookup tables per tile shape (SkTile::rel_entry / lane_off)
     std::map<std::array<int, 6>, BatchPlan> plans; // dataflow schedule: batch plans per grid / raster phase / sweep count
     bool checked = false;
 };
@@ -608,6 +609,37 @@ int reinit_f32_core(float* d_phi, const float* d_phiS_in, int nx, int ny, int nz
     return LSF_OK;
 }
 
+// lookup tables of a skewed tile shape (lsf_skew.hpp: sk_fill_tables), built once per shape and device
+int get_sk_tables(int wy, int wz, const uint32_t** out)
+{
+    Ctx& c = ctx();
+    const int key = wy * 16 + wz;
+    auto it = c.sk_tables.find(key);
+    if (it == c.sk_tables.end()) {
+        std::vector<uint32_t> h;
+#define LSF_SK_TAB(WY_, WZ_)                                                                 \
+    do {                                                                                     \
+        using T_ = SkTile<16, WY_, WZ_>;                                                     \
+        h.assign((size_t)T_::REL_WORDS + T_::OFF_WORDS, 0u);                                 \
+        sk_fill_tables<16, WY_, WZ_>(h.data());                                              \
+    } while (0)
+        if (key == 0x11) LSF_SK_TAB(1, 1);
+        else if (key == 0x21) LSF_SK_TAB(2, 1);
+        else if (key == 0x41) LSF_SK_TAB(4, 1);
+        else if (key == 0x12) LSF_SK_TAB(1, 2);
+        else if (key == 0x42) LSF_SK_TAB(4, 2);
+        else if (key == 0x24) LSF_SK_TAB(2, 4);
+        else LSF_SK_TAB(2, 2);
+#undef LSF_SK_TAB
+        uint32_t* d = nullptr;
+        HIPCHK(hipMalloc((void**)&d, h.size() * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        it = c.sk_tables.emplace(key, d).first;
+    }
+    *out = it->second;
+    return LSF_OK;
+}
+
 // LSF_GS_SCHEDULE selects how the exact Gauss-Seidel tile graph is executed (all are bit-identical):
 //   "dataflow" (default) skewed tiles, one launch per batch of sweeps, dependencies resolved in the kernel
 //   "skew"               skewed tiles, one launch per time slot (also the fallback of a dataflow launch that timed out)
@@ -734,6 +766,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     fa.ctl = ctl;
     fa.nTiles = (long)nTi * nTj * nTk;
     fa.last_packed = tl->last;
+    if (skew && !getenv("LSF_GS_NO_TABLES") && (rc = get_sk_tables(wy, wz, &fa.tables))) return rc;
 
     // start slot of sweep g, generated on demand (slot schedules; never transposed)
     std::vector<long> start{0};
@@ -1447,6 +1480,9 @@ int lsf_release_workspace(void)
         if (kv.second.d_meta) HIPCHK(hipFree(kv.second.d_meta));
     }
     c.plans.clear();
+    for (auto& kv : c.sk_tables)
+        if (kv.second) HIPCHK(hipFree(kv.second));
+    c.sk_tables.clear();
     for (auto* lists : {&c.tiles, &c.skew_tiles}) {
         for (auto& kv : *lists)
             if (kv.second.d) HIPCHK(hipFree(kv.second.d));

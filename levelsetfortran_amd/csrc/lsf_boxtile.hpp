@@ -60,6 +60,7 @@ struct GsArgs {
     const int* plane_size;  // [np] tiles per hyperplane
     const int* sweep_tab;   // [nsweeps][4] {sign i, sign j, sign k, spacing in hyperplanes behind sweep s - 1}
     unsigned long long timeout_ticks; // bound of every spin of the dataflow launch (100 MHz ticks)
+    const uint32_t* tables;  // skewed tiles: lookup tables of the tile shape (SkTile: rel_tab | off_tab), or NULL
     unsigned long long* dbg; // optional phase timers (s_memrealtime ticks): wait, load, march, publish, tasks
 };
 

@@ -56,7 +56,107 @@ struct SkTile {
     {
         return r < NCORE ? r * RA + k : NCORE * RA + (r - NCORE) * RH + (r < YD0 ? k : k - 4);
     }
+    __host__ __device__ static constexpr int row_at(int r)
+    {
+        return r < NCORE ? r * RA : NCORE * RA + (r - NCORE) * RH - (r < YD0 ? 0 : 4);
+    }
+    // frame coordinates (bq, cq) of LDS row r of a tile with nj x nk rows (rows beyond a partial tile alias a valid row),
+    // and its class: up = upstream halo, core = bundle row
+    __host__ __device__ static void row_coords(int r, int nj, int nk, int* bq_, int* cq_, int* up_, int* core_)
+    {
+        int bq, cq, up = 0, core = 0;
+        if (r < YU0) {
+            cq = r / NYT, bq = r - NYT * cq, core = 1;
+            bq = bq < nj - 1 ? bq : nj - 1, cq = cq < nk - 1 ? cq : nk - 1;
+        } else if (r < ZU0) {
+            const int q = r - YU0;
+            cq = q / 3, bq = q - 3 * cq - 3, up = 1;
+            cq = cq < nk - 1 ? cq : nk - 1;
+        } else if (r < YD0) {
+            const int q0 = r - ZU0, q = q0 < 3 * NYT - 1 ? q0 : 3 * NYT - 1, hz = q / NYT;
+            bq = q - NYT * hz, bq = bq < nj - 1 ? bq : nj - 1, cq = hz - 3, up = 1;
+        } else if (r < ZD0) {
+            const int q = r - YD0;
+            cq = q / 3, bq = nj + q - 3 * cq;
+            cq = cq < nk - 1 ? cq : nk - 1;
+        } else {
+            const int q0 = r - ZD0, q = q0 < 3 * NYT - 1 ? q0 : 3 * NYT - 1, hz = q / NYT;
+            bq = q - NYT * hz, bq = bq < nj - 1 ? bq : nj - 1, cq = nk + hz;
+        }
+        *bq_ = bq, *cq_ = cq, *up_ = up, *core_ = core;
+    }
+    // LDS index of the stencil value mm - 3 (absolute offset along the lane's axis, mm = 0..6) of the cell a lane works
+    // on at step 0; the value of step t sits t entries further.  pos = the sweep runs in the positive direction of that axis
+    __host__ __device__ static int lane_off(int bc, int cc, int axis, bool pos, int nj, int nk, int mm)
+    {
+        const int dA = mm - 3, dF = pos ? dA : -dA;
+        int base = (cc * NYT + bc) * RA;
+        if (axis == 1) {
+            const int bq = bc + dF;
+            base = row_at((bq >= 0 && bq < nj) ? cc * NYT + bq : (bq < 0 ? YU0 + cc * 3 + bq + 3 : YD0 + cc * 3 + bq - nj));
+        } else if (axis == 2) {
+            const int cq = cc + dF;
+            base = row_at((cq >= 0 && cq < nk) ? cq * NYT + bc : (cq < 0 ? ZU0 + (cq + 3) * NYT + bc : ZD0 + (cq - nk) * NYT + bc));
+        }
+        return base + 3 + dF;
+    }
+    // Tables for FULL tiles deep inside the grid (every row of the LDS image is an interior row: no clamping, no wall
+    // flags), which are > 90 % of the tiles of a BASELINE-size grid.  They replace ~250 of the ~3000 vector instructions
+    // a wavefront spends on a tile -- the kernel is bound by vector issue -- by two loads:
+    //   rel_tab[r][(sj > 0) * 2 + (sk > 0)] = rel_j | rel_k << 5 | (bq + cq + 3) << 10 | flags << 16   (rowtab entry of row r:
+    //       offset = rel_j * sx + rel_k * sxy from the tile origin, flags as in rowtab)
+    //   off_tab[tid][pos][8] (16 bit each) = lane_off(.., mm) of thread tid for a sweep running in the positive (pos = 1) or
+    //       negative direction of the lane's axis
+    // A thread's entries (all four / both directions: 48 bytes) do not depend on the tile, so they are requested when the
+    // block starts -- before it knows its tile -- and have arrived long before they are used (SkPre).
+    __host__ __device__ static uint32_t rel_entry(int r, bool sjpos, bool skpos)
+    {
+        int bq, cq, up, core;
+        row_coords(r, NYT, NZT, &bq, &cq, &up, &core);
+        const int rel_j = 3 + (sjpos ? bq : NYT - 1 - bq), rel_k = 3 + (skpos ? cq : NZT - 1 - cq);
+        return (uint32_t)rel_j | ((uint32_t)rel_k << 5) | ((uint32_t)(bq + cq + 3) << 10) | ((uint32_t)(up + 2 * (up | core)) << 16);
+    }
+    static constexpr int REL_WORDS = 4 * NR, OFF_WORDS = 2 * 64 * W * 4; // 32-bit words of the two tables
 };
+
+// host side: fills the two tables of a tile shape (see SkTile); layout [rel_tab | off_tab]
+template <int TA, int WY, int WZ>
+inline void sk_fill_tables(uint32_t* out)
+{
+    using T = SkTile<TA, WY, WZ>;
+    for (int r = 0; r < T::NR; ++r)
+        for (int d = 0; d < 4; ++d) out[4 * r + d] = T::rel_entry(r, (d >> 1) != 0, (d & 1) != 0);
+    uint16_t* off = (uint16_t*)(out + T::REL_WORDS);
+    const int NT = 64 * T::W;
+    for (int pos = 0; pos < 2; ++pos)
+        for (int tid = 0; tid < NT; ++tid) {
+            const int lane = tid & 63, wave = tid >> 6, t16 = lane & 15, bl = t16 / 3, axis = t16 - 3 * bl;
+            const int b = 5 * (wave % WY) + bl, c = 4 * (wave / WY) + (lane >> 4);
+            const bool row_ok = bl < 5;
+            const int bc = row_ok ? b : 0, cc = row_ok ? c : 0;
+            for (int mm = 0; mm < 8; ++mm)
+                off[(size_t)(2 * tid + pos) * 8 + mm] = mm < 7 ? (uint16_t)T::lane_off(bc, cc, axis, pos != 0, T::NYT, T::NZT, mm) : 0;
+        }
+}
+
+// a thread's table entries (see SkTile), requested at block start
+struct SkPre {
+    uint4 rel, off0, off1;
+};
+template <int TA, int WY, int WZ>
+__device__ __forceinline__ SkPre sk_prefetch(const GsArgs& a)
+{
+    using T = SkTile<TA, WY, WZ>;
+    SkPre p;
+    p.rel = p.off0 = p.off1 = make_uint4(0u, 0u, 0u, 0u);
+    if (a.tables) {
+        const int tid = threadIdx.x;
+        p.rel = ((const uint4*)a.tables)[tid < T::NR ? tid : 0];
+        const uint4* o = (const uint4*)(a.tables + T::REL_WORDS) + 2 * tid;
+        p.off0 = o[0], p.off1 = o[1];
+    }
+    return p;
+}
 
 // One tile.  SC1 = false: every value this tile reads was written by an earlier launch (slot schedule).
 // SC1 = true: producers may have run in this launch on another XCD (persistent schedule): results are stored
@@ -64,7 +164,7 @@ struct SkTile {
 // (cdna_hip_programming.md G16).  Measured on the slot schedule: no cost (4.75 vs 4.82 ms per 512^3 sweep), whereas
 // an agent-scope acquire per tile (L2 invalidate) with plain loads made every tile 35 % slower.
 template <int TA, int WY, int WZ, bool STRICT, bool SC1>
-__device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int g, int si, int sj, int sk)
+__device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int g, int si, int sj, int sk, const SkPre& pre)
 {
     static_assert(TA == 16, "row-per-16-lanes loader");
     using T = SkTile<TA, WY, WZ>;
@@ -91,7 +191,7 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
     const int nj = min(NYT, ny - j_lo), nk = min(NZT, nz - k_lo);
     const int nxi = nx - 1;                       // interior cells along x
     const int X0 = TA * m - NYT * fB - NZT * fC;  // Fx of row (0,0) at step 0
-    const int gb = g % a.nbuf;
+    const int gb = a.nbuf == 4 ? (g & 3) : g % 3; // nbuf is 3 or 4: no division by a run-time value
     const double* in = a.buf[gb];
     double* out = a.buf[gb + 1 == a.nbuf ? 0 : gb + 1];
 
@@ -107,27 +207,19 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
     double* out_t = out + org;
     const double* ps_t = a.phiS + org;
     const int gi0 = si > 0 ? 1 + X0 : nx - 1 - X0; // global i of frame position Fx = X0
+    // deep tile: full, and every row of its LDS image (3 halo rows on each side included) is an interior row
+    const bool deep = a.tables && nj == NYT && nk == NZT && j_lo >= 4 && j_lo + NYT + 2 <= ny - 1 && k_lo >= 4 && k_lo + NZT + 2 <= nz - 1;
+    const int dir = (sj > 0 ? 2 : 0) + (sk > 0 ? 1 : 0);
     for (int r = tid; r < T::NR; r += NT) {
-        int bq, cq, up = 0, core = 0;
-        // rows beyond a partial tile (nj < NYT or nk < NZT) are never consumed: they alias a valid row
-        if (r < T::YU0) {
-            cq = r / NYT, bq = r - NYT * cq, core = 1;
-            bq = min(bq, nj - 1), cq = min(cq, nk - 1);
-        } else if (r < T::ZU0) {
-            const int q = r - T::YU0;
-            cq = q / 3, bq = q - 3 * cq - 3, up = 1;
-            cq = min(cq, nk - 1);
-        } else if (r < T::YD0) {
-            const int q = min(r - T::ZU0, 3 * NYT - 1), hz = q / NYT;
-            bq = min(q - NYT * hz, nj - 1), cq = hz - 3, up = 1;
-        } else if (r < T::ZD0) {
-            const int q = r - T::YD0;
-            cq = q / 3, bq = nj + q - 3 * cq;
-            cq = min(cq, nk - 1);
-        } else {
-            const int q = min(r - T::ZD0, 3 * NYT - 1), hz = q / NYT;
-            bq = min(q - NYT * hz, nj - 1), cq = nk + hz;
+        if (deep) {
+            const uint32_t w = r == tid ? (dir == 0 ? pre.rel.x : (dir == 1 ? pre.rel.y : (dir == 2 ? pre.rel.z : pre.rel.w)))
+                                        : a.tables[4 * r + dir];
+            const int o = (int)(w & 31u) * (int)sx + (int)((w >> 5) & 31u) * (int)sxy, bc_ = (int)((w >> 10) & 63u) - 3;
+            rowtab[r] = make_int2(o * 4 + (int)(w >> 16), si > 0 ? gi0 - bc_ : gi0 + bc_);
+            continue;
         }
+        int bq, cq, up, core;
+        T::row_coords(r, nj, nk, &bq, &cq, &up, &core);
         const int gj_r = j_lo + (sj > 0 ? bq : nj - 1 - bq), gk_r = k_lo + (sk > 0 ? cq : nk - 1 - cq);
         const int rin = (int)((unsigned)(gj_r - 1) <= (unsigned)(ny - 2)) & (int)((unsigned)(gk_r - 1) <= (unsigned)(nz - 2));
         const int gj = min(max(gj_r, 0), ny), gk = min(max(gk_r, 0), nz);
@@ -228,21 +320,17 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
     const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
     const bool yquirk = axis == a.quirk_axis;
     const int row_core = (cc * NYT + bc) * RA + 3;
-    auto row_at = [](int r) { return r < T::NCORE ? r * RA : T::NCORE * RA + (r - T::NCORE) * T::RH - (r < T::YD0 ? 0 : 4); };
     int off[7];
+    {
+        const bool pos = (axis == 0 ? si : (axis == 1 ? sj : sk)) > 0;
+        if (deep) { // one 16-byte load instead of ~25 vector instructions per offset
+            const uint4 pk = pos ? pre.off1 : pre.off0;
+            off[0] = (int)(pk.x & 0xffffu), off[1] = (int)(pk.x >> 16), off[2] = (int)(pk.y & 0xffffu), off[3] = (int)(pk.y >> 16);
+            off[4] = (int)(pk.z & 0xffffu), off[5] = (int)(pk.z >> 16), off[6] = (int)(pk.w & 0xffffu);
+        } else {
 #pragma unroll
-    for (int mm = 0; mm < 7; ++mm) {
-        const int dA = mm - 3; // absolute offset along the lane's axis
-        const int dF = (axis == 0 ? si : (axis == 1 ? sj : sk)) > 0 ? dA : -dA;
-        int base = row_core - 3;
-        if (axis == 1) {
-            const int bq = bc + dF;
-            base = row_at((bq >= 0 && bq < nj) ? cc * NYT + bq : (bq < 0 ? T::YU0 + cc * 3 + bq + 3 : T::YD0 + cc * 3 + bq - nj));
-        } else if (axis == 2) {
-            const int cq = cc + dF;
-            base = row_at((cq >= 0 && cq < nk) ? cq * NYT + bc : (cq < 0 ? T::ZU0 + (cq + 3) * NYT + bc : T::ZD0 + (cq - nk) * NYT + bc));
+            for (int mm = 0; mm < 7; ++mm) off[mm] = T::lane_off(bc, cc, axis, pos, nj, nk, mm);
         }
-        off[mm] = base + 3 + dF;
     }
     const int fx0 = X0 - bc - cc;
     double acc = 0.0;
@@ -409,7 +497,8 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
     const int seg = (bx >= a.seg_end[0]) + (bx >= a.seg_end[1]) + (bx >= a.seg_end[2]);
     const uint32_t packed = a.seg_tiles[seg][bx - (seg ? a.seg_end[seg - 1] : 0)];
     if (ld_flag(a.ctl + 0) != 0) return; // converged or failed in an earlier launch
-    skew_tile<TA, WY, WZ, STRICT, false>(a, packed, a.seg_g[seg], a.seg_sign[seg][0], a.seg_sign[seg][1], a.seg_sign[seg][2]);
+    const SkPre pre = sk_prefetch<TA, WY, WZ>(a);
+    skew_tile<TA, WY, WZ, STRICT, false>(a, packed, a.seg_g[seg], a.seg_sign[seg][0], a.seg_sign[seg][1], a.seg_sign[seg][2], pre);
 }
 
 // Dataflow schedule: ONE launch per batch of sweeps, one block per tile.  The tiles of the batch form a list in slot
@@ -433,6 +522,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
     const long per_sweep = (long)nM * a.nTj * a.nTk;
     {
         const unsigned long long tsA = __builtin_amdgcn_s_memrealtime();
+        const SkPre pre = sk_prefetch<TA, WY, WZ>(a); // in flight while the block takes its ticket and waits for its tile
         if (tid == 0) {
             const long t = (long)__hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int go = 0;
@@ -500,7 +590,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
         if (go == 0) return;
         const unsigned long long tsB = __builtin_amdgcn_s_memrealtime();
         if (go == 1) {
-            skew_tile<TA, WY, WZ, STRICT, true>(a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]));
+            skew_tile<TA, WY, WZ, STRICT, true>(a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads(); // every wave of the tile has drained its stores (and left the LDS image)

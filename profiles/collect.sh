@@ -11,11 +11,20 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 # the fp32 Jacobi path (BASELINE configuration 5), same command shape
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_f32" -- python3 bench.py --dtype f32 > "$OUT/bench_f32_under_rocprof.json" 2> "$OUT/trace_f32.log"
+# the driver's own command (--steps 20 --warmup 5) under the kernel trace: its persist-kernel average must agree with the
+# roofline.avg_launch_us of the BENCH line
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_s20" -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > "$OUT/bench_s20_under_rocprof.json" 2> "$OUT/trace_s20.log"
+# min/max flow, exact ordering: kernel trace of 1 + 16 iterations (k_minmax_fp<0/1/2> per iteration)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mm" -- python3 profiles/micro/mm_pmc.py 512 gs 16 > "$OUT/mm_under_rocprof.txt" 2> "$OUT/trace_mm.log"
+# PMC passes at STEADY STATE (round 1 used 2-sweep launches, i.e. fill and drain): PMC_STEPS sweeps after as many warm-up
+# sweeps; the counters are summed over both launches and divided by the sweeps they cover (summarize.py)
+PMC_STEPS=${PMC_STEPS:-32}
 for C in FETCH_SIZE WRITE_SIZE; do
   for M in gs jacobi; do
-    rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_$M" -- python3 bench.py --steps 2 --warmup 0 --mode $M --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/pmc_${C}_$M.log"
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_$M" -- python3 bench.py --steps $PMC_STEPS --warmup $PMC_STEPS --mode $M --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/pmc_${C}_$M.log"
   done
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_f32" -- python3 bench.py --steps 2 --warmup 0 --dtype f32 > /dev/null 2> "$OUT/pmc_${C}_f32.log"
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_f32" -- python3 bench.py --steps $PMC_STEPS --warmup $PMC_STEPS --dtype f32 > /dev/null 2> "$OUT/pmc_${C}_f32.log"
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_mm" -- python3 profiles/micro/mm_pmc.py 512 gs 16 > /dev/null 2> "$OUT/pmc_${C}_mm.log"
 done
 cat > "$OUT/cal.py" <<'PY'
 import sys, torch
@@ -38,7 +47,7 @@ PY
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_${C}_cal" -- python3 "$OUT/cal.py" > /dev/null 2> "$OUT/pmc_${C}_cal.log"
 done
-python3 profiles/summarize.py "$OUT" "$TAG"
+python3 profiles/summarize.py "$OUT" "$TAG" $((2 * PMC_STEPS))
 bash profiles/sq_pass.sh "$TAG"
 # gpurun only carries gpurun_out/ back: stage the committed summaries there (copy them into profiles/ afterwards)
 mkdir -p "gpurun_out/profiles_$TAG"

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX from the repo root:  bash profiles/sq_pass.sh r01
-# SQ issue/stall counters of the two sweep kernels (own PMC passes, --kernel-trace only).
+# SQ issue/stall counters of the two sweep kernels (own PMC passes, --kernel-trace only), at the STEADY STATE of the
+# headline: 64 sweeps after 64 (round 1 profiled 2-sweep launches, i.e. fill and drain).
 set -u
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -8,9 +9,9 @@ OUT=gpurun_out/sq_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
 P2="GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA"
-for M in gs jacobi; do
-  rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d "$OUT/p1_$M" -- python3 bench.py --steps 2 --warmup 0 --mode $M --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/p1_$M.log"
-  rocprofv3 --pmc $P2 --kernel-trace --output-format csv -d "$OUT/p2_$M" -- python3 bench.py --steps 2 --warmup 0 --mode $M --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/p2_$M.log"
+for M in ${SQ_MODES:-gs jacobi}; do
+  rocprofv3 --pmc $P1 --kernel-trace --output-format csv -d "$OUT/p1_$M" -- python3 bench.py --steps ${SQ_STEPS:-64} --warmup ${SQ_STEPS:-64} --mode $M --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/p1_$M.log"
+  rocprofv3 --pmc $P2 --kernel-trace --output-format csv -d "$OUT/p2_$M" -- python3 bench.py --steps ${SQ_STEPS:-64} --warmup ${SQ_STEPS:-64} --mode $M --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/p2_$M.log"
 done
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, os, sys

@@ -13,6 +13,7 @@ import os
 import sys
 
 out_dir, tag = sys.argv[1], sys.argv[2]
+SWEEPS = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0  # sweeps covered by the PMC passes (warm-up + timed)
 here = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -21,7 +22,7 @@ def one(pattern):
     return g[0] if g else None
 
 
-for sub, suffix in (("trace", ""), ("trace_f32", "_f32")):
+for sub, suffix in (("trace", ""), ("trace_f32", "_f32"), ("trace_s20", "_steps20"), ("trace_mm", "_minmax")):
     stats = one(f"{sub}/**/*kernel_stats.csv")
     if stats:
         rows = list(csv.DictReader(open(stats)))
@@ -46,9 +47,19 @@ def gs_kernel_name():
     return "k_reinit_gs_box"
 
 
-for mode, kern in (("gs", gs_kernel_name()), ("jacobi", "k_reinit_jacobi"), ("f32", "k_reinit_jacobi_f32")):
+def jacobi_kernel_name():
+    f = one("pmc_FETCH_SIZE_jacobi/**/*counter_collection.csv")
+    if f:
+        for r in csv.DictReader(open(f)):
+            if "k_reinit_jacobi_sh" in r["Kernel_Name"]:
+                return "k_reinit_jacobi_sh"
+    return "k_reinit_jacobi"
+
+
+for mode, kern in (("gs", gs_kernel_name()), ("jacobi", jacobi_kernel_name()), ("f32", "k_reinit_jacobi_f32"), ("mm", "k_minmax_fp")):
     entry = {}
     bytes_per_cell = 12.0 if mode == "f32" else 24.0
+    sweeps = 17.0 if mode == "mm" else SWEEPS  # mm_time.py: 1 + 16 iterations
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         f = one(f"pmc_{ctr}_{mode}/**/*counter_collection.csv")
         if not f:
@@ -61,11 +72,10 @@ for mode, kern in (("gs", gs_kernel_name()), ("jacobi", "k_reinit_jacobi"), ("f3
                 ndisp += 1
         entry[ctr] = {"sum_KiB": tot, "dispatches": ndisp}
     if "FETCH_SIZE" in entry and "WRITE_SIZE" in entry:
-        sweeps = 2.0
         fr = entry["FETCH_SIZE"]["sum_KiB"] * 1024 / sweeps
         wr = entry["WRITE_SIZE"]["sum_KiB"] * 1024 / sweeps
         entry["per_sweep"] = {"fetch_raw": fr, "fetch_corrected": 2 * fr, "write": wr, "hbm_raw": fr + wr,
-                              "hbm_corrected": 2 * fr + wr, "algorithmic": bytes_per_cell * 510 ** 3}
+                              "hbm_corrected": 2 * fr + wr, "algorithmic": 16.0 * 512 ** 3 if mode == "mm" else bytes_per_cell * 510 ** 3, "sweeps_covered": sweeps}
         traffic[kern] = {"512": 2 * fr + wr}
     res[kern] = entry
 # calibration of the counters on a kernel with a known byte count in the same access width (8 B per lane):
@@ -98,7 +108,7 @@ if "FETCH_SIZE" in cal:
 json.dump(res, open(os.path.join(here, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 if traffic:
     json.dump(traffic, open(os.path.join(here, "traffic.json"), "w"), indent=1)
-for name in ("bench_under_rocprof.json", "bench_f32_under_rocprof.json"):
+for name in ("bench_under_rocprof.json", "bench_f32_under_rocprof.json", "bench_s20_under_rocprof.json"):
     b = os.path.join(out_dir, name)
     if os.path.exists(b):
         lines = [l for l in open(b) if l.startswith("{")]
