@@ -433,6 +433,11 @@ def main() -> None:
             # ranks wait.  Needs every GPU of the job visible to rank 0 (torch.distributed.run does not hide them).
             if world > 1:
                 sp = []
+                # the other ranks wait on the HOST (a gloo group): an RCCL barrier would keep a polling kernel on the very
+                # devices rank 0 is about to measure
+                host_group = None if shared_gpu else dist.new_group(backend="gloo")
+                torch.cuda.synchronize(dev)
+                dist.barrier(group=host_group)
                 if rank == 0 and not shared_gpu and torch.cuda.device_count() >= world:
                     try:
                         sp = _single_process_entries(lib, world, 64 if N < 128 else 512, K, W, args.arith)
@@ -440,10 +445,7 @@ def main() -> None:
                         sp = [{"path": "one process, lsf_multi", "value": None, "error": repr(e)[:300]}]
                         failed = True
                 entries.extend(sp)
-                if shared_gpu:
-                    dist.barrier()
-                else:
-                    dist.barrier(device_ids=[local_rank])
+                dist.barrier(group=host_group)
             decomposed = {"entries": entries,
                           "note": "Jacobi ordering (not reference-equal; bit-identical to the single-GPU Jacobi sweep), whole-job "
                                   "aggregates; same K sweeps after W warm-up sweeps, barrier + synchronize on both sides, max over "

@@ -449,31 +449,24 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
                      hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
-int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx,
-                double h, double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace,
-                int trace_cap, hipStream_t st)
+// The Jacobi reinit loop of one device (fp64 and fp32): per sweep the sweep kernel, the extrapolation BC and the
+// fixed-order RMS reduction with the stop / NaN test on the device; the host looks at the stop flag every CHECK_EVERY
+// sweeps (sweeps enqueued past the verdict return at once).
+template <typename T>
+int jacobi_loop(T* d_phi, const T* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h, double tol, bool strict,
+                int* sweeps_done, double* rms_trace, int trace_cap, hipStream_t st)
 {
-    int rc = check_dims(nx, ny, nz);
-    if (rc) return rc;
-    if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
-    if (first_raster < 0 || first_raster > 7) return fail(LSF_ERR_INVALID, "first_raster must be 0..7");
-    const int order = mode & LSF_ORDER_MASK;
-    const bool strict = (mode & LSF_ARITH_STRICT) != 0;
-    if (order != LSF_ORDER_GS && order != LSF_ORDER_JACOBI) return fail(LSF_ERR_INVALID, "unknown ordering");
-    if (!d_phi) return fail(LSF_ERR_INVALID, "phi is NULL");
-    if (order == LSF_ORDER_GS)
-        return reinit_slot_core(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done,
-                                rms_trace, trace_cap, st);
+    constexpr bool F32 = sizeof(T) == 4;
+    int rc = LSF_OK;
     Ctx& c = ctx();
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
     const int max_sweeps = iter + 1; // DO n=0,iter (subs.f90:735)
-
-    if ((rc = ws(c.slot[S_PONG], n * sizeof(double)))) return rc;
-    const double* d_phiS = d_phiS_in;
+    if ((rc = ws(c.slot[S_PONG], n * sizeof(T)))) return rc;
+    const T* d_phiS = d_phiS_in;
     if (!d_phiS) {
-        if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
-        HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st)); // :731
-        d_phiS = (const double*)c.slot[S_PHIS].p;
+        if ((rc = ws(c.slot[S_PHIS], n * sizeof(T)))) return rc;
+        HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(T), hipMemcpyDeviceToDevice, st)); // subs.f90:731
+        d_phiS = (const T*)c.slot[S_PHIS].p;
     }
     if ((rc = ws(c.slot[S_CTL], 64))) return rc;
     if ((rc = ws(c.slot[S_TRACE], (size_t)max_sweeps * sizeof(double)))) return rc;
@@ -481,107 +474,44 @@ int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, 
     double* d_trace = (double*)c.slot[S_TRACE].p;
     HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
 
-    // sweep geometry (Jacobi only from here on; the exact ordering returned above)
     const int jlo[3] = {1, 1, 1}, jhi[3] = {nx, ny, nz};
-    const JacPlan jp = jacobi_plan(jlo, jhi, strict);
-    const long n_sweep_part = jp.nparts;
+    JacPlan jp;
+    dim3 fgrid;
+    long n_sweep_part;
+    if constexpr (F32) {
+        fgrid = dim3(cdiv(nx - 1, F32_BX), cdiv(cdiv(ny - 1, 2), F32_BY), cdiv(nz - 1, F32_KC));
+        n_sweep_part = (long)fgrid.x * fgrid.y * fgrid.z;
+    } else {
+        jp = jacobi_plan(jlo, jhi, strict);
+        n_sweep_part = jp.nparts;
+    }
     const dim3 bgrid = bc_grid(nx + 1, ny + 1, nz + 1);
     const long n_bc_part = (long)bgrid.x * bgrid.y * bgrid.z;
     const long n_part = n_sweep_part + n_bc_part;
     if ((rc = ws(c.slot[S_PART], (size_t)n_part * sizeof(double)))) return rc;
     double* part = (double*)c.slot[S_PART].p;
-    const double den = rms_denominator(nx, ny, nz);
+    // fp64: the reference's INTEGER*4 product nx*ny*nz (subs.f90:914), wrapping like the reference; it is negative for the
+    // 1536^3 grid of configuration 5 (RMS = NaN, STOP) and there is no fp32 reference behaviour to mirror: fp32 fields
+    // divide by the true product
+    const double den = F32 ? (double)nx * (double)ny * (double)nz : rms_denominator(nx, ny, nz);
     const Box bx{nx + 1, ny + 1, nz + 1, 0, 0, 0, nx, ny, nz};
+    const int xwall = F32 ? F32_XWALL : 0;
 
-    double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
-    int host_ctl[3] = {0, 0, 0};
-    prof_begin();
-    const long launches_per_sweep = 1;
-    for (int s = 0; s < max_sweeps; ++s) {
-        const double* A = bufs[s & 1];
-        double* B = bufs[(s + 1) & 1];
-        prof_mark(st);
-        jacobi_launch(jp, strict, A, B, d_phiS, bx, jlo, jhi, dx, h, part, ctl, st);
-        prof_mark(st);
-        hipLaunchKernelGGL(k_bc<double>, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, dx,
-                           part + n_sweep_part, ctl, 0);
-        prof_mark(st);
-        hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
-        prof_mark(st);
-        if ((s + 1) % CHECK_EVERY == 0 && s + 1 < max_sweeps) {
-            HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (host_ctl[0]) break;
-        }
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const int nsw = host_ctl[1];
-    prof_end(nsw);
-    g_prof.sweep_launches = launches_per_sweep * g_prof.sweeps;
-    g_prof.kernel = jp.kind == 2 ? "k_reinit_jacobi_sh" : "k_reinit_jacobi";
-    if (bufs[nsw & 1] != d_phi)
-        HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (rms_trace && trace_cap > 0 && nsw > 0)
-        HIPCHK(hipMemcpyAsync(rms_trace, d_trace, sizeof(double) * (size_t)std::min(nsw, trace_cap),
-                              hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (sweeps_done) *sweeps_done = nsw;
-    if (host_ctl[2]) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, subs.f90:926)");
-    return LSF_OK;
-}
-
-
-// fp32 Jacobi reinit (BASELINE configuration 5).  Same loop as the Jacobi branch of reinit_core; the RMS is
-// accumulated in double from fp32 differences.
-int reinit_f32_core(float* d_phi, const float* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
-                    double tol, int* sweeps_done, double* rms_trace, int trace_cap, hipStream_t st)
-{
-    int rc = check_dims(nx, ny, nz);
-    if (rc) return rc;
-    if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
-    if (!d_phi) return fail(LSF_ERR_INVALID, "phi is NULL");
-    Ctx& c = ctx();
-    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
-    const int max_sweeps = iter + 1;
-    if ((rc = ws(c.slot[S_PONG], n * sizeof(float)))) return rc;
-    const float* d_phiS = d_phiS_in;
-    if (!d_phiS) {
-        if ((rc = ws(c.slot[S_PHIS], n * sizeof(float)))) return rc;
-        HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-        d_phiS = (const float*)c.slot[S_PHIS].p;
-    }
-    if ((rc = ws(c.slot[S_CTL], 64))) return rc;
-    if ((rc = ws(c.slot[S_TRACE], (size_t)max_sweeps * sizeof(double)))) return rc;
-    int* ctl = (int*)c.slot[S_CTL].p;
-    double* d_trace = (double*)c.slot[S_TRACE].p;
-    HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
-
-    const dim3 jgrid(cdiv(nx - 1, F32_BX), cdiv(cdiv(ny - 1, 2), F32_BY), cdiv(nz - 1, F32_KC));
-    const long n_sweep_part = (long)jgrid.x * jgrid.y * jgrid.z;
-    const dim3 bgrid = bc_grid(nx + 1, ny + 1, nz + 1);
-    const long n_bc_part = (long)bgrid.x * bgrid.y * bgrid.z;
-    const long n_part = n_sweep_part + n_bc_part;
-    if ((rc = ws(c.slot[S_PART], (size_t)n_part * sizeof(double)))) return rc;
-    double* part = (double*)c.slot[S_PART].p;
-    // the reference's INTEGER*4 product nx*ny*nz (subs.f90:914) is negative for the 1536^3 grid of configuration 5
-    // (RMS = NaN, STOP); there is no fp32 reference behaviour to mirror, so the fp32 path divides by the true product
-    const double den = (double)nx * (double)ny * (double)nz;
-    const Box bx{nx + 1, ny + 1, nz + 1, 0, 0, 0, nx, ny, nz};
-
-    float* bufs[2] = {d_phi, (float*)c.slot[S_PONG].p};
+    T* bufs[2] = {d_phi, (T*)c.slot[S_PONG].p};
     int host_ctl[3] = {0, 0, 0};
     prof_begin();
     for (int s = 0; s < max_sweeps; ++s) {
-        const float* A = bufs[s & 1];
-        float* B = bufs[(s + 1) & 1];
+        const T* A = bufs[s & 1];
+        T* B = bufs[(s + 1) & 1];
         prof_mark(st);
-        hipLaunchKernelGGL((k_reinit_jacobi_f32<false>), jgrid, dim3(F32_BX, F32_BY), 0, st, A, B, d_phiS, bx, 1, 1, 1, nx,
-                           ny, nz, (float)dx, (float)h, part, ctl, F32_XWALL);
+        if constexpr (F32)
+            hipLaunchKernelGGL((k_reinit_jacobi_f32<false>), fgrid, dim3(F32_BX, F32_BY), 0, st, A, B, d_phiS, bx, 1, 1, 1, nx, ny, nz,
+                               (float)dx, (float)h, part, ctl, xwall);
+        else
+            jacobi_launch(jp, strict, A, B, d_phiS, bx, jlo, jhi, dx, h, part, ctl, st);
         prof_mark(st);
-        hipLaunchKernelGGL(k_bc<float>, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, (float)dx,
-                           part + n_sweep_part, ctl, F32_XWALL);
+        hipLaunchKernelGGL(k_bc<T>, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, (T)dx, part + n_sweep_part, ctl,
+                           xwall);
         prof_mark(st);
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
         prof_mark(st);
@@ -597,16 +527,46 @@ int reinit_f32_core(float* d_phi, const float* d_phiS_in, int nx, int ny, int nz
     const int nsw = host_ctl[1];
     prof_end(nsw);
     g_prof.sweep_launches = g_prof.sweeps;
-    g_prof.kernel = "k_reinit_jacobi_f32";
+    g_prof.kernel = F32 ? "k_reinit_jacobi_f32" : (jp.kind == 2 ? "k_reinit_jacobi_sh" : "k_reinit_jacobi");
     if (bufs[nsw & 1] != d_phi)
-        HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(T), hipMemcpyDeviceToDevice, st));
     if (rms_trace && trace_cap > 0 && nsw > 0)
-        HIPCHK(hipMemcpyAsync(rms_trace, d_trace, sizeof(double) * (size_t)std::min(nsw, trace_cap),
-                              hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(rms_trace, d_trace, sizeof(double) * (size_t)std::min(nsw, trace_cap), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (sweeps_done) *sweeps_done = nsw;
     if (host_ctl[2]) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, subs.f90:926)");
     return LSF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int reinit_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx,
+                double h, double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace,
+                int trace_cap, hipStream_t st)
+{
+    int rc = check_dims(nx, ny, nz);
+    if (rc) return rc;
+    if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
+    if (first_raster < 0 || first_raster > 7) return fail(LSF_ERR_INVALID, "first_raster must be 0..7");
+    const int order = mode & LSF_ORDER_MASK;
+    const bool strict = (mode & LSF_ARITH_STRICT) != 0;
+    if (order != LSF_ORDER_GS && order != LSF_ORDER_JACOBI) return fail(LSF_ERR_INVALID, "unknown ordering");
+    if (!d_phi) return fail(LSF_ERR_INVALID, "phi is NULL");
+    if (order == LSF_ORDER_GS)
+        return reinit_slot_core(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done,
+                                rms_trace, trace_cap, st);
+    return jacobi_loop<double>(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, strict, sweeps_done, rms_trace, trace_cap, st);
+}
+
+// fp32 Jacobi reinit (BASELINE configuration 5): the same loop on float fields; the RMS is accumulated in double from
+// fp32 differences
+int reinit_f32_core(float* d_phi, const float* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
+                    double tol, int* sweeps_done, double* rms_trace, int trace_cap, hipStream_t st)
+{
+    int rc = check_dims(nx, ny, nz);
+    if (rc) return rc;
+    if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
+    if (!d_phi) return fail(LSF_ERR_INVALID, "phi is NULL");
+    return jacobi_loop<float>(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, false, sweeps_done, rms_trace, trace_cap, st);
 }
 
 // lookup tables of a skewed tile shape (lsf_skew.hpp: sk_fill_tables), built once per shape and device

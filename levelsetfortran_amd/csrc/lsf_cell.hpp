@@ -239,8 +239,9 @@ __device__ __forceinline__ void weno_iface_fast(const double v[6], double floor2
     const double R = rcp_nr(__builtin_fmax(Dp * Dm, 1e-300));
     const double rp = Dm * R, rm = Dp * R;
     const double Sa = e_ab - e_bc, S0 = e_bc - e_cm;
-    pwp = __builtin_fma(rp, __builtin_fma(n0 * (1.0 / 3.0), Sa, m2 * (0.5 * S0)), -(S0 * (1.0 / 12.0)));
-    pwm = __builtin_fma(rm, __builtin_fma(m2 * (1.0 / 3.0), S0, n0 * (0.5 * Sa)), -(Sa * (1.0 / 12.0)));
+    const double A = n0 * Sa, B = m2 * S0; // the two products both corrections are made of
+    pwp = __builtin_fma(rp, __builtin_fma(A, 1.0 / 3.0, B * 0.5), -(S0 * (1.0 / 12.0)));
+    pwm = __builtin_fma(rm, __builtin_fma(B, 1.0 / 3.0, A * 0.5), -(Sa * (1.0 / 12.0)));
     cen12 = __builtin_fma(7.0, d2 + d3, -(d1 + d4));
 }
 
