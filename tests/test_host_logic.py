@@ -1,8 +1,11 @@
 """Decomposition / halo-plan index arithmetic of levelsetfortran_amd.distributed (pure host logic)."""
 import itertools
+import os
 
 import numpy as np
 import pytest
+
+from conftest import ROOT
 
 from levelsetfortran_amd import distributed as D
 
@@ -116,3 +119,42 @@ def test_rms_denominator_of_the_decomposed_loop():
     assert d32.den == 1535.0 ** 3
     small = D.make_block(0, (1, 1, 1), (61, 61, 61))
     assert D.DistributedReinit(_Backend(torch.float64), small, 1e-3, 1e-5).den == 61.0 ** 3
+
+
+# ---------------------------------------------------------------------------------- the patched Fortran host (no GPU)
+def _dropin_exe():
+    exe = os.path.join(ROOT, "build", "dropin", "set3d_hip.exec")
+    return exe if os.path.exists(exe) else None
+
+
+@pytest.mark.skipif(_dropin_exe() is None, reason="drop-in executable not built")
+def test_host_reads_the_namelist_and_pads_per_axis(tmp_path):
+    """Host edits E4 / E4b without a GPU: the reference's main program, patched, reads &lsf_inputs,
+    applies pad cells per axis and side, prints the grid it will use -- and then stops LOUDLY at the first seam, because
+    the library has no CPU fallback.  (Grid: twoCube10's 12 x 1 x 1 box padded to 112 x 64 x 64 cells.)"""
+    import subprocess
+
+    import stl_io
+
+    s = np.load(os.path.join(ROOT, "tests", "golden", "surfaces.npz"))
+    stl_io.stl_write(tmp_path / "twoCube10.stl", s["twocube10_surfX"], s["twocube10_surfElem"])
+    (tmp_path / "in.nml").write_text("&lsf_inputs\n  dx = 0.125\n  dd = 7\n  dd_lo = 7, 27, 27\n  dd_hi = 8, 28, 28\n"
+                                     "  reinit_iter = 3\n  minmax_iter = 0\n  reinit2_iter = 0\n  arith = 'strict'\n  resident = 1\n/\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LSF_")}
+    env["LSF_REINIT_ITER"] = "5"  # the environment overrides the namelist
+    env["HIP_VISIBLE_DEVICES"] = "-1"
+    env["ROCR_VISIBLE_DEVICES"] = "-1"
+    p = subprocess.run(f"ulimit -s unlimited; cd {tmp_path}; {_dropin_exe()} twoCube10.stl in.nml", shell=True, env=env, text=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = p.stdout
+    assert "Run parameters read from in.nml" in out
+    assert "(namelist)" in out
+    # x: ceil(12 / 0.125) + 1 + 7 + 8 = 112; y, z: ceil(1 / 0.125) + 1 + 27 + 28 = 64
+    assert "Grid Size: nx = 112 , ny = 64 ,nz = 64" in out, out[-1500:]
+    assert "no HIP device visible" in out and "has no CPU fallback" in out.replace("\n", "")
+    assert p.returncode != 0
+
+    # a namelist that is named but missing is an error, not a silent default
+    p = subprocess.run(f"cd {tmp_path}; {_dropin_exe()} twoCube10.stl missing.nml", shell=True, env=env, text=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert "namelist file not found" in p.stdout and p.returncode != 0
