@@ -443,6 +443,54 @@ void jacobi_launch(const JacPlan& p, bool strict, const double* A, double* B, co
 #undef LSF_JAC_SH
 }
 
+// the same for float fields (k_reinit_jacobi_f32_sh<WX>: a lane owns the pair (i, j) / (i, j+1); one pair row per block)
+JacPlan jacobi_plan_f32(const int lo[3], const int hi[3])
+{
+    JacPlan p;
+    const int cx = hi[0] - lo[0], cy = hi[1] - lo[1], cz = hi[2] - lo[2], npair = cdiv(cy, 2);
+    const bool thinx = cx <= 8 && cy >= 64;
+    const char* env = getenv("LSF_JAC_SH");
+    const bool off = env && env[0] == '0' && env[1] == 0;
+    if (thinx || off) {
+        p.kind = thinx ? 1 : 0;
+        p.grid = thinx ? dim3(cdiv(npair, F32_BX), cdiv(cx, F32_BY), cdiv(cz, F32_KC)) : dim3(cdiv(cx, F32_BX), cdiv(npair, F32_BY), cdiv(cz, F32_KC));
+        p.nparts = (long)p.grid.x * p.grid.y * p.grid.z;
+        return p;
+    }
+    p.kind = 2;
+    int best = 1 << 30;
+    for (int wx : {1, 2, 4, 8}) {
+        const int waves = wx * cdiv(cx, 64 * wx - 1);
+        if (waves < best) best = waves, p.wx = wx;
+    }
+    int fwx = 0, fby = 0;
+    if (env && sscanf(env, "%dx%d", &fwx, &fby) >= 1 && (fwx == 1 || fwx == 2 || fwx == 4 || fwx == 8)) p.wx = fwx;
+    p.by = 1;
+    p.nbx = cdiv(cx, 64 * p.wx - 1), p.nby = npair, p.nbz = cdiv(cz, F32_KC);
+    p.nparts = ((long)p.nbx * p.nby * p.nbz + 7) / 8 * 8;
+    p.grid = dim3((unsigned)p.nparts);
+    return p;
+}
+void jacobi_launch_f32(const JacPlan& p, const float* A, float* B, const float* phiS, const Box& bx, const int lo[3], const int hi[3],
+                       double dx, double h, double* part, const int* done, int xwall, hipStream_t st)
+{
+#define LSF_F32_SH(WX_)                                                                                                   \
+    hipLaunchKernelGGL((k_reinit_jacobi_f32_sh<WX_>), p.grid, dim3(64 * WX_), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], hi[0], \
+                       hi[1], hi[2], (float)dx, (float)h, part, done, xwall, p.nbx, p.nby, p.nbz)
+    if (p.kind == 2) {
+        if (p.wx == 1) LSF_F32_SH(1);
+        else if (p.wx == 2) LSF_F32_SH(2);
+        else if (p.wx == 4) LSF_F32_SH(4);
+        else LSF_F32_SH(8);
+    } else if (p.kind == 1)
+        hipLaunchKernelGGL((k_reinit_jacobi_f32<true>), p.grid, dim3(F32_BX, F32_BY), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], hi[0],
+                           hi[1], hi[2], (float)dx, (float)h, part, done, xwall);
+    else
+        hipLaunchKernelGGL((k_reinit_jacobi_f32<false>), p.grid, dim3(F32_BX, F32_BY), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], hi[0],
+                           hi[1], hi[2], (float)dx, (float)h, part, done, xwall);
+#undef LSF_F32_SH
+}
+
 int gs_schedule();
 int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
                      double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace, int trace_cap,
@@ -476,15 +524,10 @@ int jacobi_loop(T* d_phi, const T* d_phiS_in, int nx, int ny, int nz, int iter, 
 
     const int jlo[3] = {1, 1, 1}, jhi[3] = {nx, ny, nz};
     JacPlan jp;
-    dim3 fgrid;
     long n_sweep_part;
-    if constexpr (F32) {
-        fgrid = dim3(cdiv(nx - 1, F32_BX), cdiv(cdiv(ny - 1, 2), F32_BY), cdiv(nz - 1, F32_KC));
-        n_sweep_part = (long)fgrid.x * fgrid.y * fgrid.z;
-    } else {
-        jp = jacobi_plan(jlo, jhi, strict);
-        n_sweep_part = jp.nparts;
-    }
+    if constexpr (F32) jp = jacobi_plan_f32(jlo, jhi);
+    else jp = jacobi_plan(jlo, jhi, strict);
+    n_sweep_part = jp.nparts;
     const dim3 bgrid = bc_grid(nx + 1, ny + 1, nz + 1);
     const long n_bc_part = (long)bgrid.x * bgrid.y * bgrid.z;
     const long n_part = n_sweep_part + n_bc_part;
@@ -504,11 +547,8 @@ int jacobi_loop(T* d_phi, const T* d_phiS_in, int nx, int ny, int nz, int iter, 
         const T* A = bufs[s & 1];
         T* B = bufs[(s + 1) & 1];
         prof_mark(st);
-        if constexpr (F32)
-            hipLaunchKernelGGL((k_reinit_jacobi_f32<false>), fgrid, dim3(F32_BX, F32_BY), 0, st, A, B, d_phiS, bx, 1, 1, 1, nx, ny, nz,
-                               (float)dx, (float)h, part, ctl, xwall);
-        else
-            jacobi_launch(jp, strict, A, B, d_phiS, bx, jlo, jhi, dx, h, part, ctl, st);
+        if constexpr (F32) jacobi_launch_f32(jp, A, B, d_phiS, bx, jlo, jhi, dx, h, part, ctl, xwall, st);
+        else jacobi_launch(jp, strict, A, B, d_phiS, bx, jlo, jhi, dx, h, part, ctl, st);
         prof_mark(st);
         hipLaunchKernelGGL(k_bc<T>, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, (T)dx, part + n_sweep_part, ctl,
                            xwall);
@@ -527,7 +567,7 @@ int jacobi_loop(T* d_phi, const T* d_phiS_in, int nx, int ny, int nz, int iter, 
     const int nsw = host_ctl[1];
     prof_end(nsw);
     g_prof.sweep_launches = g_prof.sweeps;
-    g_prof.kernel = F32 ? "k_reinit_jacobi_f32" : (jp.kind == 2 ? "k_reinit_jacobi_sh" : "k_reinit_jacobi");
+    g_prof.kernel = F32 ? (jp.kind == 2 ? "k_reinit_jacobi_f32_sh" : "k_reinit_jacobi_f32") : (jp.kind == 2 ? "k_reinit_jacobi_sh" : "k_reinit_jacobi");
     if (bufs[nsw & 1] != d_phi)
         HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(T), hipMemcpyDeviceToDevice, st));
     if (rms_trace && trace_cap > 0 && nsw > 0)
@@ -1925,20 +1965,12 @@ int lsf_jacobi_sweep_box_f32(const float* d_in, float* d_out, const float* d_phi
     if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) return LSF_OK;
     if ((rc = sweep_region_ok(box, lo, hi))) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int npair = cdiv(hi[1] - lo[1], 2);
-    const bool thinx = hi[0] - lo[0] <= 8 && hi[1] - lo[1] >= 64;
-    const dim3 grid = thinx ? dim3(cdiv(npair, F32_BX), cdiv(hi[0] - lo[0], F32_BY), cdiv(hi[2] - lo[2], F32_KC))
-                            : dim3(cdiv(hi[0] - lo[0], F32_BX), cdiv(npair, F32_BY), cdiv(hi[2] - lo[2], F32_KC));
-    const long np = (long)grid.x * grid.y * grid.z;
+    const JacPlan jp = jacobi_plan_f32(lo, hi);
+    const long np = jp.nparts;
     double* part = nullptr;
     if ((rc = stream_partials(st, (size_t)np, &part))) return rc;
     const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
-    if (thinx)
-        hipLaunchKernelGGL((k_reinit_jacobi_f32<true>), grid, dim3(F32_BX, F32_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0],
-                           lo[1], lo[2], hi[0], hi[1], hi[2], (float)dx, (float)h, part, (const int*)nullptr, 0);
-    else
-        hipLaunchKernelGGL((k_reinit_jacobi_f32<false>), grid, dim3(F32_BX, F32_BY), 0, st, d_in, d_out, d_phiS, bx, lo[0],
-                           lo[1], lo[2], hi[0], hi[1], hi[2], (float)dx, (float)h, part, (const int*)nullptr, 0);
+    jacobi_launch_f32(jp, d_in, d_out, d_phiS, bx, lo, hi, dx, h, part, nullptr, 0, st);
     return finish_partials(st, part, np, d_sumsq);
 }
 

@@ -96,6 +96,44 @@ __device__ __forceinline__ void weno_axis_f32(const f2 q[7], bool yquirk, f2& dm
     dp = fma2(splat(1.0f / 12.0f), cen12, PWp);
 }
 
+// Interface form (see weno_iface_fast in lsf_cell.hpp): v[0..5] = phi(i-2 .. i+3) for the two cells of a lane; returns the
+// D+ correction of cell i, the D- correction of cell i+1 and cen12 of cell i (all unscaled).  The two normalisations keep
+// their own reciprocal: the product of the two denominators can leave the fp32 range.
+__device__ __forceinline__ void weno_iface_f32(const f2 v[6], f2& pwp, f2& pwm, f2& cen12)
+{
+    const f2 d1 = v[1] - v[0], d2 = v[2] - v[1], d3 = v[3] - v[2], d4 = v[4] - v[3], d5 = v[5] - v[4];
+    const f2 um = d2 - d1, u0 = d3 - d2, u1 = d4 - d3, u2 = d5 - d4;
+    const f2 e_ab = u2 - u1, e_bc = u1 - u0, e_cm = u0 - um;
+    const f2 C = splat(13.0f / 3.0f), three = splat(3.0f);
+    const f2 t0 = fma2(-three, u1, u2), t1 = u1 + u0, t2 = fma2(three, u0, -um);
+    const f2 mx = max2(max2(max2(abs2(d1), abs2(d2)), max2(abs2(d3), abs2(d4))), abs2(d5));
+    const f2 eps = fma2(splat(1.E-6f / 3.0f) * mx, mx, splat(LSF_F32_FLOOR));
+    f2 q0 = fma2(t0, t0, fma2(C * e_ab, e_ab, eps)), q1 = fma2(t1, t1, fma2(C * e_bc, e_bc, eps)),
+       q2 = fma2(t2, t2, fma2(C * e_cm, e_cm, eps));
+    const f2 s = pow2_inv(q0 + q1 + q2);
+    q0 *= s, q1 *= s, q2 *= s;
+    const f2 t12 = q1 * q2, t02 = q0 * q2, t01 = q0 * q1;
+    const f2 n0 = t12 * t12, n1 = t02 * t02, m2 = t01 * t01;
+    const f2 rp = rcp2(fma2(three, m2, fma2(splat(6.0f), n1, n0))); // plus side of cell i:    1, 6, 3
+    const f2 rm = rcp2(fma2(three, n0, fma2(splat(6.0f), n1, m2))); // minus side of cell i+1: mirrored
+    const f2 Sa = e_ab - e_bc, S0 = e_bc - e_cm;
+    const f2 A = n0 * Sa, B = m2 * S0;
+    pwp = fma2(rp, fma2(A, splat(1.0f / 3.0f), B * splat(0.5f)), -(S0 * splat(1.0f / 12.0f)));
+    pwm = fma2(rm, fma2(B, splat(1.0f / 3.0f), A * splat(0.5f)), -(Sa * splat(1.0f / 12.0f)));
+    cen12 = fma2(splat(7.0f), d2 + d3, -(d1 + d4));
+}
+
+// the two one-sided differences of one cell pair from its two interfaces (q[0..6] = -3..+3): kernels that cannot share
+// interfaces between lanes (thin rims) use this, so that every fp32 kernel returns the same bits for the same cell
+__device__ __forceinline__ void weno_axis_from_ifaces_f32(const f2 q[7], f2& dm, f2& dp)
+{
+    f2 pwp_l, pwm_c, cen_l, pwp_c, pwm_r, cen_c;
+    weno_iface_f32(q, pwp_l, pwm_c, cen_l);
+    weno_iface_f32(q + 1, pwp_c, pwm_r, cen_c);
+    dm = fma2(splat(1.0f / 12.0f), cen_c, -pwm_c);
+    dp = fma2(splat(1.0f / 12.0f), cen_c, pwp_c);
+}
+
 // Godunov term of one axis for the pair (subs.f90:684-692), unscaled one-sided differences.  With
 // sg = sign(phic) (+1 / -1): max(max(sg dm, 0)^2, min(sg dp, 0)^2) is the reference's switch in one expression.
 __device__ __forceinline__ f2 godunov_f32(f2 sg, f2 dm, f2 dp)
@@ -208,9 +246,9 @@ __global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const floa
                 qy[0] = mk2(r0, r1), qy[1] = mk2(r1, r2), qy[2] = mk2(r2, c.x), qy[3] = c;
                 qy[4] = mk2(c.y, r5), qy[5] = mk2(r5, r6), qy[6] = mk2(r6, r7);
                 f2 wa, wb, wc, wd, we, wf;
-                weno_axis_f32(qx, false, wa, wb);
-                weno_axis_f32(qy, true, wc, wd);
-                weno_axis_f32(qz, false, we, wf);
+                weno_axis_from_ifaces_f32(qx, wa, wb); // x and z in the interface form (the arithmetic of
+                weno_axis_f32(qy, true, wc, wd);       // k_reinit_jacobi_f32_sh), y per cell
+                weno_axis_from_ifaces_f32(qz, we, wf);
                 if (wA) a.x = wa.x, b.x = wb.x, cc.x = wc.x, d.x = wd.x, e.x = we.x, f.x = wf.x;
                 if (wB) a.y = wa.y, b.y = wb.y, cc.y = wc.y, d.y = wd.y, e.y = we.y, f.y = wf.y;
             }
@@ -252,6 +290,160 @@ __global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const floa
         double t = 0.0;
         for (int w = 0; w < F32_BX * F32_BY / 64; ++w) t += red[w];
         partials[blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)] = t;
+    }
+}
+
+// =============================================================================================
+// The fp32 sweep with WENO interfaces shared along x (DPP + LDS between wavefronts) and z (register carry); same
+// structure as k_reinit_jacobi_sh (lsf_kernels.hpp), a lane owning the pair (i, j) / (i, j+1).  Block = 64 WX lanes along
+// x, first lane a helper; every load of a step is issued at its top without a branch in front of it.
+// =============================================================================================
+__device__ __forceinline__ f2 dpp_shr1_f2(f2 v)
+{
+    const int a = __builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v.x), 0x138, 0xf, 0xf, false);
+    const int b = __builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v.y), 0x138, 0xf, 0xf, false);
+    return mk2(__uint_as_float((unsigned)a), __uint_as_float((unsigned)b));
+}
+
+template <int WX>
+__global__ __launch_bounds__(64 * WX) void k_reinit_jacobi_f32_sh(const float* __restrict__ A, float* __restrict__ Bout,
+                                                                  const float* __restrict__ phiS, Box bx, int lo0, int lo1, int lo2,
+                                                                  int hi0, int hi1, int hi2, float dx, float h,
+                                                                  double* __restrict__ partials, const int* __restrict__ done,
+                                                                  int xwall, int nbx, int nby, int nbz)
+{
+    __shared__ double red[WX];
+    __shared__ f2 xch[2][WX];
+    if (done && *done) return;
+    const unsigned per = gridDim.x >> 3;
+    const unsigned L = (blockIdx.x & 7u) * per + (blockIdx.x >> 3); // XCD-aware numbering, see k_reinit_jacobi_sh
+    const unsigned nblk = (unsigned)nbx * nby * nbz;
+    const int tid = threadIdx.x, lane = tid & 63, wx = tid >> 6;
+    float acc = 0.f;
+    if (L < nblk) {
+        const int bxi = (int)(L % (unsigned)nbx), byi = (int)((L / (unsigned)nbx) % (unsigned)nby), bzi = (int)(L / ((unsigned)nbx * nby));
+        const int xl = 64 * wx + lane;
+        const int li = lo0 - 1 + bxi * (64 * WX - 1) + xl;
+        const int lj = lo1 + 2 * byi;
+        const int k0 = lo2 + bzi * F32_KC, k1 = min(k0 + F32_KC, hi2);
+        const int sx = bx.lx;
+        const long sxy = (long)bx.lx * bx.ly;
+        const bool cell = xl >= 1 && li < hi0;
+        const bool two = lj + 1 < hi1;
+        const int gi = li + bx.gx0, gj = lj + bx.gy0;
+        const bool i_weno = gi > 3 && gi < bx.nx - 4;
+        const bool jA = i_weno && gj > 3 && gj < bx.ny - 4;
+        const bool jB = i_weno && two && gj + 1 > 3 && gj + 1 < bx.ny - 4;
+        const float inv_dx = 1.0f / dx, dx2 = dx * dx;
+        const bool on_xwall = xwall && cell && (gi == 1 || gi == bx.nx - 1);
+        // byte offsets inside a k-plane, fixed along the march: the lane's two points, their x neighbours (colA/B - 8 +
+        // immediates; range-checked by the descriptor where they leave the plane) and the six rows above and below
+        const int lic = min(li, bx.lx - 1);
+        unsigned row[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) row[t] = 4u * (unsigned)(lic + sx * min(max(lj + t - 3, 0), bx.ly - 1));
+        const unsigned colA = row[3], colB = row[4];
+        const unsigned plane_bytes = 4u * (unsigned)sxy;
+        auto desc = [&](const float* base) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)plane_bytes, 0x00020000);
+        };
+        auto at = [](__amdgpu_buffer_rsrc_t r, unsigned boff) -> float {
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, boff, 0, 0));
+        };
+        auto ldz = [&](int k) -> f2 {
+            const auto r = desc(A + sxy * min(max(k, 0), bx.lz - 1));
+            return mk2(at(r, colA), at(r, colB));
+        };
+        f2 qz[7];
+#pragma unroll
+        for (int m = 0; m < 7; ++m) qz[m] = ldz(k0 - 4 + m);
+        f2 pwm_z;
+        {
+            f2 t0_, t1_;
+            weno_iface_f32(qz + 1, t0_, pwm_z, t1_);
+        }
+        int pb = 0;
+        for (int k = k0; k < k1; ++k) {
+            const auto P = desc(A + sxy * k);
+            f2 vx[6];
+#pragma unroll
+            for (int m = 0; m < 6; ++m)
+                if (m != 2) vx[m] = mk2(at(P, colA - 8u + 4u * (unsigned)m), at(P, colB - 8u + 4u * (unsigned)m));
+#pragma unroll
+            for (int m = 0; m < 6; ++m) qz[m] = qz[m + 1];
+            qz[6] = ldz(k + 3);
+            const f2 c = qz[3];
+            vx[2] = c;
+            const int gk = k + bx.gz0;
+            const bool k_weno = gk > 3 && gk < bx.nz - 4;
+            const bool wA = jA && k_weno, wB = jB && k_weno;
+            f2 pwp_z, pwm_z_next, cen_z, pwp_x, pwm_x, cen_x;
+            weno_iface_f32(qz + 1, pwp_z, pwm_z_next, cen_z);
+            const float r0 = at(P, row[0]), r1 = at(P, row[1]), r2 = at(P, row[2]), r5 = at(P, row[5]), r6 = at(P, row[6]),
+                        r7 = at(P, row[7]);
+            const auto PS = desc(phiS + sxy * k);
+            const f2 pS = mk2(at(PS, colA), at(PS, colB));
+            weno_iface_f32(vx, pwp_x, pwm_x, cen_x);
+            f2 pwm_l = dpp_shr1_f2(pwm_x);
+            if (WX > 1) {
+                if (lane == 63) xch[pb][wx] = pwm_x;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (lane == 0 && wx > 0) pwm_l = xch[pb][wx - 1];
+                pb ^= 1;
+            }
+            // first-order one-sided differences (subs.f90:657-662), always valid; WENO where the branch test holds
+            f2 a = c - vx[1], b = vx[3] - c;
+            f2 cc = c - mk2(r2, c.x), d = mk2(c.y, r5) - c;
+            f2 e = c - qz[2], f = qz[4] - c;
+            {
+                const f2 twelfth = splat(1.0f / 12.0f);
+                const f2 wa = fma2(twelfth, cen_x, -pwm_l), wb = fma2(twelfth, cen_x, pwp_x);
+                const f2 we = fma2(twelfth, cen_z, -pwm_z), wf = fma2(twelfth, cen_z, pwp_z);
+                f2 qy[7], wc, wd;
+                qy[0] = mk2(r0, r1), qy[1] = mk2(r1, r2), qy[2] = mk2(r2, c.x), qy[3] = c;
+                qy[4] = mk2(c.y, r5), qy[5] = mk2(r5, r6), qy[6] = mk2(r6, r7);
+                weno_axis_f32(qy, true, wc, wd);
+                if (wA) a.x = wa.x, b.x = wb.x, cc.x = wc.x, d.x = wd.x, e.x = we.x, f.x = wf.x;
+                if (wB) a.y = wa.y, b.y = wb.y, cc.y = wc.y, d.y = wd.y, e.y = we.y, f.y = wf.y;
+            }
+            const f2 sg = mk2(c.x > 0.f ? 1.f : -1.f, c.y > 0.f ? 1.f : -1.f);
+            const f2 S = godunov_f32(sg, a, b) + godunov_f32(sg, cc, d) + godunov_f32(sg, e, f);
+            const f2 nv = finish_f32(c, S, mk2(pS.x, two ? pS.y : 1.f), dx2, inv_dx, h);
+            if (cell) {
+                const auto PB = desc(Bout + sxy * k);
+                const f2 dl = nv - c;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nv.x), PB, colA, 0, 0);
+                acc = __builtin_fmaf(dl.x, dl.x, acc);
+                if (two) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nv.y), PB, colB, 0, 0);
+                    acc = __builtin_fmaf(dl.y, dl.y, acc);
+                }
+                if (on_xwall) { // the pure x-face wall points beside this pair (single-domain sweeps)
+                    const f2 wv = nv + splat(dx);
+                    for (int side = 0; side < 2; ++side) {
+                        if (side == 0 ? gi != 1 : gi != bx.nx - 1) continue;
+                        const f2 old = side == 0 ? vx[1] : vx[3];
+                        const f2 wdl = wv - old;
+                        const unsigned sh = side == 0 ? (unsigned)-4 : 4u;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wv.x), PB, colA + sh, 0, 0);
+                        acc = __builtin_fmaf(wdl.x, wdl.x, acc);
+                        if (two) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wv.y), PB, colB + sh, 0, 0);
+                            acc = __builtin_fmaf(wdl.y, wdl.y, acc);
+                        }
+                    }
+                }
+            }
+            pwm_z = pwm_z_next;
+        }
+    }
+    const double tot = wave_sum((double)acc);
+    if (lane == 0) red[wx] = tot;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < WX; ++w) t += red[w];
+        partials[L] = t;
     }
 }
 
