@@ -23,16 +23,33 @@ __device__ __forceinline__ double fmin2(double a, double b) { return (a < b) ? a
 // STRICT: one axis of the WENO branch (subs.f90:509-552 / :555-598 / :601-644).
 // q[0..6] = phi at -3..+3 along the axis in ABSOLUTE orientation; yquirk = subs.f90:576.
 // ---------------------------------------------------------------------------------------------
+// x / dx exactly as the IEEE division the reference executes (correctly rounded), for a divisor whose correctly rounded
+// reciprocal rdx = 1. / dx is at hand: one product and two residual corrections (q1 is within half an ulp and a hair of
+// x / dx, the second correction rounds it correctly -- Markstein).  17 of the 27 divisions of an axis divide by dx
+// (subs.f90:509-513, :525-530): five instructions each instead of the ~11 of a general fp64 division.  phi, hence x, is
+// far from the overflow and underflow thresholds; NaN propagates (the reference's NaN is born in phiSign, subs.f90:169,
+// not here: the twoCube10 stop sweep is tested).
+__device__ __forceinline__ double div_dx(double x, double dx, double rdx)
+{
+#pragma clang fp contract(off)
+    const double q0 = x * rdx;
+    const double r0 = __builtin_fma(-dx, q0, x);
+    const double q1 = __builtin_fma(r0, rdx, q0);
+    const double r1 = __builtin_fma(-dx, q1, x);
+    return __builtin_fma(r1, rdx, q1);
+}
+
 __device__ __forceinline__ void weno_axis_strict(const double q[7], double dx, bool yquirk, double& dm,
                                                  double& dp)
 {
 #pragma clang fp contract(off)
+    const double rdx = 1. / dx; // loop invariant: hoisted out of every march
     const double m3 = q[0], m2 = q[1], m1 = q[2], c0 = q[3], r1 = q[4], r2 = q[5], r3 = q[6];
-    const double ap = (r3 - 2. * r2 + r1) / dx;
-    const double am = (m3 - 2. * m2 + m1) / dx;
-    const double bp = (r2 - 2. * r1 + c0) / dx;
-    const double bm = (m2 - 2. * m1 + c0) / dx;
-    const double cp = (r1 - 2. * c0 + m1) / dx;
+    const double ap = div_dx(r3 - 2. * r2 + r1, dx, rdx);
+    const double am = div_dx(m3 - 2. * m2 + m1, dx, rdx);
+    const double bp = div_dx(r2 - 2. * r1 + c0, dx, rdx);
+    const double bm = div_dx(m2 - 2. * m1 + c0, dx, rdx);
+    const double cp = div_dx(r1 - 2. * c0 + m1, dx, rdx);
     const double cm = cp, dpp = bm, dmm = bp;
 
     const double IS0p = 13. * (ap - bp) * (ap - bp) + 3. * (ap - 3. * bp) * (ap - 3. * bp);
@@ -42,12 +59,12 @@ __device__ __forceinline__ void weno_axis_strict(const double q[7], double dx, b
     const double IS2p = 13. * (cp - dpp) * (cp - dpp) + 3. * (3. * cp - dpp) * (3. * cp - dpp);
     const double IS2m = 13. * (cm - dmm) * (cm - dmm) + 3. * (3. * cm - dmm) * (3. * cm - dmm);
 
-    const double p0 = (m2 - m3) / dx;
-    const double p1 = (m1 - m2) / dx;
-    const double p2 = (c0 - m1) / dx;
-    const double p3 = (r1 - c0) / dx;
-    const double p4 = (r2 - r1) / dx;
-    const double p5 = yquirk ? (r3 - r3) / dx : (r3 - r2) / dx;
+    const double p0 = div_dx(m2 - m3, dx, rdx);
+    const double p1 = div_dx(m1 - m2, dx, rdx);
+    const double p2 = div_dx(c0 - m1, dx, rdx);
+    const double p3 = div_dx(r1 - c0, dx, rdx);
+    const double p4 = div_dx(r2 - r1, dx, rdx);
+    const double p5 = yquirk ? div_dx(r3 - r3, dx, rdx) : div_dx(r3 - r2, dx, rdx);
 
     const double epsp =
         (1.E-6) * fmax2(p1 * p1, fmax2(p2 * p2, fmax2(p3 * p3, fmax2(p4 * p4, p5 * p5)))) + 1.E-99;
@@ -109,12 +126,13 @@ __device__ __forceinline__ double cell_update_strict(const double qx[7], const d
         weno_axis_strict(qy, dx, true, c, d);
         weno_axis_strict(qz, dx, false, e, f);
     } else {
-        a = (phic - qx[2]) / dx;
-        b = (qx[4] - phic) / dx;
-        c = (phic - qy[2]) / dx;
-        d = (qy[4] - phic) / dx;
-        e = (phic - qz[2]) / dx;
-        f = (qz[4] - phic) / dx;
+        const double rdx = 1. / dx;
+        a = div_dx(phic - qx[2], dx, rdx);
+        b = div_dx(qx[4] - phic, dx, rdx);
+        c = div_dx(phic - qy[2], dx, rdx);
+        d = div_dx(qy[4] - phic, dx, rdx);
+        e = div_dx(phic - qz[2], dx, rdx);
+        f = div_dx(qz[4] - phic, dx, rdx);
     }
     const double gM = godunov_strict(phic, a, b, c, d, e, f);
     const double sgn = pS / __builtin_sqrt(pS * pS + dx * dx * gM); // subs.f90:169
@@ -312,8 +330,9 @@ __device__ __forceinline__ void axis_pair(const double q[7], bool weno_ok, bool 
         if (weno_ok) {
             weno_axis_strict(q, dx, yquirk, dm, dp);
         } else {
-            dm = (q[3] - q[2]) / dx; // subs.f90:657-662
-            dp = (q[4] - q[3]) / dx;
+            const double rdx = 1. / dx;
+            dm = div_dx(q[3] - q[2], dx, rdx); // subs.f90:657-662
+            dp = div_dx(q[4] - q[3], dx, rdx);
         }
     } else {
         if (weno_ok) {

@@ -119,6 +119,21 @@ def test_reinit_twocube10(lsf, twocube):
     phi = F(twocube["phi0"])
     with pytest.raises(lsf.LsfNaNError):
         lsf.reinit(phi, None, None, nx, ny, nz, 10000, dx, h, arith="strict")
+    # ... at the reference's own sweep: its NaN is born in phiSign (0 / 0, subs.f90:169) at sweep index 272, and every
+    # RMS value it printed before that is reproduced (STRICT divides by dx through a reciprocal sequence that must round
+    # like the IEEE division -- lsf_cell.hpp div_dx -- an error there would move this trace)
+    import ctypes
+
+    from levelsetfortran_amd import _lib
+
+    k = int(twocube["nan_sweep_index"])
+    phi = F(twocube["phi0"])
+    trace = np.zeros(k + 8)
+    done = ctypes.c_int(0)
+    rc = _lib.load().lsf_reinit(phi.ctypes.data, nx, ny, nz, k + 5, dx, h, 1.0e-5, _lib.LSF_ARITH_STRICT, ctypes.byref(done),
+                                trace.ctypes.data, k + 8)
+    assert rc == _lib.LSF_ERR_NAN and done.value == k + 1
+    assert np.isnan(trace[k]) and np.allclose(trace[:k], twocube["rms"][:k], rtol=1e-10, atol=0)
 
 
 def test_reinit_device_seam_resume_with_phiS(lsf, oracle, synth):
