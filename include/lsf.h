@@ -214,6 +214,19 @@ int lsf_pack_box(const double *d_field, const lsf_box *box, const int lo[3], con
 int lsf_unpack_box(double *d_field, const lsf_box *box, const int lo[3], const int hi[3],
                    const double *d_buf, void *stream);
 
+/* ---- the surface format in front of the path: binary STL -----------------------------
+ * stlRead (subs.f90:17-121) reads the triangles and merges repeated vertices with a linear search per vertex:
+ * O(triangles x nodes), minutes for a million triangles.  lsf_stl_read does the same job with a hash and returns EXACTLY
+ * the reference's node numbering and connectivity: a vertex is merged with the FIRST earlier node whose three REAL*4
+ * coordinates differ by less than 1e-13 each (subs.f90:73-75), nodes created by the triangle being read are not yet
+ * searchable (the search bound nSurfNode is updated once per triangle, subs.f90:91; it starts at 3), numbering follows
+ * first occurrence.  Host-only (no device needed).
+ *   lsf_stl_read   parses `path`, keeps the result for the calling thread, returns the counts
+ *   lsf_stl_get    copies it out -- surfX(nSurfNode,3) REAL(8), surfElem(nSurfElem,3) INTEGER*4 1-based, both in
+ *                  Fortran order -- and releases it */
+int lsf_stl_read(const char *path, int *nSurfElem, int *nSurfNode);
+int lsf_stl_get(double *surfX, int32_t *surfElem);
+
 /* ---- one process, every GPU of the node (replaces the call site set3d.f90:308 for a host that wants them all) --------
  * lsf_reinit_multi has lsf_reinit's arguments plus a device list.  The field is split into dims[0] x dims[1] x dims[2]
  * blocks (dims NULL: 2x1x1, 2x2x1, 2x2x2 for 2, 4, 8 devices -- BASELINE configurations 4 and 5 -- otherwise the prime

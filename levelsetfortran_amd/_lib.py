@@ -73,6 +73,8 @@ SIGNATURES = {
     "lsf_snapshot": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int]),
     "lsf_sumsq_diff": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_double)]),
     "lsf_write_vti": (c_int, [ctypes.c_char_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p]),
+    "lsf_stl_read": (c_int, [ctypes.c_char_p, POINTER(c_int), POINTER(c_int)]),
+    "lsf_stl_get": (c_int, [c_void_p, c_void_p]),
     "lsf_box_reserve": (c_int, [c_void_p, ctypes.c_size_t]),
     "lsf_reinit_multi": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_int, c_void_p, c_int,
                                  c_void_p, POINTER(c_int), c_void_p, c_int]),

@@ -12,6 +12,8 @@
 !                                                        replaces the loop set3d.f90:218-268
 !   advectNodes(phi,phiSB,nx,ny,nz,dx,xLo,surfXX,nSurfNode,iter)
 !                                                        replaces set3d.f90:470-479 and :487-501
+!   stlRead(surfX,nSurfNode,surfElem,filename,nSurfElem,surfElemTag,surfOrder,nBndComp,nBndElem,bndNormal)
+!                                                        replaces subs.f90:17-121 (same list)
 !
 ! and reproduces what the reference prints around them (subs.f90:916,923,929 and
 ! set3d.f90:449,456,463) and its STOP on a NaN residual (subs.f90:926, set3d.f90:458).
@@ -53,7 +55,7 @@ USE, INTRINSIC :: iso_c_binding
 IMPLICIT NONE
 PRIVATE
 PUBLIC :: reinit, narrowBand, minmaxFlow, phi0Init, advectNodes, lsf_env_real, lsf_env_int, lsf_pad_cells
-PUBLIC :: writeVti, snapshotPhi, sumSqDiff, syncHost, syncHostInt
+PUBLIC :: writeVti, snapshotPhi, sumSqDiff, syncHost, syncHostInt, stlRead
 
 INTEGER(c_int), PARAMETER :: LSF_OK = 0, LSF_ERR_NAN = 1
 INTEGER(c_int), PARAMETER :: LSF_ORDER_JACOBI = 1, LSF_ARITH_STRICT = 256
@@ -150,6 +152,18 @@ INTERFACE
       REAL(c_double), VALUE :: dx
       INTEGER(c_int) :: rc
    END FUNCTION lsf_write_vti
+   FUNCTION lsf_stl_read(path,nSurfElem,nSurfNode) BIND(C,NAME='lsf_stl_read') RESULT(rc)
+      IMPORT :: c_int, c_char
+      CHARACTER(KIND=c_char), INTENT(IN) :: path(*)
+      INTEGER(c_int), INTENT(OUT) :: nSurfElem,nSurfNode
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_stl_read
+   FUNCTION lsf_stl_get(surfX,surfElem) BIND(C,NAME='lsf_stl_get') RESULT(rc)
+      IMPORT :: c_int, c_double
+      REAL(c_double), INTENT(OUT) :: surfX(*)
+      INTEGER(c_int), INTENT(OUT) :: surfElem(*)
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_stl_get
    FUNCTION lsf_last_error() BIND(C,NAME='lsf_last_error') RESULT(p)
       IMPORT :: c_ptr
       TYPE(c_ptr) :: p
@@ -514,5 +528,49 @@ INTEGER(c_int) :: rc
 rc = lsf_mirror_sync(c_loc(a))
 IF (rc /= LSF_OK) CALL lsf_fail('lsf_mirror_sync',rc)
 END SUBROUTINE syncHostInt
+
+!*************************************************************************************!
+! Read STL and Allocate  (same dummy arguments as subs.f90:17; host edit E11)
+! The reference merges repeated vertices with a linear search per vertex (quadratic);
+! lsf_stl_read returns the same nodes and connectivity from a hash (include/lsf.h).
+!*************************************************************************************!
+SUBROUTINE stlRead(surfX,nSurfNode,surfElem,filename,nSurfElem,surfElemTag,surfOrder,nBndComp,nBndElem,bndNormal)
+CHARACTER, INTENT(IN) :: filename*80
+INTEGER*4 nSurfNode,nSurfElem
+INTEGER*4,ALLOCATABLE,DIMENSION(:,:),INTENT(OUT) :: surfElem
+REAL,ALLOCATABLE,DIMENSION(:,:),INTENT(OUT) :: surfX
+INTEGER,ALLOCATABLE,DIMENSION(:),INTENT(OUT) :: surfElemTag,surfOrder
+REAL,ALLOCATABLE,DIMENSION(:,:),INTENT(OUT) :: bndNormal
+INTEGER,INTENT(OUT) :: nBndComp,nBndElem
+INTEGER(c_int) :: rc
+CHARACTER(KIND=c_char) :: cname(LEN_TRIM(filename)+1)
+INTEGER :: i
+
+PRINT*
+PRINT*, " Reading in .stl Mesh "
+PRINT*
+
+DO i = 1,LEN_TRIM(filename)
+   cname(i) = filename(i:i)
+END DO
+cname(LEN_TRIM(filename)+1) = c_null_char
+rc = lsf_stl_read(cname,nSurfElem,nSurfNode)
+IF (rc /= LSF_OK) CALL lsf_fail('lsf_stl_read',rc)
+ALLOCATE(surfElem(nSurfElem,3))
+ALLOCATE(surfX(nSurfNode,3))
+rc = lsf_stl_get(surfX,surfElem)
+IF (rc /= LSF_OK) CALL lsf_fail('lsf_stl_get',rc)
+
+! subs.f90:108-118 (the reference allocates bndNormal before it sets nBndComp; one component is what it means)
+nBndComp = 1
+nBndElem = 0
+ALLOCATE(surfOrder(nSurfElem))
+ALLOCATE(surfElemTag(nSurfElem))
+ALLOCATE(bndNormal(nBndComp,3))
+surfOrder = 1
+surfElemTag = 0
+bndNormal = 0.
+
+END SUBROUTINE stlRead
 
 END MODULE lsf_hip

@@ -158,3 +158,80 @@ def test_host_reads_the_namelist_and_pads_per_axis(tmp_path):
     p = subprocess.run(f"cd {tmp_path}; {_dropin_exe()} twoCube10.stl missing.nml", shell=True, env=env, text=True,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert "namelist file not found" in p.stdout and p.returncode != 0
+
+
+# ---------------------------------------------------------------------------------- lsf_stl_read (host only)
+def _stl_merge_literal(tris):
+    """subs.f90:64-93 restated literally (test tooling; quadratic): tris float32 (ntri, 3, 3) -> nodes, 1-based elem."""
+    ntri = tris.shape[0]
+    nodes = np.full((max(ntri * 5, 3), 3), 1.0e6, dtype=np.float32)
+    elem = np.zeros((ntri, 3), dtype=np.int32)
+    bound, k = 3, 0
+    for n in range(ntri):
+        for p in range(3):
+            v = tris[n, p]
+            share = 0
+            for kk in range(1, bound + 1):
+                d = np.abs(nodes[kk - 1] - v)  # REAL*4 arithmetic
+                if np.all(d.astype(np.float64) < 1.0e-13):
+                    share = kk
+                    break
+            if share:
+                elem[n, p] = share
+            else:
+                k += 1
+                nodes[k - 1] = v
+                elem[n, p] = k
+        bound = k
+    return nodes[:k].astype(np.float64), elem
+
+
+def _read_native(path):
+    import ctypes
+
+    from levelsetfortran_amd import _lib
+
+    lib = _lib.load()
+    nt, nn = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.lsf_stl_read(str(path).encode(), ctypes.byref(nt), ctypes.byref(nn)))
+    X = np.zeros((nn.value, 3), order="F")
+    E = np.zeros((nt.value, 3), dtype=np.int32, order="F")
+    _lib.check(lib.lsf_stl_get(X.ctypes.data, E.ctypes.data))
+    return X, E
+
+
+def test_native_stl_reader_reproduces_the_reference_merge(tmp_path):
+    """lsf_stl_read (hash) == the literal quadratic loop of stlRead on: the two sample surfaces, near-duplicate tiny
+    coordinates (the 1e-13 tolerance only bites below 2^-19), a vertex repeated INSIDE one triangle (not merged: the
+    search bound moves once per triangle) except in the first triangle (bound starts at 3), signed zeros."""
+    import stl_io
+
+    s = np.load(os.path.join(ROOT, "tests", "golden", "surfaces.npz"))
+    for tag in ("twocube10", "cube40"):
+        X0, E0 = s[tag + "_surfX"].astype(np.float64), s[tag + "_surfElem"]
+        stl_io.stl_write(tmp_path / (tag + ".stl"), X0, E0)
+        X, E = _read_native(tmp_path / (tag + ".stl"))
+        assert np.array_equal(X, X0) and np.array_equal(E, E0), tag
+    rng = np.random.default_rng(7)
+    pool = rng.integers(-3, 4, size=(40, 3)).astype(np.float32) * np.float32(0.25)
+    pool[5] = (3e-14, 0.5, -0.25)      # within 1e-13 of pool[6] in x although the bits differ
+    pool[6] = (-2e-14, 0.5, -0.25)
+    pool[7] = (1.5e-6, 1e-7, 0.0)      # just below 2^-19: distinct floats 1e-13 apart do not exist here
+    pool[8] = (np.float32(1.5e-6) + np.float32(2e-13), 1e-7, -0.0)
+    pool[9] = (np.nextafter(np.float32(2.0 ** -19), np.float32(0)), 0.0, 0.0)
+    pool[10] = (np.float32(2.0 ** -19), 0.0, 0.0)
+    idx = rng.integers(0, 40, size=(300, 3))
+    idx[0] = (3, 3, 4)       # first triangle repeats a vertex: merged (bound = 3 covers the slot just filled)
+    idx[1] = (11, 11, 12)    # a later triangle repeats a NEW vertex: two nodes
+    idx[2] = (11, 5, 6)
+    tris = pool[idx]
+    rec = np.zeros(300, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("pad", "<i2")]))
+    rec["v"] = tris
+    with open(tmp_path / "syn.stl", "wb") as f:
+        f.write(b"x".ljust(80, b" "))
+        f.write(np.int32(300).tobytes())
+        f.write(rec.tobytes())
+    Xl, El = _stl_merge_literal(tris)
+    X, E = _read_native(tmp_path / "syn.stl")
+    assert np.array_equal(E, El) and np.array_equal(X, Xl)
+    assert E[0, 0] == E[0, 1] and E[1, 0] != E[1, 1]  # the two quirks are in the data
