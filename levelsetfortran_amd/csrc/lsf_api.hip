@@ -2130,8 +2130,20 @@ int lsf_box_reserve(void* stream, size_t max_partials)
 
 extern "C" {
 
+// the lsf_multi_* calls visit other devices: the calling thread gets its own device back (HIP's and the library's)
+struct DeviceRestore {
+    int hip_dev = -1, lsf_dev = 0;
+    DeviceRestore() : lsf_dev(g_device) { if (hipGetDevice(&hip_dev) != hipSuccess) hip_dev = -1; (void)hipGetLastError(); }
+    ~DeviceRestore()
+    {
+        g_device = lsf_dev;
+        if (hip_dev >= 0) (void)hipSetDevice(hip_dev);
+    }
+};
+
 int lsf_multi_create(int nx, int ny, int nz, const int* devices, int ndev, const int dims_in[3], int f32, lsf_multi** out)
 {
+    DeviceRestore restore_;
     Trace trace_("lsf_multi_create");
     if (!out) return fail(LSF_ERR_INVALID, "NULL pointer");
     *out = nullptr;
@@ -2193,6 +2205,7 @@ int lsf_multi_create(int nx, int ny, int nz, const int* devices, int ndev, const
 
 int lsf_multi_destroy(lsf_multi* M)
 {
+    DeviceRestore restore_;
     if (!M) return LSF_OK;
     for (auto& R : M->r64) lsfm::free_rank(R);
     for (auto& R : M->r32) lsfm::free_rank(R);
@@ -2216,6 +2229,7 @@ int lsf_multi_block(const lsf_multi* M, int r, int g0[3], int ext[3], int own_lo
 
 int lsf_multi_scatter(lsf_multi* M, const void* host_phi)
 {
+    DeviceRestore restore_;
     if (!M || !host_phi) return fail(LSF_ERR_INVALID, "NULL pointer");
     std::string err;
     const int rc = M->f32 ? lsfm::scatter(M->r32, (const float*)host_phi, M->nx, M->ny, &err)
@@ -2226,6 +2240,7 @@ int lsf_multi_scatter(lsf_multi* M, const void* host_phi)
 
 int lsf_multi_upload_block(lsf_multi* M, int r, const void* d_block)
 {
+    DeviceRestore restore_;
     if (!M || !d_block || r < 0 || r >= M->ndev) return fail(LSF_ERR_INVALID, "bad block index / NULL pointer");
     HIPCHK(hipSetDevice(M->devs[r]));
     if (M->f32) HIPCHK(hipMemcpy(M->r32[r].buf[0], d_block, M->r32[r].g.npoints() * sizeof(float), hipMemcpyDeviceToDevice));
@@ -2236,6 +2251,7 @@ int lsf_multi_upload_block(lsf_multi* M, int r, const void* d_block)
 
 int lsf_multi_run(lsf_multi* M, int iter, double dx, double h, double tol, int mode, int* sweeps_done, double* rms_trace, int trace_cap)
 {
+    DeviceRestore restore_;
     Trace trace_("lsf_multi_run");
     if (!M) return fail(LSF_ERR_INVALID, "NULL pointer");
     if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
@@ -2262,6 +2278,7 @@ int lsf_multi_run(lsf_multi* M, int iter, double dx, double h, double tol, int m
 
 int lsf_multi_gather(lsf_multi* M, void* host_phi)
 {
+    DeviceRestore restore_;
     if (!M || !host_phi) return fail(LSF_ERR_INVALID, "NULL pointer");
     std::string err;
     const int rc = M->f32 ? lsfm::gather(M->r32, M->result_parity, (float*)host_phi, M->nx, M->ny, &err)

@@ -416,6 +416,33 @@ __global__ __launch_bounds__(256) void k_narrowband(const double* __restrict__ p
 // first iteration, which uses the caller's mask (nbmask != nullptr).  Wall points are never
 // updated (a band cell on a wall would read outside the array in the reference).
 // =============================================================================================
+// (i, j, k) of the linear point index p of a field with extents (sx, sy, .): 32-bit divisions when the field has fewer
+// than 2^31 points (a 64-bit division by a run-time value is ~150 instructions: two of them per point made the min/max
+// streaming kernels vector-bound at half the HBM rate)
+__device__ __forceinline__ void point_ijk(long p, int sx, int sy, long n, int& i, int& j, int& k)
+{
+    if (n <= 0x7fffffffL) {
+        const unsigned pu = (unsigned)p, q = pu / (unsigned)sx;
+        i = (int)(pu - q * (unsigned)sx);
+        k = (int)(q / (unsigned)sy);
+        j = (int)(q - (unsigned)k * (unsigned)sy);
+    } else {
+        const long q = p / sx;
+        i = (int)(p - q * sx);
+        k = (int)(q / sy);
+        j = (int)(q - (long)k * sy);
+    }
+}
+// ... and of p + d, given those of p and the decomposition (di, dj, dk) of the step d (di < sx, dj < sy)
+__device__ __forceinline__ void step_ijk(int& i, int& j, int& k, int di, int dj, int dk, int sx, int sy)
+{
+    i += di;
+    if (i >= sx) i -= sx, ++j;
+    j += dj;
+    if (j >= sy) j -= sy, ++k;
+    k += dk;
+}
+
 __device__ __forceinline__ bool in_band(const int32_t* nbmask, long g, double a, double dx)
 {
     return nbmask ? nbmask[g] == 1 : __builtin_fabs(a) < 4.1 * dx;
@@ -433,8 +460,10 @@ __global__ __launch_bounds__(256) void k_minmax_jacobi(const double* __restrict_
     const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1), n = sxy * (nz + 1);
     const double dxx = 1. / (dx * dx);
     double acc = 0.0;
-    for (long p = blockIdx.x * 256L + threadIdx.x; p < n; p += 256L * gridDim.x) {
-        const int i = p % sx, j = (p / sx) % (ny + 1), k = p / sxy;
+    int i, j, k, di, dj, dk;
+    point_ijk(blockIdx.x * 256L + threadIdx.x, nx + 1, ny + 1, n, i, j, k);
+    point_ijk(256L * gridDim.x, nx + 1, ny + 1, n, di, dj, dk); // the grid stride (below n whenever the loop repeats)
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < n; p += 256L * gridDim.x, step_ijk(i, j, k, di, dj, dk, nx + 1, ny + 1)) {
         const double c = A[p];
         double out = c;
         const bool interior = i >= 1 && i <= nx - 1 && j >= 1 && j <= ny - 1 && k >= 1 && k <= nz - 1;
@@ -498,6 +527,11 @@ __global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A,
     const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1), n = sxy * (nz + 1);
     const double dxx = 1. / (dx * dx);
     const long round = PASS == 0 ? (long)gridDim.x : 64L * gridDim.x;
+    // decomposition of the step of 256 points between a thread's consecutive points (rows shorter than 256 points: the
+    // step spans whole rows; planes smaller than 256 points are handled by step_ijk's carries as long as 256 < sx * sy,
+    // smaller fields take the division every time)
+    const bool tiny = sxy <= 256;
+    const int d256j = (int)(256 / sx), d256i = (int)(256 - (long)d256j * sx);
     for (long base = 0; base < nchunks; base += round) {
         unsigned long long m = 1ull;
         if (PASS != 0) {
@@ -521,11 +555,16 @@ __global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A,
             __syncthreads();
             double acc = 0.0;
             int mine = 0;
+            int i, j, k;
+            point_ijk(chunk * CH + threadIdx.x, nx + 1, ny + 1, n, i, j, k);
 #pragma unroll
             for (int t = 0; t < CH / 256; ++t) {
                 const long p = chunk * CH + t * 256 + threadIdx.x;
                 if (p >= n) break;
-                const int i = p % sx, j = (p / sx) % (ny + 1), k = p / sxy;
+                if (t > 0) {
+                    if (tiny) point_ijk(p, nx + 1, ny + 1, n, i, j, k);
+                    else step_ijk(i, j, k, d256i, d256j, 0, nx + 1, ny + 1);
+                }
                 const double c = A[p];
                 const bool interior = i >= 1 && i <= nx - 1 && j >= 1 && j <= ny - 1 && k >= 1 && k <= nz - 1;
                 const bool band = interior && in_band(nbmask, p, c, dx);
