@@ -915,8 +915,10 @@ __global__ __launch_bounds__(256) void k_pack(const T* __restrict__ f, T* __rest
 {
     const long n = (long)e0 * e1 * e2;
     const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
-    for (long p = blockIdx.x * 256L + threadIdx.x; p < n; p += 256L * gridDim.x) {
-        const int x = p % e0, y = (p / e0) % e1, z = p / ((long)e0 * e1);
+    int x, y, z, dxs, dys, dzs; // point_ijk / step_ijk: no 64-bit division per point (a slab is far below 2^31 points)
+    point_ijk(blockIdx.x * 256L + threadIdx.x, e0, e1, n, x, y, z);
+    point_ijk(256L * gridDim.x, e0, e1, n, dxs, dys, dzs);
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < n; p += 256L * gridDim.x, step_ijk(x, y, z, dxs, dys, dzs, e0, e1)) {
         const long g = (lo0 + x) + sx * (lo1 + y) + sxy * (lo2 + z);
         if (unpack) fw[g] = buf[p];
         else buf[p] = f[g];

@@ -173,4 +173,8 @@ def test_sumsq_bracket_equals_per_call_reduction():
     st = be.compute.cuda_stream
     assert lib.lsf_sumsq_end(st) == _lib.LSF_ERR_INVALID
     assert lib.lsf_sumsq_begin(st) == _lib.LSF_OK and lib.lsf_sumsq_begin(st) == _lib.LSF_ERR_INVALID
+    # the per-stream buffer of partial sums can be sized up front (then the box calls neither allocate nor synchronise) --
+    # but not inside a bracket
+    assert lib.lsf_box_reserve(st, 1 << 18) == _lib.LSF_ERR_INVALID
     assert lib.lsf_sumsq_end(st) == _lib.LSF_OK
+    assert lib.lsf_box_reserve(st, 1 << 18) == _lib.LSF_OK
