@@ -384,8 +384,17 @@ struct JacPlan {
     int kind = 0; // 0 per-cell kernel, 1 per-cell THINX, 2 shared-interface kernel
     dim3 grid;
     int wx = 1, by = 4, nbx = 0, nby = 0, nbz = 0;
+    int kc = JAC_KC; // planes a block marches: JAC_KC, halved while a thin region (a rim of a decomposed sweep) would leave CUs idle
     long nparts = 0; // partial sums the launch writes
 };
+// planes per block: JAC_KC (= F32_KC) amortises the six-plane window a block loads before its first cell; a region with few
+// block columns (the 3-cell rims of a decomposed sweep) gets shorter marches until the launch has ~8 blocks per CU
+static int jacobi_kc(long columns, int cz)
+{
+    int kc = JAC_KC;
+    while (kc > 4 && columns * cdiv(cz, kc) < 2048) kc >>= 1;
+    return kc;
+}
 JacPlan jacobi_plan(const int lo[3], const int hi[3], bool strict)
 {
     JacPlan p;
@@ -397,7 +406,9 @@ JacPlan jacobi_plan(const int lo[3], const int hi[3], bool strict)
     if (env && !off && sscanf(env, "%dx%d", &fwx, &fby) != 2) fwx = fby = 0;
     if (strict || thinx || off) {
         p.kind = thinx ? 1 : 0;
-        p.grid = thinx ? dim3(cdiv(cy, JAC_BX), cdiv(cx, JAC_BY), cdiv(cz, JAC_KC)) : dim3(cdiv(cx, JAC_BX), cdiv(cy, JAC_BY), cdiv(cz, JAC_KC));
+        const long cols = thinx ? (long)cdiv(cy, JAC_BX) * cdiv(cx, JAC_BY) : (long)cdiv(cx, JAC_BX) * cdiv(cy, JAC_BY);
+        p.kc = jacobi_kc(cols, cz);
+        p.grid = thinx ? dim3(cdiv(cy, JAC_BX), cdiv(cx, JAC_BY), cdiv(cz, p.kc)) : dim3(cdiv(cx, JAC_BX), cdiv(cy, JAC_BY), cdiv(cz, p.kc));
         p.nparts = (long)p.grid.x * p.grid.y * p.grid.z;
         return p;
     }
@@ -411,7 +422,8 @@ JacPlan jacobi_plan(const int lo[3], const int hi[3], bool strict)
     static const int shapes[][2] = {{1, 4}, {2, 2}, {4, 1}, {4, 2}, {8, 1}};
     for (auto& sh : shapes)
         if (sh[0] == fwx && sh[1] == fby) p.wx = fwx, p.by = fby;
-    p.nbx = cdiv(cx, 64 * p.wx - 1), p.nby = cdiv(cy, p.by), p.nbz = cdiv(cz, JAC_KC);
+    p.nbx = cdiv(cx, 64 * p.wx - 1), p.nby = cdiv(cy, p.by);
+    p.kc = jacobi_kc((long)p.nbx * p.nby, cz), p.nbz = cdiv(cz, p.kc);
     const long nblk = (long)p.nbx * p.nby * p.nbz;
     p.nparts = (nblk + 7) / 8 * 8; // the launch is padded to a multiple of the 8 XCDs (k_reinit_jacobi_sh)
     p.grid = dim3((unsigned)p.nparts);
@@ -422,10 +434,10 @@ void jacobi_launch(const JacPlan& p, bool strict, const double* A, double* B, co
 {
 #define LSF_JAC_OLD(ST_, TX_)                                                                                               \
     hipLaunchKernelGGL((k_reinit_jacobi<ST_, TX_>), p.grid, dim3(JAC_BX, JAC_BY), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], \
-                       hi[0], hi[1], hi[2], dx, h, part, done)
+                       hi[0], hi[1], hi[2], dx, h, part, done, p.kc)
 #define LSF_JAC_SH(WX_, BY_)                                                                                                   \
     hipLaunchKernelGGL((k_reinit_jacobi_sh<WX_, BY_>), p.grid, dim3(64 * WX_ * BY_), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], \
-                       hi[0], hi[1], hi[2], dx, h, part, done, p.nbx, p.nby, p.nbz)
+                       hi[0], hi[1], hi[2], dx, h, part, done, p.nbx, p.nby, p.nbz, p.kc)
     if (p.kind == 2) {
         const int sh = p.wx * 16 + p.by;
         if (sh == 0x14) LSF_JAC_SH(1, 4);
@@ -454,7 +466,9 @@ JacPlan jacobi_plan_f32(const int lo[3], const int hi[3])
     const bool off = env && env[0] == '0' && env[1] == 0;
     if (thinx || off) {
         p.kind = thinx ? 1 : 0;
-        p.grid = thinx ? dim3(cdiv(npair, F32_BX), cdiv(cx, F32_BY), cdiv(cz, F32_KC)) : dim3(cdiv(cx, F32_BX), cdiv(npair, F32_BY), cdiv(cz, F32_KC));
+        const long cols = thinx ? (long)cdiv(npair, F32_BX) * cdiv(cx, F32_BY) : (long)cdiv(cx, F32_BX) * cdiv(npair, F32_BY);
+        p.kc = jacobi_kc(cols, cz);
+        p.grid = thinx ? dim3(cdiv(npair, F32_BX), cdiv(cx, F32_BY), cdiv(cz, p.kc)) : dim3(cdiv(cx, F32_BX), cdiv(npair, F32_BY), cdiv(cz, p.kc));
         p.nparts = (long)p.grid.x * p.grid.y * p.grid.z;
         return p;
     }
@@ -467,7 +481,8 @@ JacPlan jacobi_plan_f32(const int lo[3], const int hi[3])
     int fwx = 0, fby = 0;
     if (env && sscanf(env, "%dx%d", &fwx, &fby) >= 1 && (fwx == 1 || fwx == 2 || fwx == 4 || fwx == 8)) p.wx = fwx;
     p.by = 1;
-    p.nbx = cdiv(cx, 64 * p.wx - 1), p.nby = npair, p.nbz = cdiv(cz, F32_KC);
+    p.nbx = cdiv(cx, 64 * p.wx - 1), p.nby = npair;
+    p.kc = jacobi_kc((long)p.nbx * p.nby, cz), p.nbz = cdiv(cz, p.kc);
     p.nparts = ((long)p.nbx * p.nby * p.nbz + 7) / 8 * 8;
     p.grid = dim3((unsigned)p.nparts);
     return p;
@@ -477,7 +492,7 @@ void jacobi_launch_f32(const JacPlan& p, const float* A, float* B, const float* 
 {
 #define LSF_F32_SH(WX_)                                                                                                   \
     hipLaunchKernelGGL((k_reinit_jacobi_f32_sh<WX_>), p.grid, dim3(64 * WX_), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], hi[0], \
-                       hi[1], hi[2], (float)dx, (float)h, part, done, xwall, p.nbx, p.nby, p.nbz)
+                       hi[1], hi[2], (float)dx, (float)h, part, done, xwall, p.nbx, p.nby, p.nbz, p.kc)
     if (p.kind == 2) {
         if (p.wx == 1) LSF_F32_SH(1);
         else if (p.wx == 2) LSF_F32_SH(2);
@@ -485,10 +500,10 @@ void jacobi_launch_f32(const JacPlan& p, const float* A, float* B, const float* 
         else LSF_F32_SH(8);
     } else if (p.kind == 1)
         hipLaunchKernelGGL((k_reinit_jacobi_f32<true>), p.grid, dim3(F32_BX, F32_BY), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], hi[0],
-                           hi[1], hi[2], (float)dx, (float)h, part, done, xwall);
+                           hi[1], hi[2], (float)dx, (float)h, part, done, xwall, p.kc);
     else
         hipLaunchKernelGGL((k_reinit_jacobi_f32<false>), p.grid, dim3(F32_BX, F32_BY), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], hi[0],
-                           hi[1], hi[2], (float)dx, (float)h, part, done, xwall);
+                           hi[1], hi[2], (float)dx, (float)h, part, done, xwall, p.kc);
 #undef LSF_F32_SH
 }
 

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const floa
                                                                       int lo1, int lo2, int hi0, int hi1, int hi2,
                                                                       float dx, float h,
                                                                       double* __restrict__ partials,
-                                                                      const int* __restrict__ done, int xwall)
+                                                                      const int* __restrict__ done, int xwall, int kc)
 {
     __shared__ double red[F32_BX * F32_BY / 64];
     if (done && *done) return;
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const floa
     const int li = THINX ? lo0 + (int)(blockIdx.y * F32_BY + threadIdx.y) : lo0 + (int)(blockIdx.x * F32_BX + threadIdx.x);
     const int lj = THINX ? lo1 + 2 * (int)(blockIdx.x * F32_BX + threadIdx.x)
                          : lo1 + 2 * (int)(blockIdx.y * F32_BY + threadIdx.y);
-    const int k0 = lo2 + blockIdx.z * F32_KC;
-    const int k1 = min(k0 + F32_KC, hi2);
+    const int k0 = lo2 + blockIdx.z * kc;
+    const int k1 = min(k0 + kc, hi2);
     const int sx = bx.lx;
     const long sxy = (long)bx.lx * bx.ly;
     float acc = 0.f;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * WX) void k_reinit_jacobi_f32_sh(const float* _
                                                                   const float* __restrict__ phiS, Box bx, int lo0, int lo1, int lo2,
                                                                   int hi0, int hi1, int hi2, float dx, float h,
                                                                   double* __restrict__ partials, const int* __restrict__ done,
-                                                                  int xwall, int nbx, int nby, int nbz)
+                                                                  int xwall, int nbx, int nby, int nbz, int kc)
 {
     __shared__ double red[WX];
     __shared__ f2 xch[2][WX];
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64 * WX) void k_reinit_jacobi_f32_sh(const float* _
         const int xl = 64 * wx + lane;
         const int li = lo0 - 1 + bxi * (64 * WX - 1) + xl;
         const int lj = lo1 + 2 * byi;
-        const int k0 = lo2 + bzi * F32_KC, k1 = min(k0 + F32_KC, hi2);
+        const int k0 = lo2 + bzi * kc, k1 = min(k0 + kc, hi2);
         const int sx = bx.lx;
         const long sxy = (long)bx.lx * bx.ly;
         const bool cell = xl >= 1 && li < hi0;

@@ -55,14 +55,14 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi
                                                                    int lo0, int lo1, int lo2, int hi0, int hi1,
                                                                    int hi2, double dx, double h,
                                                                    double* __restrict__ partials,
-                                                                   const int* __restrict__ done)
+                                                                   const int* __restrict__ done, int kc)
 {
     __shared__ double red[JAC_BX * JAC_BY / 64];
     if (done && *done) return;
     const int li = THINX ? lo0 + (int)(blockIdx.y * JAC_BY + threadIdx.y) : lo0 + (int)(blockIdx.x * JAC_BX + threadIdx.x);
     const int lj = THINX ? lo1 + (int)(blockIdx.x * JAC_BX + threadIdx.x) : lo1 + (int)(blockIdx.y * JAC_BY + threadIdx.y);
-    const int k0 = lo2 + blockIdx.z * JAC_KC;
-    const int k1 = min(k0 + JAC_KC, hi2);
+    const int k0 = lo2 + blockIdx.z * kc; // kc: planes a block marches (JacPlan: JAC_KC, fewer for thin regions)
+    const int k1 = min(k0 + kc, hi2);
     const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
     double acc = 0.0;
     if (li < hi0 && lj < hi1) {
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * WX * BY) __attribute__((amdgpu_waves_per_eu(5)
                                                                      const double* __restrict__ phiS, Box bx, int lo0, int lo1,
                                                                      int lo2, int hi0, int hi1, int hi2, double dx, double h,
                                                                      double* __restrict__ partials, const int* __restrict__ done,
-                                                                     int nbx, int nby, int nbz)
+                                                                     int nbx, int nby, int nbz, int kc)
 {
     constexpr int NW = WX * BY;
     __shared__ double red[NW];
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * WX * BY) __attribute__((amdgpu_waves_per_eu(5)
         const int xl = 64 * wx + lane;                         // lane position inside the block, 0 = helper
         const int li = lo0 - 1 + bxi * (64 * WX - 1) + xl;     // local x index of the lane's point (>= 0: lo0 >= 1)
         const int lj = lo1 + byi * BY + ry;
-        const int k0 = lo2 + bzi * JAC_KC, k1 = min(k0 + JAC_KC, hi2);
+        const int k0 = lo2 + bzi * kc, k1 = min(k0 + kc, hi2);
         const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
         const bool cell = xl >= 1 && li < hi0 && lj < hi1;     // the lane owns a cell of this launch
         const int gi = li + bx.gx0, gj = lj + bx.gy0;
