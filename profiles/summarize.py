@@ -47,16 +47,17 @@ def gs_kernel_name():
     return "k_reinit_gs_box"
 
 
-def jacobi_kernel_name():
-    f = one("pmc_FETCH_SIZE_jacobi/**/*counter_collection.csv")
+def jacobi_kernel_name(mode="jacobi"):
+    f = one(f"pmc_FETCH_SIZE_{mode}/**/*counter_collection.csv")
+    sh, plain = ("k_reinit_jacobi_f32_sh", "k_reinit_jacobi_f32") if mode == "f32" else ("k_reinit_jacobi_sh", "k_reinit_jacobi")
     if f:
         for r in csv.DictReader(open(f)):
-            if "k_reinit_jacobi_sh" in r["Kernel_Name"]:
-                return "k_reinit_jacobi_sh"
-    return "k_reinit_jacobi"
+            if sh in r["Kernel_Name"]:
+                return sh
+    return plain
 
 
-for mode, kern in (("gs", gs_kernel_name()), ("jacobi", jacobi_kernel_name()), ("f32", "k_reinit_jacobi_f32"), ("mm", "k_minmax_fp")):
+for mode, kern in (("gs", gs_kernel_name()), ("jacobi", jacobi_kernel_name()), ("f32", jacobi_kernel_name("f32")), ("mm", "k_minmax_fp")):
     entry = {}
     bytes_per_cell = 12.0 if mode == "f32" else 24.0
     sweeps = 17.0 if mode == "mm" else SWEEPS  # mm_time.py: 1 + 16 iterations
@@ -101,7 +102,7 @@ if "FETCH_SIZE" in cal:
     # use the measured ratio instead of the blanket x2 for the committed traffic numbers
     for kern in list(traffic):
         e = res[kern]["per_sweep"]
-        cc = cal32 if (kern.endswith("_f32") and "FETCH_SIZE" in cal32) else cal
+        cc = cal32 if ("_f32" in kern and "FETCH_SIZE" in cal32) else cal
         e["fetch_calibrated"] = e["fetch_raw"] / cc["FETCH_SIZE"]["ratio"]
         e["hbm_calibrated"] = e["fetch_calibrated"] + e["write"] / cc.get("WRITE_SIZE", {"ratio": 1.0})["ratio"]
         traffic[kern] = {"512": e["hbm_calibrated"]}
