@@ -141,14 +141,16 @@ inline bool make_geom(int rank, const int dims[3], const int n[3], Geom* g, std:
 
 inline void default_dims(int world, int dims[3])
 {
-    // BASELINE.json: 4 GPUs -> 2x2x1, 8 GPUs -> 2x2x2; otherwise prime factors dealt to x, y, z in turn
+    // BASELINE.json: 4 GPUs -> a 2x2x1 decomposition, 8 GPUs -> 2x2x2.  The unit-stride axis x is cut last (2 devices: z;
+    // 4: y and z): slabs of whole rows, rims the sweep kernel covers with full wavefronts.  Otherwise the prime factors
+    // are dealt to z, y, x in turn (the same rule as distributed.py default_dims).
     dims[0] = dims[1] = dims[2] = 1;
-    if (world == 2) { dims[0] = 2; return; }
-    if (world == 4) { dims[0] = dims[1] = 2; return; }
+    if (world == 2) { dims[2] = 2; return; }
+    if (world == 4) { dims[1] = dims[2] = 2; return; }
     if (world == 8) { dims[0] = dims[1] = dims[2] = 2; return; }
     int nn = world, a = 0;
     for (int p = 2; p <= world; ++p)
-        while (nn % p == 0) dims[a % 3] *= p, nn /= p, ++a;
+        while (nn % p == 0) dims[2 - a % 3] *= p, nn /= p, ++a;
 }
 
 // reusable barrier of the worker threads (they only enqueue between two barriers, so a spin is fine)

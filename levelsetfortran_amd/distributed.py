@@ -35,15 +35,18 @@ HALO = 3  # WENO5 reaches +-3 (subs.f90:509-530)
 # decomposition (pure index arithmetic)
 # ------------------------------------------------------------------------------------------------
 def default_dims(world: int) -> Tuple[int, int, int]:
-    """BASELINE.json configs: 4 GPUs -> 2x2x1, 8 GPUs -> 2x2x2; otherwise factor x, then y, then z."""
-    table = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
+    """(Px, Py, Pz).  BASELINE.json configs: 4 GPUs -> a 2x2x1 decomposition, 8 GPUs -> 2x2x2.  The unit-stride axis x is
+    cut LAST (2 ranks: z; 4 ranks: y and z): a cut across z or y leaves face slabs made of whole rows (contiguous packs,
+    rims the sweep kernel covers with full wavefronts), a cut across x makes 3-cell-wide rims and 24-byte pack runs.
+    Otherwise the prime factors are dealt to z, y, x in turn."""
+    table = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}
     if world in table:
         return table[world]
     dims = [1, 1, 1]
     n, a = world, 0
     for p in range(2, world + 1):
         while n % p == 0:
-            dims[a % 3] *= p
+            dims[2 - a % 3] *= p
             n //= p
             a += 1
     return tuple(dims)
@@ -392,8 +395,8 @@ class DistributedReinit:
 def bench_decomposed(global_pts, K: int, W: int, device, arith: str = "fast", dtype: str = "f64", shared_gpu: bool = False,
                      dims=None):
     """K timed sweeps (after W) of the block-decomposed Jacobi sweep on a grid of global_pts = (Nx, Ny, Nz) POINTS split
-    over the ranks of the job (default_dims: 2x2x1 on 4, 2x2x2 on 8 ranks; blocks need not be cubic: BASELINE
-    configuration 4 is 1024^3 on 2x2x1 = 512 x 512 x 1024 per rank).  Barrier + synchronize on both sides; the caller takes
+    over the ranks of the job (default_dims: 2x2x1 on 4 ranks with x the uncut axis, 2x2x2 on 8; blocks need not be cubic:
+    BASELINE configuration 4 is 1024^3 on 4 ranks = 1024 x 512 x 512 per rank).  Barrier + synchronize on both sides; the caller takes
     the max over ranks."""
     import time
 

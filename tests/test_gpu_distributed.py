@@ -113,15 +113,16 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     ent = d["decomposed"]["entries"]
     weak = [e for e in ent if e["scaling"] == "weak"]
     strong = [e for e in ent if e["scaling"] == "strong"]
-    assert len(weak) == 1 and weak[0]["value"] > 0 and weak[0]["global_grid"] == [192, 96, 96] and weak[0]["dims"] == [2, 1, 1]
-    # fixed global grid split over the ranks: non-cubic local blocks (48 owned + 3 ghost points along x)
-    assert len(strong) == 1 and strong[0]["global_grid"] == [96, 96, 96] and strong[0]["local_block"] == [51, 96, 96]
+    assert len(weak) == 1 and weak[0]["value"] > 0 and weak[0]["global_grid"] == [96, 96, 192] and weak[0]["dims"] == [1, 1, 2]
+    # fixed global grid split over the ranks: non-cubic local blocks (48 owned + 3 ghost points along z, the axis two
+    # ranks cut: the unit-stride axis x is cut last)
+    assert len(strong) == 1 and strong[0]["global_grid"] == [96, 96, 96] and strong[0]["local_block"] == [96, 96, 51]
     assert strong[0]["value"] > 0 and "error" not in d["decomposed"]
 
 
 def test_bench_strong_scaling_headline_on_one_gpu():
     """bench.py --mode jacobi --global G: the decomposed sweep on a FIXED global grid is the headline ("strong"); BASELINE
-    configuration 4 is `--gpus 4 --global 1024`, rehearsed here as 4 ranks sharing the GPU on a 64^3 grid (2x2x1)."""
+    configuration 4 is `--gpus 4 --global 1024`, rehearsed here as 4 ranks sharing the GPU on a 64^3 grid (2x2x1, x uncut)."""
     import json
     import subprocess
 

@@ -101,7 +101,8 @@ def test_multi_resident_pieces_and_refusals(lsf):
         lo, hi = (ctypes.c_int * 3)(), (ctypes.c_int * 3)()
         dev = ctypes.c_int(-1)
         _lib.check(lib.lsf_multi_block(M, 3, g0, ext, lo, hi, ctypes.byref(dev)))
-        assert dev.value == 0 and list(lo) == [25, 20, 0] and list(hi) == [50, 40, 44] and list(g0) == [22, 17, 0]
+        # 4 blocks: 1 x 2 x 2 (x, the unit-stride axis, is cut last); block 3 = (0, 1, 1)
+        assert dev.value == 0 and list(lo) == [0, 20, 22] and list(hi) == [50, 40, 44] and list(g0) == [0, 17, 19]
         got = phi0.copy(order="F")
         _lib.check(lib.lsf_multi_scatter(M, got.ctypes.data))
         done = ctypes.c_int(0)

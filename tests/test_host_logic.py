@@ -20,7 +20,9 @@ def test_split_points_covers_and_balances():
 
 
 def test_default_dims_follow_baseline_configs():
-    assert D.default_dims(4) == (2, 2, 1) and D.default_dims(8) == (2, 2, 2) and D.default_dims(1) == (1, 1, 1)
+    # a 2x2x1 decomposition on 4 ranks, 2x2x2 on 8; the unit-stride axis x is the one cut last
+    assert D.default_dims(4) == (1, 2, 2) and D.default_dims(8) == (2, 2, 2) and D.default_dims(1) == (1, 1, 1)
+    assert D.default_dims(2) == (1, 1, 2) and D.default_dims(6) == (1, 3, 2) and D.default_dims(16) == (2, 2, 4)
     for w in (2, 3, 6, 12):
         assert np.prod(D.default_dims(w)) == w
 
