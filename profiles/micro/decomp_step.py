@@ -18,7 +18,10 @@ for dtype in ('f64', 'f32'):
             for (peer, _s, r_box, _a, _sd), rb in zip(dr.plan, dr.recv_bufs): be.unpack(f, b, r_box, rb, be.comm)
     dr.exchange = fake_exchange
     n = b.npoints_local()
-    a = (torch.rand(n, dtype=torch.float64, device=dev) * 0.1).to(be.dtype)
+    # the bench's own field (smooth two-sphere distance), not noise: these kernels run power-limited, and a field of random
+    # mantissas costs 5 % (fp64) to 13 % (fp32) more time for the same arithmetic (profiles/micro/core_probe.py)
+    rng = tuple((g, g + e) for g, e in zip(b.g0, b.ext))
+    a = fields.two_sphere_phi0_device((N, N, N), dev, ranges=rng)[0].to(be.dtype)
     bufs = [a, a.clone()]; ps = a.clone()
     def steps(k):
         for s in range(k):
@@ -29,7 +32,7 @@ for dtype in ('f64', 'f32'):
     # the single-domain sweep of the same number of owned cells
     import levelsetfortran_amd as lsf
     M = 512
-    f = (torch.rand(M ** 3, dtype=torch.float64, device=dev) * 0.1).to(be.dtype)
+    f = fields.two_sphere_phi0_device((M, M, M), dev)[0].to(be.dtype)
     lsf.reinit(f, None, None, M - 1, M - 1, M - 1, 3, dx, h, tol=0.0, order='jacobi'); torch.cuda.synchronize()
     t0 = time.perf_counter(); lsf.reinit(f, None, None, M - 1, M - 1, M - 1, 15, dx, h, tol=0.0, order='jacobi'); torch.cuda.synchronize()
     ms1 = (time.perf_counter() - t0) / 16 * 1e3
