@@ -357,8 +357,8 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
         axis_pair<STRICT>(q, weno_ok, yquirk, dx, floor2, dm, dp);
         const double gg = axis_godunov<STRICT>(q[3], dm, dp);
         const double gX = gg, gY = dpp_mov<0x101>(gg), gZ = dpp_mov<0x102>(gg); // row_shl:1, row_shl:2
-        const double newv = finish_update<STRICT>(q[3], gX, gY, gZ, pS, dx, inv_dx, h);
-        if (active && axis == 0) {
+        if (active && axis == 0) { // only the x lane of a cell needs the tail (|grad|, sign, Euler step)
+            const double newv = finish_update<STRICT>(q[3], gX, gY, gZ, pS, dx, inv_dx, h);
             lds[row_core + t] = newv;
             const double dlt = newv - q[3];
             acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
