@@ -230,13 +230,15 @@ int lsf_stl_get(double *surfX, int32_t *surfElem);
 /* ---- one process, every GPU of the node (replaces the call site set3d.f90:308 for a host that wants them all) --------
  * lsf_reinit_multi has lsf_reinit's arguments plus a device list.  The field is split into dims[0] x dims[1] x dims[2]
  * blocks (dims NULL: 1x1x2, 1x2x2, 2x2x2 for 2, 4, 8 devices -- BASELINE configurations 4 and 5; x, the unit-stride
- * axis, is cut last -- otherwise the prime factors dealt to z, y, x in turn), one block per entry of `devices`; the library runs the Jacobi sweep (LSF_ORDER_JACOBI only:
- * the reference's in-place ordering does not shard) with 3-cell face halos copied peer to peer
+ * axis, is cut last -- otherwise the prime factors dealt to z, y, x in turn), one block per entry of `devices`; the
+ * library runs the Jacobi sweep (LSF_ORDER_JACOBI only: the reference's in-place ordering does not shard, SURVEY.md
+ * section 8e) with 3-cell face halos copied peer to peer
  * over xGMI on a communication stream per device while the interior cells are updated on the compute stream, and one
  * host thread per device that only enqueues; the RMS of sweep s is judged while sweep s + 1 runs.  The result is bit-
  * identical to lsf_reinit with the same mode on one device.  `devices` may name a device more than once (several blocks
- * share it): that is how the path is tested on a one-GPU machine.  The lsf_multi_* calls are the same thing in pieces,
- * for callers that keep the blocks resident (bench.py). */
+ * share it): that is how the path is tested on a one-GPU machine.  `phi` is a HOST array; a device twin of it left by
+ * an earlier seam call (lsf_mirror) is brought home first and dropped afterwards.  The lsf_multi_* calls are the same
+ * thing in pieces, for callers that keep the blocks resident (bench.py). */
 typedef struct lsf_multi lsf_multi;
 int lsf_reinit_multi(double *phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,
                      const int *devices, int ndev, const int dims[3], int *sweeps_done, double *rms_trace, int trace_cap);

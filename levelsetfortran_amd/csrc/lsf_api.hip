@@ -2306,8 +2306,21 @@ static int reinit_multi_any(void* phi, int f32, int nx, int ny, int nz, int iter
 {
     if (!phi) return fail(LSF_ERR_INVALID, "phi is NULL");
     lsf_multi* M = nullptr;
-    int rc = lsf_multi_create(nx, ny, nz, devices, ndev, dims, f32, &M);
+    int rc = LSF_OK;
+    // The blocks are scattered from and gathered into the HOST array.  If an earlier seam call left the latest content of
+    // this array in its device twin (lsf_mirror LAZY), bring it home first; afterwards the host copy is the newer one, so
+    // the twin no longer counts (the next seam call uploads again).
+    Twin* tw = nullptr;
+    if (ensure_device() == LSF_OK) {
+        Slot sl = S_HPHI;
+        if (twin_of(ctx(), phi, 0, &tw, &sl) && tw->host_stale) {
+            HIPCHK(hipMemcpy(phi, ctx().slot[sl].p, tw->bytes, hipMemcpyDeviceToHost));
+            tw->host_stale = false;
+        }
+    }
+    rc = lsf_multi_create(nx, ny, nz, devices, ndev, dims, f32, &M);
     if (rc) return rc;
+    if (tw) tw->current = false;
     rc = lsf_multi_scatter(M, phi);
     if (!rc) rc = lsf_multi_run(M, iter, dx, h, tol, mode, sweeps_done, rms_trace, trace_cap);
     if (rc == LSF_OK || rc == LSF_ERR_NAN) {

@@ -39,6 +39,8 @@
 !     reinit2_iter = 2000       ! cap of reinit #2                     (set3d.f90:576)
 !     order = 'gs'              ! 'gs' (the reference's raster order, exact) | 'jacobi'
 !     arith = 'fast'            ! 'fast' | 'strict' (bit-identical to the reference)
+!     devices = 0, 1, 2, 3      ! order = 'jacobi' only: reinit runs block-decomposed on these GPUs, one block each
+!                               !   (lsf_reinit_multi; a device may be listed more than once); unset: one GPU
 !     resident = 2              ! 0: every seam copies its arrays in and out (default of the C ABI)
 !                               ! 1: skip the host-to-device copy of an array the last seam left on the device
 !                               ! 2: (default here) ... and leave results on the device until the host needs them:
@@ -47,7 +49,7 @@
 !
 ! Every entry is optional; environment variables of the same meaning (LSF_DX, LSF_DD,
 ! LSF_DD_{X,Y,Z}_{LO,HI}, LSF_REINIT_ITER, LSF_MINMAX_ITER, LSF_REINIT2_ITER, LSF_ORDER,
-! LSF_ARITH, LSF_RESIDENT) override the namelist.
+! LSF_ARITH, LSF_RESIDENT, LSF_DEVICES="0,1,2,3") override the namelist.
 !*************************************************************************************!
 MODULE lsf_hip
 
@@ -67,6 +69,7 @@ INTEGER, SAVE :: nml_dd = -1, nml_dd_lo(3) = -1, nml_dd_hi(3) = -1
 INTEGER, SAVE :: nml_reinit_iter = -1, nml_minmax_iter = -1, nml_reinit2_iter = -1
 CHARACTER(LEN=16), SAVE :: nml_order = ' ', nml_arith = ' '
 INTEGER, SAVE :: nml_resident = -1
+INTEGER(c_int), SAVE :: nml_devices(16) = -1
 LOGICAL, SAVE :: mirror_set = .FALSE.
 
 INTERFACE
@@ -81,6 +84,19 @@ INTERFACE
       REAL(c_double), INTENT(OUT) :: rms_trace(*)
       INTEGER(c_int) :: rc
    END FUNCTION lsf_reinit
+   ! int lsf_reinit_multi(double*,int,int,int,int,double,double,double,int,const int*,int,const int[3],int*,double*,int)
+   FUNCTION lsf_reinit_multi(phi,nx,ny,nz,iter,dx,h,tol,mode,devices,ndev,dims,sweeps_done,rms_trace,trace_cap) &
+            BIND(C,NAME='lsf_reinit_multi') RESULT(rc)
+      IMPORT :: c_int, c_double, c_ptr
+      REAL(c_double), INTENT(INOUT) :: phi(*)
+      INTEGER(c_int), VALUE :: nx,ny,nz,iter,mode,ndev,trace_cap
+      REAL(c_double), VALUE :: dx,h,tol
+      INTEGER(c_int), INTENT(IN) :: devices(*)
+      TYPE(c_ptr), VALUE :: dims            ! NULL: the library's default decomposition
+      INTEGER(c_int), INTENT(OUT) :: sweeps_done
+      REAL(c_double), INTENT(OUT) :: rms_trace(*)
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_reinit_multi
    FUNCTION lsf_minmax(phi,phiNB,phiSB,nx,ny,nz,iter,dx,h1,tol,mode,iters_done,rms_trace,trace_cap) &
             BIND(C,NAME='lsf_minmax') RESULT(rc)
       IMPORT :: c_int, c_double
@@ -201,11 +217,11 @@ END FUNCTION lsf_mode
 !*************************************************************************************!
 SUBROUTINE lsf_load_inputs()
 REAL :: dx
-INTEGER :: dd,dd_lo(3),dd_hi(3),reinit_iter,minmax_iter,reinit2_iter,ios,u,resident
+INTEGER :: dd,dd_lo(3),dd_hi(3),reinit_iter,minmax_iter,reinit2_iter,ios,u,resident,devices(16)
 CHARACTER(LEN=16) :: order,arith
 CHARACTER(LEN=1024) :: path
 LOGICAL :: there
-NAMELIST /lsf_inputs/ dx,dd,dd_lo,dd_hi,reinit_iter,minmax_iter,reinit2_iter,order,arith,resident
+NAMELIST /lsf_inputs/ dx,dd,dd_lo,dd_hi,reinit_iter,minmax_iter,reinit2_iter,order,arith,resident,devices
 IF (nml_loaded) RETURN
 nml_loaded = .TRUE.
 path = ' '
@@ -221,7 +237,7 @@ IF (.NOT. there) THEN
 END IF
 dx = nml_dx; dd = nml_dd; dd_lo = nml_dd_lo; dd_hi = nml_dd_hi
 reinit_iter = nml_reinit_iter; minmax_iter = nml_minmax_iter; reinit2_iter = nml_reinit2_iter
-order = nml_order; arith = nml_arith; resident = nml_resident
+order = nml_order; arith = nml_arith; resident = nml_resident; devices = nml_devices
 u = 47
 OPEN(UNIT=u,FILE=TRIM(path),STATUS='old',ACTION='read',IOSTAT=ios)
 IF (ios == 0) READ(u,NML=lsf_inputs,IOSTAT=ios)
@@ -232,9 +248,33 @@ END IF
 CLOSE(u)
 nml_dx = dx; nml_dd = dd; nml_dd_lo = dd_lo; nml_dd_hi = dd_hi
 nml_reinit_iter = reinit_iter; nml_minmax_iter = minmax_iter; nml_reinit2_iter = reinit2_iter
-nml_order = order; nml_arith = arith; nml_resident = resident
+nml_order = order; nml_arith = arith; nml_resident = resident; nml_devices = devices
 PRINT*, " Run parameters read from ",TRIM(path)
 END SUBROUTINE lsf_load_inputs
+
+! GPUs for the block-decomposed reinit: LSF_DEVICES="0,1,..." or the namelist's `devices`; nd = leading entries >= 0
+SUBROUTINE lsf_device_list(devs,nd)
+INTEGER(c_int), INTENT(OUT) :: devs(16),nd
+CHARACTER(LEN=256) :: v
+INTEGER :: st,ios
+CALL lsf_load_inputs()
+devs = nml_devices
+CALL get_environment_variable('LSF_DEVICES',v,STATUS=st)
+IF (st == 0 .AND. LEN_TRIM(v) > 0) THEN
+   devs = -1
+   v = v(1:LEN_TRIM(v))//' /'                        ! the slash ends the list: entries not given stay -1
+   READ(v,*,IOSTAT=ios) devs
+   IF (ios /= 0) THEN
+      PRINT*, " liblsf_hip: cannot read LSF_DEVICES=",TRIM(v)
+      STOP 1
+   END IF
+END IF
+nd = 0
+DO WHILE (nd < 16)
+   IF (devs(nd+1) < 0) EXIT
+   nd = nd+1
+END DO
+END SUBROUTINE lsf_device_list
 
 SUBROUTINE lsf_fail(where,rc)
 CHARACTER(LEN=*), INTENT(IN) :: where
@@ -266,7 +306,7 @@ REAL,INTENT(IN) :: dx,h
 REAL,DIMENSION(0:nx,0:ny,0:nz),INTENT(INOUT) :: phi,gradPhiMag
 REAL,DIMENSION(0:nx,0:ny,0:nz,3),INTENT(INOUT) :: gradPhi
 REAL,ALLOCATABLE :: trace(:)
-INTEGER(c_int) :: rc,done
+INTEGER(c_int) :: rc,done,mode,devs(16),nd
 INTEGER :: n
 
 ! gradPhi and gradPhiMag are dead outputs of the reference's reinit: the host zeroes them
@@ -274,8 +314,18 @@ INTEGER :: n
 ! They are left untouched.
 
 ALLOCATE(trace(iter+1))
-rc = lsf_reinit(phi,nx,ny,nz,iter,dx,h,1.E-5,lsf_mode(),done,trace,iter+1)
-IF (rc /= LSF_OK .AND. rc /= LSF_ERR_NAN) CALL lsf_fail('lsf_reinit',rc)
+mode = lsf_mode()
+CALL lsf_device_list(devs,nd)
+IF (nd >= 2 .AND. IAND(mode,LSF_ORDER_JACOBI) /= 0) THEN
+   ! one block per listed GPU, halos peer to peer, same result as one GPU (include/lsf.h: lsf_reinit_multi)
+   PRINT*, " Reinit block-decomposed over ",nd," devices "
+   rc = lsf_reinit_multi(phi,nx,ny,nz,iter,dx,h,1.E-5,mode,devs,nd,C_NULL_PTR,done,trace,iter+1)
+   IF (rc /= LSF_OK .AND. rc /= LSF_ERR_NAN) CALL lsf_fail('lsf_reinit_multi',rc)
+ELSE
+   IF (nd >= 2) PRINT*, " liblsf_hip: devices ignored, the reference's in-place ordering does not shard (order = 'jacobi' does) "
+   rc = lsf_reinit(phi,nx,ny,nz,iter,dx,h,1.E-5,mode,done,trace,iter+1)
+   IF (rc /= LSF_OK .AND. rc /= LSF_ERR_NAN) CALL lsf_fail('lsf_reinit',rc)
+END IF
 
 ! what the reference prints, sweep by sweep (subs.f90:915-926)
 DO n = 0,done-1

@@ -107,3 +107,50 @@ def test_baseline_config3_twocube10_512(tmp_path):
     assert np.array_equal(a1[::8, ::4, ::4], g["reinit_sample"]) and sha1 == str(g["reinit_sha"])
     sha2, a2 = _sha_file_payload(tmp_path / "smoothedDistanceFunction.vti", shape)
     assert np.array_equal(a2[::8, ::4, ::4], g["minmax_sample"]) and sha2 == str(g["minmax_sha"])
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="drop-in executable not built")
+def test_fortran_host_drives_the_block_decomposed_reinit(tmp_path):
+    """order = 'jacobi' with a device list in &lsf_inputs: the reference's host runs both reinit calls block-decomposed
+    (lsf_reinit_multi, one block per listed device; here four blocks sharing this box's GPU) between seams that keep
+    their arrays on the device (resident = 2).  Both .vti payloads and the printed residuals equal the one-GPU Jacobi
+    run, and LSF_DEVICES overrides the namelist."""
+    import stl_io
+
+    s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    outs = {}
+    for name, devices in (("one", None), ("four", "0, 0, 0, 0"), ("env", None)):
+        d = tmp_path / name
+        d.mkdir()
+        stl_io.stl_write(d / "cube40.stl", s["cube40_surfX"], s["cube40_surfElem"])
+        nml = "&lsf_inputs\n  order = 'jacobi'\n  reinit_iter = 40\n  minmax_iter = 6\n  reinit2_iter = 9\n"
+        if devices:
+            nml += f"  devices = {devices}\n"
+        (d / "run.nml").write_text(nml + "/\n")
+        env = {k: v for k, v in os.environ.items() if not k.startswith("LSF_")}
+        if name == "env":
+            env["LSF_DEVICES"] = "0,0"
+        p = subprocess.run(f"ulimit -s unlimited; cd {d}; {EXE} cube40.stl run.nml", shell=True, env=env, text=True,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:]
+        outs[name] = p.stdout
+    assert "block-decomposed" not in outs["one"]
+    assert outs["four"].count("Reinit block-decomposed over  4  devices") == 2
+    assert outs["env"].count("Reinit block-decomposed over  2  devices") == 2
+    shape = (62, 62, 62)
+    rms_one = [float(x) for x in re.findall(r"RMS Error:\s+(\S+)", outs["one"])]
+    assert len(rms_one) == 41 + 6 + 10
+    for name in ("four", "env"):
+        for f in ("signedDistanceFunction.vti", "smoothedDistanceFunction.vti"):
+            assert np.array_equal(stl_io.vti_read_phi(tmp_path / name / f, shape), stl_io.vti_read_phi(tmp_path / "one" / f, shape)), (name, f)
+        rms = [float(x) for x in re.findall(r"RMS Error:\s+(\S+)", outs[name])]
+        assert np.allclose(rms, rms_one, rtol=1e-10, atol=0)  # block sums added in rank order vs one fixed-order sum
+    # the exact ordering does not shard: a device list is ignored there, with a note
+    d = tmp_path / "gs"
+    d.mkdir()
+    stl_io.stl_write(d / "cube40.stl", s["cube40_surfX"], s["cube40_surfElem"])
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LSF_")}
+    env.update(LSF_DEVICES="0,0", LSF_REINIT_ITER="3", LSF_MINMAX_ITER="0", LSF_REINIT2_ITER="0")
+    p = subprocess.run(f"ulimit -s unlimited; cd {d}; {EXE} cube40.stl", shell=True, env=env, text=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0 and "devices ignored" in p.stdout
