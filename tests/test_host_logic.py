@@ -141,7 +141,7 @@ def test_host_reads_the_namelist_and_pads_per_axis(tmp_path):
     s = np.load(os.path.join(ROOT, "tests", "golden", "surfaces.npz"))
     stl_io.stl_write(tmp_path / "twoCube10.stl", s["twocube10_surfX"], s["twocube10_surfElem"])
     (tmp_path / "in.nml").write_text("&lsf_inputs\n  dx = 0.125\n  dd = 7\n  dd_lo = 7, 27, 27\n  dd_hi = 8, 28, 28\n"
-                                     "  reinit_iter = 3\n  minmax_iter = 0\n  reinit2_iter = 0\n  arith = 'strict'\n  resident = 1\n/\n")
+                                     "  reinit_iter = 3\n  minmax_iter = 0\n  reinit2_iter = 0\n  arith = 'strict'\n  resident = 1\n  devices = 0, 0\n/\n")
     env = {k: v for k, v in os.environ.items() if not k.startswith("LSF_")}
     env["LSF_REINIT_ITER"] = "5"  # the environment overrides the namelist
     env["HIP_VISIBLE_DEVICES"] = "-1"
