@@ -23,27 +23,38 @@ __device__ __forceinline__ double fmin2(double a, double b) { return (a < b) ? a
 // STRICT: one axis of the WENO branch (subs.f90:509-552 / :555-598 / :601-644).
 // q[0..6] = phi at -3..+3 along the axis in ABSOLUTE orientation; yquirk = subs.f90:576.
 // ---------------------------------------------------------------------------------------------
-// x / dx exactly as the IEEE division the reference executes (correctly rounded), for a divisor whose correctly rounded
-// reciprocal rdx = 1. / dx is at hand: one product and two residual corrections (q1 is within half an ulp and a hair of
-// x / dx, the second correction rounds it correctly -- Markstein).  17 of the 27 divisions of an axis divide by dx
-// (subs.f90:509-513, :525-530): five instructions each instead of the ~11 of a general fp64 division.  phi, hence x, is
-// far from the overflow and underflow thresholds; NaN propagates (the reference's NaN is born in phiSign, subs.f90:169,
-// not here: the twoCube10 stop sweep is tested).
-__device__ __forceinline__ double div_dx(double x, double dx, double rdx)
+// n / d exactly as the IEEE division, by the sequence the compiler itself emits for an fp64 division (v_rcp_f64, two
+// Newton steps on the reciprocal, one product, one residual correction) WITHOUT its v_div_scale / v_div_fmas / v_div_fixup
+// frame: those only act when an operand or the quotient is near the ends of the exponent range (or is zero, infinite,
+// NaN), which weno_axis_strict rules out before it comes here.  The refined reciprocal is a value of its own so that the
+// two weights of a WENO side, which divide by the same sum (subs.f90:540-543), share it.
+__device__ __forceinline__ double recip_refined(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double div_by(double n, double d, double r)
 {
 #pragma clang fp contract(off)
-    const double q0 = x * rdx;
-    const double r0 = __builtin_fma(-dx, q0, x);
-    const double q1 = __builtin_fma(r0, rdx, q0);
-    const double r1 = __builtin_fma(-dx, q1, x);
-    return __builtin_fma(r1, rdx, q1);
+    const double q = n * r;
+    const double e = __builtin_fma(-d, q, n);
+    return __builtin_fma(e, r, q);
 }
+
+// x / dx: 17 of the 27 divisions of an axis divide by dx (subs.f90:509-513, :525-530); with the refined reciprocal of dx
+// hoisted out of the march each is three instructions instead of the ~11 of a general fp64 division.  phi, hence x, is
+// far from the overflow and underflow thresholds (a zero numerator gives zero); NaN propagates (the reference's NaN is
+// born in phiSign, subs.f90:169, not here: the twoCube10 stop sweep is tested).
+__device__ __forceinline__ double div_dx(double x, double dx, double rdx) { return div_by(x, dx, rdx); }
 
 __device__ __forceinline__ void weno_axis_strict(const double q[7], double dx, bool yquirk, double& dm,
                                                  double& dp)
 {
 #pragma clang fp contract(off)
-    const double rdx = 1. / dx; // loop invariant: hoisted out of every march
+    const double rdx = recip_refined(dx); // loop invariant: hoisted out of every march
     const double m3 = q[0], m2 = q[1], m1 = q[2], c0 = q[3], r1 = q[4], r2 = q[5], r3 = q[6];
     const double ap = div_dx(r3 - 2. * r2 + r1, dx, rdx);
     const double am = div_dx(m3 - 2. * m2 + m1, dx, rdx);
@@ -71,17 +82,30 @@ __device__ __forceinline__ void weno_axis_strict(const double q[7], double dx, b
     const double epsm =
         (1.E-6) * fmax2(p0 * p0, fmax2(p1 * p1, fmax2(p2 * p2, fmax2(p3 * p3, p4 * p4)))) + 1.E-99;
 
-    const double a0p = 1. / ((epsp + IS0p) * (epsp + IS0p));
-    const double a0m = 1. / ((epsm + IS0m) * (epsm + IS0m));
-    const double a1p = 6. / ((epsp + IS1p) * (epsp + IS1p));
-    const double a1m = 6. / ((epsm + IS1m) * (epsm + IS1m));
-    const double a2p = 3. / ((epsp + IS2p) * (epsp + IS2p));
-    const double a2m = 3. / ((epsm + IS2m) * (epsm + IS2m));
-
-    const double w0p = a0p / (a0p + a1p + a2p);
-    const double w0m = a0m / (a0m + a1m + a2m);
-    const double w2p = a2p / (a0p + a1p + a2p);
-    const double w2m = a2m / (a0m + a1m + a2m);
+    const double x0p = (epsp + IS0p) * (epsp + IS0p), x0m = (epsm + IS0m) * (epsm + IS0m);
+    const double x1p = (epsp + IS1p) * (epsp + IS1p), x1m = (epsm + IS1m) * (epsm + IS1m);
+    const double x2p = (epsp + IS2p) * (epsp + IS2p), x2m = (epsm + IS2m) * (epsm + IS2m);
+    double w0p, w0m, w2p, w2m;
+    // The ten divisions of subs.f90:533-543.  eps >= 1e-99 and IS <= ~100 max(p^2) <= 1e8 eps bound every divisor from
+    // below (x >= 1e-198) and the weights' quotients to [1e-17, 1]; with the six sums eps + IS below 1e120 every divisor,
+    // numerator and quotient is also far from the exponent limits where the hardware division would rescale -- then
+    // div_by is that division bit for bit.  Anything else (a diverging field on its way to NaN, NaN itself) takes `/`.
+    const double big = fmax2(fmax2(fmax2(epsp + IS0p, epsp + IS1p), epsp + IS2p), fmax2(fmax2(epsm + IS0m, epsm + IS1m), epsm + IS2m));
+    if (__builtin_expect(big < 1.0e120, 1)) {
+        const double a0p = div_by(1., x0p, recip_refined(x0p)), a0m = div_by(1., x0m, recip_refined(x0m));
+        const double a1p = div_by(6., x1p, recip_refined(x1p)), a1m = div_by(6., x1m, recip_refined(x1m));
+        const double a2p = div_by(3., x2p, recip_refined(x2p)), a2m = div_by(3., x2m, recip_refined(x2m));
+        const double sp = a0p + a1p + a2p, sm = a0m + a1m + a2m;
+        const double rp = recip_refined(sp), rm = recip_refined(sm);
+        w0p = div_by(a0p, sp, rp), w2p = div_by(a2p, sp, rp);
+        w0m = div_by(a0m, sm, rm), w2m = div_by(a2m, sm, rm);
+    } else {
+        const double a0p = 1. / x0p, a0m = 1. / x0m, a1p = 6. / x1p, a1m = 6. / x1m, a2p = 3. / x2p, a2m = 3. / x2m;
+        w0p = a0p / (a0p + a1p + a2p);
+        w0m = a0m / (a0m + a1m + a2m);
+        w2p = a2p / (a0p + a1p + a2p);
+        w2m = a2m / (a0m + a1m + a2m);
+    }
 
     const double PWp = 1. / 3. * w0p * (ap - 2. * bp + cp) + 1. / 6. * (w2p - 0.5) * (bp - 2. * cp + dpp);
     const double PWm = 1. / 3. * w0m * (am - 2. * bm + cm) + 1. / 6. * (w2m - 0.5) * (bm - 2. * cm + dmm);
@@ -126,7 +150,7 @@ __device__ __forceinline__ double cell_update_strict(const double qx[7], const d
         weno_axis_strict(qy, dx, true, c, d);
         weno_axis_strict(qz, dx, false, e, f);
     } else {
-        const double rdx = 1. / dx;
+        const double rdx = recip_refined(dx);
         a = div_dx(phic - qx[2], dx, rdx);
         b = div_dx(qx[4] - phic, dx, rdx);
         c = div_dx(phic - qy[2], dx, rdx);
@@ -330,7 +354,7 @@ __device__ __forceinline__ void axis_pair(const double q[7], bool weno_ok, bool 
         if (weno_ok) {
             weno_axis_strict(q, dx, yquirk, dm, dp);
         } else {
-            const double rdx = 1. / dx;
+            const double rdx = recip_refined(dx);
             dm = div_dx(q[3] - q[2], dx, rdx); // subs.f90:657-662
             dp = div_dx(q[4] - q[3], dx, rdx);
         }
