@@ -825,7 +825,9 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         int* d_done = d_cnt + (size_t)BATCH * np;
         int* d_ticket = d_done + BATCH;
         unsigned long long* d_dbg = nullptr;
-        if (getenv("LSF_TRACE")) {
+        // per-tile wait / work times of the dataflow launch: three contended atomics per tile (+70 % run time), so its own
+        // switch and not part of LSF_TRACE, whose per-call times are meant to be read as measurements
+        if (getenv("LSF_TRACE_TILES")) {
             if ((rc = ws(c.slot[S_DBG], 64))) return rc;
             d_dbg = (unsigned long long*)c.slot[S_DBG].p;
         }

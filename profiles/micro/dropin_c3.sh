@@ -24,6 +24,9 @@ cat > c3.nml <<NML
 /
 NML
 OUT=$GRAFT_REPO_ROOT/gpurun_out/c3_dropin.txt
+# one discarded run first: the first process that allocates 8 GB of device memory on a fresh box pays for it (snapshot and
+# narrowBand 30 ms instead of < 1 ms, reinit + 150 ms), later processes do not
+bash -c "ulimit -s unlimited; $GRAFT_REPO_ROOT/build/dropin/set3d_hip.exec twoCube10.stl c3.nml > /dev/null 2>&1"
 T0=$(date +%s.%N)
 bash -c "ulimit -s unlimited; LSF_TRACE=1 $GRAFT_REPO_ROOT/build/dropin/set3d_hip.exec twoCube10.stl c3.nml > out.txt 2> err.txt"
 T1=$(date +%s.%N)
