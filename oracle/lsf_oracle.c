@@ -197,6 +197,12 @@ static void sweep_hyper(double *phi, const double *phiS, int nx, int ny, int nz,
     int p, aa, bb;
     const int na = nx - 1, nb = ny - 1, nc = nz - 1;
     for (p = 3; p <= na + nb + nc; ++p) {
+        /* the cells of one hyperplane do not read one another: with -fopenmp (liblsf_oracle_omp.so, used only to
+         * generate long fixtures) they are shared among threads; every cell still executes the same operations on the
+         * same operands, so the result is the one of the serial loop bit for bit (tests/test_oracle_golden.py) */
+#ifdef _OPENMP
+#pragma omp parallel for private(bb) schedule(static)
+#endif
         for (aa = 1; aa <= na; ++aa) {
             for (bb = 1; bb <= nb; ++bb) {
                 int cc = p - aa - bb;

@@ -13,7 +13,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "liblsf_oracle.so")
+# LSF_ORACLE_OMP=1: the OpenMP build of the same source (oracle/Makefile `omp`; long fixtures only)
+ORACLE_SO = os.path.join(ORACLE_DIR, "liblsf_oracle_omp.so" if os.environ.get("LSF_ORACLE_OMP") else "liblsf_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_subs.so")
 
 GS_LEX, GS_HYPER, JACOBI = 0, 1, 2
@@ -33,6 +34,8 @@ def lib():
     if _lib is None:
         if not os.path.exists(ORACLE_SO):
             build()
+            if os.environ.get("LSF_ORACLE_OMP"):
+                subprocess.run(["make", "-s", "-C", ORACLE_DIR, "omp"], check=True)
         L = ctypes.CDLL(ORACLE_SO)
         L.lsf_oracle_weno.restype = c_double
         L.lsf_oracle_weno.argtypes = [c_int] * 6 + [c_double, _dp]

@@ -1,4 +1,4 @@
-"""BASELINE config 3 at its stated size: twoCube10.stl on a CUBIC 512^3 grid (per-axis pad cells, host edit E4b),
+"""BASELINE configs 3 and 2 at their stated sizes.  Config 3: twoCube10.stl on a CUBIC 512^3 grid (per-axis pad cells, host edit E4b),
 WENO5 reinit at a fixed sweep count (the surface diverges later in the reference itself) + 200
 min/max-flow iterations.  Fixtures: tests/golden/make_golden_c3_cubic.py (phi0 by the pinned oracle, the sweeps by the
 reference's OWN `reinit`, min/max by the pinned oracle; SHA-256 of every full field + strided samples).
@@ -126,3 +126,76 @@ def test_config3_cubic_512_through_the_fortran_host_with_a_namelist(tmp_path):
         assert np.array_equal(a[::16, ::8, ::8], g[key + "_sample"]), name
         assert hashlib.sha256(np.ascontiguousarray(a.ravel(order="F")).tobytes()).hexdigest() == str(g[key + "_sha"]), name
         del a
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 2 run to convergence: cube40.stl at 256^3, reinit until RMS < 1e-5 (3 298 sweeps), no min/max flow.
+# Fixture: tests/golden/make_golden_c2_conv.py (the pinned oracle; its first 8 sweeps are checked there against the
+# reference's own reinit at this size).
+# ---------------------------------------------------------------------------------------------------------------------
+def _c2_converged():
+    path = os.path.join(GOLDEN, "cube40_256_converged.npz")
+    if not os.path.exists(path):
+        pytest.skip("cube40_256_converged.npz not generated")
+    return np.load(path), np.load(os.path.join(GOLDEN, "cube40_256.npz"))
+
+
+def test_config2_cube40_256_to_convergence_on_the_device():
+    import torch
+
+    import levelsetfortran_amd as lsf
+    import stl_io
+
+    g, g8 = _c2_converged()
+    s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    X, E = s["cube40_surfX"].astype(np.float64), s["cube40_surfElem"]
+    dx, h = float(g["dx"]), float(g["h"])
+    n, xLo, mn, mx = stl_io.grid_from_surface(X, dx=dx, dd=10)
+    assert tuple(n) == (255, 255, 255)
+    nx, ny, nz = n
+    shape = (256, 256, 256)
+    phi0 = torch.ones(256 ** 3, dtype=torch.float64, device="cuda")
+    lsf.phi0Init(phi0, nx, ny, nz, dx, xLo, mn, mx, X, E)
+    assert _sha_t(phi0) == str(g8["phi0_sha"])
+    sweeps = int(g["sweeps"])
+    # STRICT: the reference's raster order and arithmetic, same stop sweep, same field, same residuals
+    phi = phi0.clone()
+    rep = lsf.reinit(phi, None, None, nx, ny, nz, 10000, dx, h, arith="strict")
+    assert rep.converged and rep.count == sweeps
+    assert np.array_equal(phi.cpu().numpy().reshape(shape, order="F")[::8, ::8, ::8], g["sample"])
+    assert _sha_t(phi) == str(g["sha"])
+    assert np.allclose(rep.rms, g["rms"], rtol=1e-7, atol=0)
+    # FAST: stops at the same sweep, 1e-12 RMS from the reference's converged field, same inside / outside
+    fast = phi0.clone()
+    repf = lsf.reinit(fast, None, None, nx, ny, nz, 10000, dx, h, arith="fast")
+    assert repf.converged and repf.count == sweeps
+    d = fast - phi
+    assert float(torch.sqrt(torch.mean(d * d))) < 1e-12
+    assert bool(((fast < 0) == (phi < 0)).all())
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="drop-in executable not built")
+def test_config2_cube40_256_to_convergence_through_the_fortran_host(tmp_path):
+    """The reference's main program as BASELINE config 2 states it (256^3, reinit only): the .vti it writes holds the
+    converged field of the fixture, and it printed every residual of the 3 298 sweeps."""
+    import stl_io
+
+    g, _ = _c2_converged()
+    s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    stl_io.stl_write(tmp_path / "cube40.stl", s["cube40_surfX"], s["cube40_surfElem"])
+    (tmp_path / "c2.nml").write_text(f"&lsf_inputs\n  dx = {float(g['dx'])!r}\n  minmax_iter = 0\n  reinit2_iter = 0\n  arith = 'strict'\n/\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LSF_")}
+    p = subprocess.run(f"ulimit -s unlimited; cd {tmp_path}; {EXE} cube40.stl c2.nml", shell=True, env=env, text=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800)
+    out = p.stdout
+    assert p.returncode == 0, out[-3000:]
+    assert "Grid Size: nx = 255 , ny = 255 ,nz = 255" in out
+    sweeps = int(g["sweeps"])
+    its = [int(x) for x in re.findall(r"Iteration:\s+(\d+)", out)]
+    assert its[:sweeps - 1] == list(range(sweeps - 1))  # the last sweep prints the steady-state line instead
+    assert "Distance function time integration has reached steady state" in out
+    rms = [float(x) for x in re.findall(r"RMS Error:\s+(\S+)", out)][:sweeps - 1]
+    assert np.allclose(rms, g["rms"][:sweeps - 1], rtol=1e-7, atol=0)
+    a = stl_io.vti_read_phi(tmp_path / "signedDistanceFunction.vti", (256, 256, 256))
+    assert np.array_equal(a[::8, ::8, ::8], g["sample"])
+    assert hashlib.sha256(np.ascontiguousarray(a.ravel(order="F")).tobytes()).hexdigest() == str(g["sha"])

@@ -151,3 +151,31 @@ def test_node_advection_cube40(oracle, cube40):
                        adv["xLo"], s["cube40_surfX"].astype(np.float64))
     assert np.array_equal(XX, adv["surfXX"])
     assert np.abs(XX - s["cube40_surfX"]).max() > 0.05  # the nodes really moved
+
+
+def test_threaded_hyperplane_sweep_is_the_same_sweep(synth, tmp_path):
+    """oracle/Makefile `omp`: the hyperplane sweep with the cells of a hyperplane shared among threads (used only to make
+    the long 256^3 fixture, tests/golden/make_golden_c2_conv.py) returns the reference's field and printed residuals bit
+    for bit, like the serial orders above."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    if subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "omp"]).returncode != 0:
+        pytest.skip("no OpenMP toolchain")
+    np.savez(tmp_path / "case.npz", **{k: synth[k] for k in ("phi0", "phi_16", "rms", "nx", "ny", "nz", "dx", "h")})
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "import oracle_lib as o\n"
+        f"g = np.load({str(tmp_path / 'case.npz')!r})\n"
+        "phi = np.asfortranarray(g['phi0'].copy())\n"
+        "rc, n, tr = o.reinit(phi, int(g['nx']), int(g['ny']), int(g['nz']), 15, float(g['dx']), float(g['h']), order=o.GS_HYPER)\n"
+        "assert o.ORACLE_SO.endswith('_omp.so') and rc == 0 and n == 16\n"
+        "assert np.array_equal(phi, g['phi_16']) and np.array_equal(tr, g['rms'])\n"
+        "print('same')\n")
+    env = dict(os.environ, LSF_ORACLE_OMP="1", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
