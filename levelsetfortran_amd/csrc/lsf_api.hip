@@ -358,10 +358,18 @@ double rms_denominator(int nx, int ny, int nz)
 const int RASTER_SIGN[8][3] = {{+1, +1, +1}, {+1, +1, -1}, {+1, -1, -1}, {-1, -1, -1},
                                {-1, +1, -1}, {-1, -1, +1}, {-1, +1, +1}, {+1, -1, +1}};
 
-dim3 bc_grid(int e0, int e1, int e2)
+// launch geometry of k_bc for the region [lo, hi) of a box: one z-slice of the grid per wall face the region touches
+dim3 bc_grid(const Box& bx, const int lo[3], const int hi[3], unsigned* faces)
 {
-    const int m = std::max(e0, std::max(e1, e2));
-    return dim3(cdiv(m, 64), m, 6);
+    const int m = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+    const int nwall[3] = {bx.nx, bx.ny, bx.nz}, g0[3] = {bx.gx0, bx.gy0, bx.gz0};
+    unsigned list = 0, cnt = 0;
+    for (int f = 0; f < 6; ++f) {
+        const int a = f >> 1, wl = ((f & 1) ? nwall[a] : 0) - g0[a];
+        if (wl >= lo[a] && wl < hi[a]) list |= (unsigned)f << (3 * cnt++);
+    }
+    *faces = list;
+    return dim3(cdiv(m, 64), m, cnt);
 }
 
 int check_dims(int nx, int ny, int nz)
@@ -544,7 +552,10 @@ int jacobi_loop(T* d_phi, const T* d_phiS_in, int nx, int ny, int nz, int iter, 
     if constexpr (F32) jp = jacobi_plan_f32(jlo, jhi);
     else jp = jacobi_plan(jlo, jhi, strict);
     n_sweep_part = jp.nparts;
-    const dim3 bgrid = bc_grid(nx + 1, ny + 1, nz + 1);
+    const Box bx{nx + 1, ny + 1, nz + 1, 0, 0, 0, nx, ny, nz};
+    const int blo[3] = {0, 0, 0}, bhi[3] = {nx + 1, ny + 1, nz + 1};
+    unsigned bfaces = 0;
+    const dim3 bgrid = bc_grid(bx, blo, bhi, &bfaces); // the whole grid: all six faces
     const long n_bc_part = (long)bgrid.x * bgrid.y * bgrid.z;
     const long n_part = n_sweep_part + n_bc_part;
     if ((rc = ws(c.slot[S_PART], (size_t)n_part * sizeof(double)))) return rc;
@@ -553,7 +564,6 @@ int jacobi_loop(T* d_phi, const T* d_phiS_in, int nx, int ny, int nz, int iter, 
     // 1536^3 grid of configuration 5 (RMS = NaN, STOP) and there is no fp32 reference behaviour to mirror: fp32 fields
     // divide by the true product
     const double den = F32 ? (double)nx * (double)ny * (double)nz : rms_denominator(nx, ny, nz);
-    const Box bx{nx + 1, ny + 1, nz + 1, 0, 0, 0, nx, ny, nz};
     const int xwall = F32 ? F32_XWALL : 0;
 
     T* bufs[2] = {d_phi, (T*)c.slot[S_PONG].p};
@@ -567,7 +577,7 @@ int jacobi_loop(T* d_phi, const T* d_phiS_in, int nx, int ny, int nz, int iter, 
         else jacobi_launch(jp, strict, A, B, d_phiS, bx, jlo, jhi, dx, h, part, ctl, st);
         prof_mark(st);
         hipLaunchKernelGGL(k_bc<T>, bgrid, dim3(64), 0, st, A, B, bx, 0, 0, 0, nx + 1, ny + 1, nz + 1, (T)dx, part + n_sweep_part, ctl,
-                           xwall);
+                           xwall, bfaces);
         prof_mark(st);
         hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, part, n_part, den, tol, d_trace, max_sweeps, ctl);
         prof_mark(st);
@@ -1326,13 +1336,15 @@ int bc_box_impl(const T* d_in, T* d_out, const lsf_box* box, const int lo[3], co
     if (!d_in || !d_out || !d_sumsq) return fail(LSF_ERR_INVALID, "NULL pointer");
     if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) return LSF_OK;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid = bc_grid(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
+    const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
+    unsigned faces = 0;
+    const dim3 grid = bc_grid(bx, lo, hi, &faces);
+    if (grid.z == 0) return LSF_OK; // no wall of the global grid inside this region
     const long np = (long)grid.x * grid.y * grid.z;
     double* part = nullptr;
     if ((rc = stream_partials(st, (size_t)np, &part))) return rc;
-    const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
     hipLaunchKernelGGL(k_bc<T>, grid, dim3(64), 0, st, d_in, d_out, bx, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], (T)dx,
-                       part, (const int*)nullptr, 0);
+                       part, (const int*)nullptr, 0, faces);
     return finish_partials(st, part, np, d_sumsq);
 }
 

@@ -291,16 +291,18 @@ __global__ __launch_bounds__(64 * WX * BY) __attribute__((amdgpu_waves_per_eu(5)
 // =============================================================================================
 // Extrapolation boundary condition, closed form of subs.f90:859-897:
 // wall point <- interior point clamp(i,1,n-1) + dx added m = min(nb, 1+nh) times in sequence.
-// grid = (ceil(maxext/64), maxext, 6 faces); each wall point is owned by exactly one face.
+// grid = (ceil(maxext/64), maxext, faces present); each wall point is owned by exactly one face.
 // =============================================================================================
 template <typename T>
 __global__ __launch_bounds__(64) void k_bc(const T* __restrict__ A, T* __restrict__ Bout, Box bx,
                                            int lo0, int lo1, int lo2, int hi0, int hi1, int hi2, T dx,
                                            double* __restrict__ partials, const int* __restrict__ done,
-                                           int skip_xface)
+                                           int skip_xface, unsigned faces)
 {
     if (done && *done) return;
-    const int face = blockIdx.z; // 0:i=0 1:i=nx 2:j=0 3:j=ny 4:k=0 5:k=nz
+    // `faces`: the wall faces this region touches, 3 bits each (gridDim.z of them): a block of a decomposed field has
+    // walls only where it has no neighbour
+    const int face = (int)((faces >> (3 * blockIdx.z)) & 7u); // 0:i=0 1:i=nx 2:j=0 3:j=ny 4:k=0 5:k=nz
     const int u = blockIdx.x * 64 + threadIdx.x, v = blockIdx.y;
     const int axis = face >> 1;
     const int nwall[3] = {bx.nx, bx.ny, bx.nz};
