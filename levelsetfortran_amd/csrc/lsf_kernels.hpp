@@ -559,6 +559,13 @@ __global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A,
             int mine = 0;
             int i, j, k;
             point_ijk(chunk * CH + threadIdx.x, nx + 1, ny + 1, n, i, j, k);
+            // the scan issues all its loads of A before it looks at any of them (the loop below ends early at the end of
+            // the field, which would otherwise keep the compiler from moving a load above the previous point's branch)
+            double cpre[CH / 256];
+            if (PASS == 0) {
+#pragma unroll
+                for (int t = 0; t < CH / 256; ++t) cpre[t] = A[min(chunk * CH + t * 256 + threadIdx.x, n - 1)];
+            }
 #pragma unroll
             for (int t = 0; t < CH / 256; ++t) {
                 const long p = chunk * CH + t * 256 + threadIdx.x;
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A,
                     if (tiny) point_ijk(p, nx + 1, ny + 1, n, i, j, k);
                     else step_ijk(i, j, k, d256i, d256j, 0, nx + 1, ny + 1);
                 }
-                const double c = A[p];
+                const double c = PASS == 0 ? cpre[t] : A[p];
                 const bool interior = i >= 1 && i <= nx - 1 && j >= 1 && j <= ny - 1 && k >= 1 && k <= nz - 1;
                 const bool band = interior && in_band(nbmask, p, c, dx);
                 if (PASS == 0) {
