@@ -47,7 +47,9 @@ __device__ __forceinline__ double div_by(double n, double d, double r)
 // x / dx: 17 of the 27 divisions of an axis divide by dx (subs.f90:509-513, :525-530); with the refined reciprocal of dx
 // hoisted out of the march each is three instructions instead of the ~11 of a general fp64 division.  phi, hence x, is
 // far from the overflow and underflow thresholds (a zero numerator gives zero); NaN propagates (the reference's NaN is
-// born in phiSign, subs.f90:169, not here: the twoCube10 stop sweep is tested).
+// born in phiSign, subs.f90:169, not here: the twoCube10 stop sweep is tested).  An INFINITE numerator gives NaN where the
+// IEEE division gives infinity: a field that already holds infinities is one sweep away from the reference's NaN STOP
+// either way (tests/test_gpu_parity.py, ..._at_the_ends_of_the_exponent_range).
 __device__ __forceinline__ double div_dx(double x, double dx, double rdx) { return div_by(x, dx, rdx); }
 
 __device__ __forceinline__ void weno_axis_strict(const double q[7], double dx, bool yquirk, double& dm,

@@ -52,6 +52,33 @@ def test_reinit_strict_matches_reference_synthetic(lsf, synth):
     assert np.array_equal(phi, synth["phi_1"])
 
 
+@pytest.mark.parametrize("scale", [1e-140, 1e-60, 1e40, 1e55, 1e70, 1e140])
+@pytest.mark.parametrize("order", ["gs", "jacobi"])
+def test_reinit_strict_at_the_ends_of_the_exponent_range(lsf, oracle, scale, order):
+    """STRICT divides by the hardware's reciprocal / Newton / correction sequence without its scale / fixup frame
+    (lsf_cell.hpp: recip_refined, div_by) wherever eps + IS < 1e120, and by the plain division elsewhere.  Fields scaled
+    so that the WENO divisors sit in the middle of that range, at its edge (1e55: IS ~ 1e114), beyond it (1e70), at the
+    underflow end, and where the reference itself overflows to NaN (1e140): every bit as the oracle's IEEE arithmetic.
+    (Below ~1e-150 the reference's own phiSign divides by an underflowed zero and fills the field with infinities; the
+    sweep after that ends in its NaN STOP here as there, but the unframed sequences turn inf / dx into NaN, so a few
+    wall cells of that last, never-written field differ: not part of this test.)"""
+    from levelsetfortran_amd import fields
+
+    npts = (26, 23, 21)
+    phi0, dx = fields.two_sphere_phi0(npts)
+    phi0 = np.asfortranarray(phi0 * scale)
+    nx, ny, nz = (n - 1 for n in npts)
+    h = fields.reinit_step(dx)
+    want = phi0.copy(order="F")
+    oracle.reinit(want, nx, ny, nz, 2, dx, h, tol=0.0, order=oracle.GS_LEX if order == "gs" else oracle.JACOBI)
+    got = phi0.copy(order="F")
+    try:
+        lsf.reinit(got, None, None, nx, ny, nz, 2, dx, h, tol=0.0, order=order, arith="strict")
+    except lsf.LsfNaNError:
+        assert np.isnan(want).any()  # the reference stops on the same NaN (subs.f90:926); the field is written back
+    assert np.array_equal(got, want, equal_nan=True), (scale, order, float(np.nanmax(np.abs(got - want))))
+
+
 def test_reinit_fast_within_tolerance_and_sign_exact(lsf, synth):
     nx, ny, nz = _n(synth)
     phi = F(synth["phi0"])
