@@ -745,10 +745,12 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     if (tr) {
         if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
         const dim3 tg(cdiv(nx + 1, 32), cdiv(ny + 1, 32), (unsigned)std::min(nz + 1, 1024));
+        // phiS = phi on entry (subs.f90:731): one pass over phi writes both transposed copies unless the caller has its own
         hipLaunchKernelGGL(k_transpose_xy, tg, dim3(256), 0, st, (const double*)d_phi, (double*)c.slot[S_PONG].p, nx + 1, ny + 1,
-                           (long)(nz + 1));
-        hipLaunchKernelGGL(k_transpose_xy, tg, dim3(256), 0, st, d_phiS_in ? d_phiS_in : (const double*)d_phi,
-                           (double*)c.slot[S_PHIS].p, nx + 1, ny + 1, (long)(nz + 1)); // phiS = phi on entry, subs.f90:731
+                           (long)(nz + 1), d_phiS_in ? (double*)nullptr : (double*)c.slot[S_PHIS].p);
+        if (d_phiS_in)
+            hipLaunchKernelGGL(k_transpose_xy, tg, dim3(256), 0, st, d_phiS_in, (double*)c.slot[S_PHIS].p, nx + 1, ny + 1,
+                               (long)(nz + 1), (double*)nullptr);
         d_phiS = (const double*)c.slot[S_PHIS].p;
     } else if (!d_phiS) {
         if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
@@ -1048,7 +1050,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     if (tr) { // back to the caller's layout: the kernel's field has extents (ny + 1, nx + 1, nz + 1)
         const dim3 tg(cdiv(ny + 1, 32), cdiv(nx + 1, 32), (unsigned)std::min(nz + 1, 1024));
         hipLaunchKernelGGL(k_transpose_xy, tg, dim3(256), 0, st, (const double*)fa.buf[nsw % nbuf], d_phi, ny + 1, nx + 1,
-                           (long)(nz + 1));
+                           (long)(nz + 1), (double*)nullptr);
     } else if (fa.buf[nsw % nbuf] != d_phi)
         HIPCHK(hipMemcpyAsync(d_phi, fa.buf[nsw % nbuf], n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (rms_trace && trace_cap > 0 && nsw > 0)

@@ -442,8 +442,9 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
 // reference flips most often (y: six of the eight transitions, subs.f90:740-855), because a flip of the MARCH axis costs
 // only n / TA time slots of spacing between two sweeps whereas a flip of a cross-section axis costs n / TA + its number of
 // tiles; the kernel marches along its unit-stride axis, so the library runs it on the transposed field (reinit_slot_core).
+// dst2 (optional): a second copy of the result (phiS = phi on entry, subs.f90:731: one read of phi serves both).
 __global__ __launch_bounds__(256) void k_transpose_xy(const double* __restrict__ src, double* __restrict__ dst, int ex, int ey,
-                                                      long planes)
+                                                      long planes, double* __restrict__ dst2)
 {
     __shared__ double t[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
@@ -461,7 +462,11 @@ __global__ __launch_bounds__(256) void k_transpose_xy(const double* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = i0 + ty + 8 * r, j = j0 + tx;
-            if (i < ex && j < ey) d[j + (long)ey * i] = t[tx][ty + 8 * r];
+            if (i < ex && j < ey) {
+                const double v = t[tx][ty + 8 * r];
+                d[j + (long)ey * i] = v;
+                if (dst2) dst2[k * pl + j + (long)ey * i] = v;
+            }
         }
         __syncthreads();
     }
