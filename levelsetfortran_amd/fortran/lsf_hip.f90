@@ -38,7 +38,9 @@
 !     minmax_iter = 200         ! cap of the min/max flow              (set3d.f90:390)
 !     reinit2_iter = 2000       ! cap of reinit #2                     (set3d.f90:576)
 !     order = 'gs'              ! 'gs' (the reference's raster order, exact) | 'jacobi'
-!     arith = 'fast'            ! 'fast' | 'strict' (bit-identical to the reference)
+!     arith = 'strict'          ! 'strict' (default: every operation as subs.f90 writes it, the reference's bits) |
+!                               ! 'fast' (same mathematics restructured for the GPU, 2 x faster, ~1e-16 per sweep away;
+!                               !   see DESIGN.md section 2 for what that becomes over thousands of sweeps)
 !     devices = 0, 1, 2, 3      ! order = 'jacobi' only: reinit runs block-decomposed on these GPUs, one block each
 !                               !   (lsf_reinit_multi; a device may be listed more than once); unset: one GPU
 !     resident = 2              ! 0: every seam copies its arrays in and out (default of the C ABI)
@@ -209,7 +211,12 @@ IF (st /= 0) v = nml_order
 IF (TRIM(v) == 'jacobi') mode = mode + LSF_ORDER_JACOBI
 CALL get_environment_variable('LSF_ARITH',v,STATUS=st)
 IF (st /= 0) v = nml_arith
-IF (TRIM(v) == 'strict') mode = mode + LSF_ARITH_STRICT
+! the reference's own arithmetic unless the run asks for the fast one: a drop-in returns the reference's numbers
+IF (LEN_TRIM(v) > 0 .AND. TRIM(v) /= 'strict' .AND. TRIM(v) /= 'fast') THEN
+   PRINT*, " liblsf_hip: arith must be 'strict' or 'fast', not ",TRIM(v)
+   STOP 1
+END IF
+IF (TRIM(v) /= 'fast') mode = mode + LSF_ARITH_STRICT
 END FUNCTION lsf_mode
 
 !*************************************************************************************!

