@@ -9,7 +9,8 @@ that is already resident in HBM.  The default ordering is the reference's own in
 ordering, reproduced exactly on the GPU (LSF_ORDER_GS): that is the path whose output matches the
 reference to the last bit (STRICT arithmetic) / to ~1e-16 (FAST arithmetic, used here).  The
 double-buffered Jacobi ordering (does not reproduce the reference field; shards across GPUs) is
-measured in the same run and reported under "jacobi".
+measured in the same run and reported under "jacobi"; the reference's own arithmetic (LSF_ARITH_STRICT, bit-identical
+results, 2 x slower) under "strict_arithmetic".
 
     python bench.py --gpus N --steps K --warmup W [--mode gs|jacobi] [--size 512] [--dtype f64|f32]
 
@@ -233,20 +234,21 @@ def main() -> None:
         phiS = phi0.clone()
         phi = phi0.clone()
 
-        def run(order_, sweeps, profile=False):
+        def run(order_, sweeps, profile=False, arith=None):
             lib.lsf_profile(1 if profile else 0)
-            rep = lsf.reinit(phi, None, None, nx, ny, nz, sweeps - 1, dx, h, tol=0.0, order=order_, arith=args.arith,
+            rep = lsf.reinit(phi, None, None, nx, ny, nz, sweeps - 1, dx, h, tol=0.0, order=order_, arith=arith or args.arith,
                              phiS=phiS)
             assert rep.count == sweeps, (rep.count, sweeps)
             return rep
 
-        def timed(order_):
+        def timed(order_, arith=None, K_=None, W_=None):
+            K_, W_ = K_ or K, W if W_ is None else W_
             phi.copy_(phi0)
-            if W > 0:
-                run(order_, W)
+            if W_ > 0:
+                run(order_, W_, arith=arith)
             barrier()
             t0 = time.perf_counter()
-            run(order_, K, profile=True)
+            run(order_, K_, profile=True, arith=arith)
             barrier()
             dt = time.perf_counter() - t0
             sw, bc, fin = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
@@ -364,6 +366,20 @@ def main() -> None:
                     "Gauss-Seidel result (5.5e-5 RMS on cube40, SURVEY.md section 0)" if other == "jacobi"
                     else "exact Gauss-Seidel ordering of the reference",
         }
+
+    if world == 1 and not args.no_secondary and not f32 and args.arith == "fast":
+        # the same ordering(s) in the reference's own arithmetic (LSF_ARITH_STRICT: bit-identical results, the drop-in's
+        # default): a shorter run, it is 2 x slower
+        KS, WS = min(K, 16), min(W, 8)
+        st = {}
+        for order_ in ("gs", "jacobi"):
+            secs, profs = timed(order_, arith="strict", K_=KS, W_=WS)
+            cells_s = float(nx - 1) * (ny - 1) * (nz - 1) * KS
+            st[order_] = {"value": cells_s / secs, "unit": "cell-updates/s", "ms_per_step": secs / KS * 1e3, "steps": KS,
+                          "warmup": WS, "roofline": roofline(profs, cells_s / KS)}
+        st["note"] = ("every operation as subs.f90 writes it (no contraction, IEEE division and square root): the field is the "
+                      "reference's bit for bit; `value` above is the FAST arithmetic (same mathematics, ~1e-16 per sweep away)")
+        out["strict_arithmetic"] = st
 
     if world == 1 and not args.no_secondary:
         # min/max-flow sweep (set3d.f90:394-462) on the same grid: 16 B per grid point per iteration
