@@ -18,6 +18,13 @@ namespace lsf {
 // Fortran MAX/MIN as compiled by flang (compare + select); STRICT only.
 __device__ __forceinline__ double fmax2(double a, double b) { return (a > b) ? a : b; }
 __device__ __forceinline__ double fmin2(double a, double b) { return (a < b) ? a : b; }
+// The same for the reinit sweep, as ONE instruction (v_max_f64 / v_min_f64) instead of a compare and two 32-bit selects:
+// identical to the compare-and-select for every pair of numbers (the second operand is a literal 0., a square or another
+// maximum at every call site, never -0, and every minimum is squared by its consumer, subs.f90:684-692, so the sign of a
+// zero cannot matter).  Only a NaN operand is treated differently (the instruction returns the other operand), and a NaN
+// reaches these only after the reference's own arithmetic has already produced one -- the sweep of its NaN STOP.
+__device__ __forceinline__ double smax(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ double smin(double a, double b) { return __builtin_fmin(a, b); }
 
 // ---------------------------------------------------------------------------------------------
 // STRICT: one axis of the WENO branch (subs.f90:509-552 / :555-598 / :601-644).
@@ -80,9 +87,9 @@ __device__ __forceinline__ void weno_axis_strict(const double q[7], double dx, b
     const double p5 = yquirk ? div_dx(r3 - r3, dx, rdx) : div_dx(r3 - r2, dx, rdx);
 
     const double epsp =
-        (1.E-6) * fmax2(p1 * p1, fmax2(p2 * p2, fmax2(p3 * p3, fmax2(p4 * p4, p5 * p5)))) + 1.E-99;
+        (1.E-6) * smax(p1 * p1, smax(p2 * p2, smax(p3 * p3, smax(p4 * p4, p5 * p5)))) + 1.E-99;
     const double epsm =
-        (1.E-6) * fmax2(p0 * p0, fmax2(p1 * p1, fmax2(p2 * p2, fmax2(p3 * p3, p4 * p4)))) + 1.E-99;
+        (1.E-6) * smax(p0 * p0, smax(p1 * p1, smax(p2 * p2, smax(p3 * p3, p4 * p4)))) + 1.E-99;
 
     const double x0p = (epsp + IS0p) * (epsp + IS0p), x0m = (epsm + IS0m) * (epsm + IS0m);
     const double x1p = (epsp + IS1p) * (epsp + IS1p), x1m = (epsm + IS1m) * (epsm + IS1m);
@@ -92,7 +99,7 @@ __device__ __forceinline__ void weno_axis_strict(const double q[7], double dx, b
     // below (x >= 1e-198) and the weights' quotients to [1e-17, 1]; with the six sums eps + IS below 1e120 every divisor,
     // numerator and quotient is also far from the exponent limits where the hardware division would rescale -- then
     // div_by is that division bit for bit.  Anything else (a diverging field on its way to NaN, NaN itself) takes `/`.
-    const double big = fmax2(fmax2(fmax2(epsp + IS0p, epsp + IS1p), epsp + IS2p), fmax2(fmax2(epsm + IS0m, epsm + IS1m), epsm + IS2m));
+    const double big = smax(smax(smax(epsp + IS0p, epsp + IS1p), epsp + IS2p), smax(smax(epsm + IS0m, epsm + IS1m), epsm + IS2m));
     if (__builtin_expect(big < 1.0e120, 1)) {
         const double a0p = div_by(1., x0p, recip_refined(x0p)), a0m = div_by(1., x0m, recip_refined(x0m));
         const double a1p = div_by(6., x1p, recip_refined(x1p)), a1m = div_by(6., x1m, recip_refined(x1m));
@@ -121,19 +128,19 @@ __device__ __forceinline__ double godunov_strict(double phic, double a, double b
                                                  double e, double f)
 {
 #pragma clang fp contract(off)
-    const double pa = fmax2(a, 0.), pb = fmax2(b, 0.), pc = fmax2(c, 0.);
-    const double pd = fmax2(d, 0.), pe = fmax2(e, 0.), pf = fmax2(f, 0.);
-    const double na = fmin2(a, 0.), nb = fmin2(b, 0.), nc = fmin2(c, 0.);
-    const double nd = fmin2(d, 0.), ne = fmin2(e, 0.), nf = fmin2(f, 0.);
+    const double pa = smax(a, 0.), pb = smax(b, 0.), pc = smax(c, 0.);
+    const double pd = smax(d, 0.), pe = smax(e, 0.), pf = smax(f, 0.);
+    const double na = smin(a, 0.), nb = smin(b, 0.), nc = smin(c, 0.);
+    const double nd = smin(d, 0.), ne = smin(e, 0.), nf = smin(f, 0.);
     double gX, gY, gZ;
     if (phic > 0.) {
-        gX = fmax2(pa * pa, nb * nb);
-        gY = fmax2(pc * pc, nd * nd);
-        gZ = fmax2(pe * pe, nf * nf);
+        gX = smax(pa * pa, nb * nb);
+        gY = smax(pc * pc, nd * nd);
+        gZ = smax(pe * pe, nf * nf);
     } else {
-        gX = fmax2(pb * pb, na * na);
-        gY = fmax2(pd * pd, nc * nc);
-        gZ = fmax2(pf * pf, ne * ne);
+        gX = smax(pb * pb, na * na);
+        gY = smax(pd * pd, nc * nc);
+        gZ = smax(pf * pf, ne * ne);
     }
     return __builtin_sqrt(gX + gY + gZ);
 }
@@ -376,9 +383,9 @@ __device__ __forceinline__ double axis_godunov(double phic, double dm, double dp
 {
     if constexpr (STRICT) {
 #pragma clang fp contract(off)
-        const double pa = fmax2(dm, 0.), pb = fmax2(dp, 0.), na = fmin2(dm, 0.), nb = fmin2(dp, 0.);
-        if (phic > 0.) return fmax2(pa * pa, nb * nb);
-        return fmax2(pb * pb, na * na);
+        const double pa = smax(dm, 0.), pb = smax(dp, 0.), na = smin(dm, 0.), nb = smin(dp, 0.);
+        if (phic > 0.) return smax(pa * pa, nb * nb);
+        return smax(pb * pb, na * na);
     } else {
         // with sg = sign(phic): max(max(sg dm, 0)^2, min(sg dp, 0)^2) is both cases of the switch (squares are
         // even); flipping a sign is one XOR on the high word instead of two selects per operand
