@@ -50,9 +50,13 @@ extern "C" {
 #define LSF_ORDER_MASK 0xff
 /* arithmetic (bit 8) */
 #define LSF_ARITH_FAST 0x000   /* restructured fp64 arithmetic (FMA, shared terms, one reciprocal   \
-                                  per WENO side); within 1e-12 RMS of LSF_ARITH_STRICT             */
+                                  per WENO side): ~1e-16 per sweep from LSF_ARITH_STRICT, within   \
+                                  1e-12 RMS of it for a thousand sweeps; over thousands of sweeps  \
+                                  the scheme itself amplifies any rounding difference at kinks of  \
+                                  the surface (isolated cells up to 1e-5 apart)  */
 #define LSF_ARITH_STRICT 0x100 /* every operation as written in subs.f90, no contraction:           \
-                                  bit-identical to the reference for LSF_ORDER_GS                  */
+                                  bit-identical to the reference for LSF_ORDER_GS (the default of  \
+                                  the Fortran shim); 1.9 x the time of LSF_ARITH_FAST              */
 
 /* ---- library / device ------------------------------------------------------------------- */
 int lsf_version(void);
