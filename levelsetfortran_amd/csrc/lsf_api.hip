@@ -68,18 +68,45 @@ int gs_ta()
     const char* e = getenv("LSF_GS_TA");
     return (e && atoi(e) == 32) ? 32 : 16;
 }
-// wavefronts per skewed tile (lsf_skew.hpp): WY x WZ adjacent 5 x 4 bundles marched in lock step, "WYxWZ" or "WY"
-void gs_skew_w(int* wy, int* wz)
+// wavefronts per skewed tile (lsf_skew.hpp): WY x WZ adjacent bundles marched in lock step, "WYxWZ" or "WY"; a leading
+// 'c' selects the one-lane-per-cell map (bundles of 16 x 4 rows: "c1x4" = 16 x 16 rows), otherwise three lanes per cell
+// (bundles of 5 x 4 rows).  *by = rows of a bundle in y (5 or 16).
+void gs_skew_w(int* wy, int* wz, int* by)
 {
     const char* e = getenv("LSF_GS_SKEW_W");
+    const bool cell = e && (e[0] == 'c' || e[0] == 'C');
+    if (cell) ++e;
     int y = 2, z = 2; // measured best at 256^3, 512^3 and 1024^3
     if (e && sscanf(e, "%dx%d", &y, &z) < 1) y = z = 2;
     if (e && !std::strchr(e, 'x')) z = 1;
     static const int ok[][2] = {{1, 1}, {2, 1}, {4, 1}, {1, 2}, {2, 2}, {4, 2}, {2, 4}};
-    *wy = *wz = 2;
+    static const int okc[][2] = {{1, 1}, {1, 2}, {1, 3}, {1, 4}};
+    if (cell) {
+        *by = 16, *wy = 1, *wz = 4;
+        for (auto& s : okc)
+            if (s[0] == y && s[1] == z) *wy = y, *wz = z;
+        return;
+    }
+    *by = 5, *wy = *wz = 2;
     for (auto& s : ok)
         if (s[0] == y && s[1] == z) *wy = y, *wz = z;
 }
+// dispatch on the tile shape: CALL(WY, WZ, BY) with compile-time arguments
+#define LSF_SK_SHAPES(CALL, wy_, wz_, by_)               \
+    do {                                                 \
+        const int shape_ = (by_)*256 + (wy_)*16 + (wz_); \
+        if (shape_ == 5 * 256 + 0x11) CALL(1, 1, 5);     \
+        else if (shape_ == 5 * 256 + 0x21) CALL(2, 1, 5); \
+        else if (shape_ == 5 * 256 + 0x41) CALL(4, 1, 5); \
+        else if (shape_ == 5 * 256 + 0x12) CALL(1, 2, 5); \
+        else if (shape_ == 5 * 256 + 0x42) CALL(4, 2, 5); \
+        else if (shape_ == 5 * 256 + 0x24) CALL(2, 4, 5); \
+        else if (shape_ == 16 * 256 + 0x11) CALL(1, 1, 16); \
+        else if (shape_ == 16 * 256 + 0x12) CALL(1, 2, 16); \
+        else if (shape_ == 16 * 256 + 0x13) CALL(1, 3, 16); \
+        else if (shape_ == 16 * 256 + 0x14) CALL(1, 4, 16); \
+        else CALL(2, 2, 5);                              \
+    } while (0)
 int gs_ny()
 {
     const char* e = getenv("LSF_GS_NY");
@@ -636,26 +663,20 @@ int reinit_f32_core(float* d_phi, const float* d_phiS_in, int nx, int ny, int nz
 }
 
 // lookup tables of a skewed tile shape (lsf_skew.hpp: sk_fill_tables), built once per shape and device
-int get_sk_tables(int wy, int wz, const uint32_t** out)
+int get_sk_tables(int wy, int wz, int by, const uint32_t** out)
 {
     Ctx& c = ctx();
-    const int key = wy * 16 + wz;
+    const int key = by * 256 + wy * 16 + wz;
     auto it = c.sk_tables.find(key);
     if (it == c.sk_tables.end()) {
         std::vector<uint32_t> h;
-#define LSF_SK_TAB(WY_, WZ_)                                                                 \
+#define LSF_SK_TAB(WY_, WZ_, BY_)                                                            \
     do {                                                                                     \
-        using T_ = SkTile<16, WY_, WZ_>;                                                     \
+        using T_ = SkTile<16, WY_, WZ_, BY_>;                                                \
         h.assign((size_t)T_::REL_WORDS + T_::OFF_WORDS, 0u);                                 \
-        sk_fill_tables<16, WY_, WZ_>(h.data());                                              \
+        sk_fill_tables<16, WY_, WZ_, BY_>(h.data());                                         \
     } while (0)
-        if (key == 0x11) LSF_SK_TAB(1, 1);
-        else if (key == 0x21) LSF_SK_TAB(2, 1);
-        else if (key == 0x41) LSF_SK_TAB(4, 1);
-        else if (key == 0x12) LSF_SK_TAB(1, 2);
-        else if (key == 0x42) LSF_SK_TAB(4, 2);
-        else if (key == 0x24) LSF_SK_TAB(2, 4);
-        else LSF_SK_TAB(2, 2);
+        LSF_SK_SHAPES(LSF_SK_TAB, wy, wz, by);
 #undef LSF_SK_TAB
         uint32_t* d = nullptr;
         HIPCHK(hipMalloc((void**)&d, h.size() * sizeof(uint32_t)));
@@ -714,10 +735,10 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     // skewed tiles need TA = 16, NY = 5 and at least two interior cells per axis
     const bool skew = sched == 3 && ta == 16 && nyc == 5 && nx >= 3 && ny >= 3 && nz >= 3;
     persist = persist && skew;
-    int wy = 1, wz = 1, nzc = 4;
+    int wy = 1, wz = 1, by = 5, nzc = 4;
     if (skew) {
-        gs_skew_w(&wy, &wz);
-        nyc = 5 * wy, nzc = 4 * wz; // rows of a tile in y and z
+        gs_skew_w(&wy, &wz, &by);
+        nyc = by * wy, nzc = 4 * wz; // rows of a tile in y and z
     }
     // Dataflow launch: the kernel marches along ITS x axis; run it on the x <-> y transposed field so that the march axis
     // is the reference's y, the axis the raster cycle flips in six of its eight transitions (a flip of the march axis
@@ -794,7 +815,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     fa.ctl = ctl;
     fa.nTiles = (long)nTi * nTj * nTk;
     fa.last_packed = tl->last;
-    if (skew && !getenv("LSF_GS_NO_TABLES") && (rc = get_sk_tables(wy, wz, &fa.tables))) return rc;
+    if (skew && !getenv("LSF_GS_NO_TABLES") && (rc = get_sk_tables(wy, wz, by, &fa.tables))) return rc;
 
     // start slot of sweep g, generated on demand (slot schedules; never transposed)
     std::vector<long> start{0};
@@ -850,7 +871,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         }
         for (int g0 = 0; g0 < max_sweeps; g0 += BATCH) {
             const int ns = std::min(BATCH, max_sweeps - g0), phase = (first_raster + g0) & 7;
-            const std::array<int, 6> key{knx, kny, nz, phase, ns, wy * 16 + wz + 256 * (int)tr + 1024 * nbuf};
+            const std::array<int, 6> key{knx, kny, nz, phase, ns, wy * 16 + wz + 256 * (int)tr + 1024 * nbuf + 8192 * by};
             auto it = c.plans.find(key);
             if (it == c.plans.end()) {
                 BatchPlan bp;
@@ -915,27 +936,25 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             // one block per tile; a block takes its tile from the ticket counter, so the grid only has to be large enough
             // (2-D: gridDim.x * blockDim.x must stay below 2^32)
             const dim3 grid((unsigned)std::min<long>(fa.total, 65536), (unsigned)((fa.total + 65535) / 65536));
-#define LSF_LAUNCH_DF(WY_, WZ_)                                                                                  \
+#define LSF_LAUNCH_DF(WY_, WZ_, BY_)                                                                             \
     do {                                                                                                         \
-        if (strict) hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, true>), grid, dim3(64 * WY_ * WZ_), 0, st, fa); \
-        else hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, false>), grid, dim3(64 * WY_ * WZ_), 0, st, fa);       \
+        if (strict) hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, BY_, true>), grid, dim3(64 * WY_ * WZ_), 0, st, fa); \
+        else hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, BY_, false>), grid, dim3(64 * WY_ * WZ_), 0, st, fa);       \
     } while (0)
-            const int shape = wy * 16 + wz;
-            if (shape == 0x11) LSF_LAUNCH_DF(1, 1);
-            else if (shape == 0x21) LSF_LAUNCH_DF(2, 1);
-            else if (shape == 0x41) LSF_LAUNCH_DF(4, 1);
-            else if (shape == 0x12) LSF_LAUNCH_DF(1, 2);
-            else if (shape == 0x42) LSF_LAUNCH_DF(4, 2);
-            else if (shape == 0x24) LSF_LAUNCH_DF(2, 4);
-            else LSF_LAUNCH_DF(2, 2);
+            LSF_SK_SHAPES(LSF_LAUNCH_DF, wy, wz, by);
 #undef LSF_LAUNCH_DF
             ++launches;
             if (g0 + BATCH < max_sweeps || d_dbg) { // stop flag between batches (later batches would exit at once anyway)
                 HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
                 if (d_dbg) {
-                    unsigned long long hd[3];
+                    unsigned long long hd[8];
                     HIPCHK(hipMemcpy(hd, d_dbg, sizeof hd, hipMemcpyDeviceToHost));
+#ifdef LSF_EXPERIMENTS
+                    if (hd[7])
+                        fprintf(stderr, "[lsf] tile phases (us per tile): row table %.2f, load %.2f, march %.2f, write back %.2f\n",
+                                hd[3] / 100.0 / hd[7], hd[4] / 100.0 / hd[7], hd[5] / 100.0 / hd[7], hd[6] / 100.0 / hd[7]);
+#endif
                     fprintf(stderr, "[lsf] dataflow batch of %d sweeps: %llu tiles, per tile: take+wait %.2f us, work+publish %.2f us\n", ns,
                             hd[2], hd[2] ? hd[0] / 100.0 / hd[2] : 0.0, hd[2] ? hd[1] / 100.0 / hd[2] : 0.0);
                 }
@@ -945,23 +964,23 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     }
     if (!marked) prof_mark(st);
     const bool slots_loop = !persist;
+#ifdef LSF_EXPERIMENTS
+    if (slots_loop && skew && getenv("LSF_TRACE_TILES")) {
+        if ((rc = ws(c.slot[S_DBG], 64))) return rc;
+        fa.dbg = (unsigned long long*)c.slot[S_DBG].p;
+        HIPCHK(hipMemsetAsync(fa.dbg, 0, 64, st));
+    }
+#endif
     auto launch_tiles = [&](int grid, hipStream_t s_) {
         if (skew) {
-#define LSF_LAUNCH_SKEW(WY_, WZ_)                                                                                          \
+#define LSF_LAUNCH_SKEW(WY_, WZ_, BY_)                                                                                     \
     do {                                                                                                                   \
         if (strict)                                                                                                        \
-            hipLaunchKernelGGL((k_reinit_gs_skew<16, WY_, WZ_, true>), dim3(grid), dim3(64 * WY_ * WZ_), 0, s_, fa);       \
+            hipLaunchKernelGGL((k_reinit_gs_skew<16, WY_, WZ_, BY_, true>), dim3(grid), dim3(64 * WY_ * WZ_), 0, s_, fa);  \
         else                                                                                                               \
-            hipLaunchKernelGGL((k_reinit_gs_skew<16, WY_, WZ_, false>), dim3(grid), dim3(64 * WY_ * WZ_), 0, s_, fa);      \
+            hipLaunchKernelGGL((k_reinit_gs_skew<16, WY_, WZ_, BY_, false>), dim3(grid), dim3(64 * WY_ * WZ_), 0, s_, fa); \
     } while (0)
-            const int shape = wy * 16 + wz;
-            if (shape == 0x11) LSF_LAUNCH_SKEW(1, 1);
-            else if (shape == 0x21) LSF_LAUNCH_SKEW(2, 1);
-            else if (shape == 0x41) LSF_LAUNCH_SKEW(4, 1);
-            else if (shape == 0x12) LSF_LAUNCH_SKEW(1, 2);
-            else if (shape == 0x42) LSF_LAUNCH_SKEW(4, 2);
-            else if (shape == 0x24) LSF_LAUNCH_SKEW(2, 4);
-            else LSF_LAUNCH_SKEW(2, 2);
+            LSF_SK_SHAPES(LSF_LAUNCH_SKEW, wy, wz, by);
 #undef LSF_LAUNCH_SKEW
             return;
         }
@@ -987,8 +1006,12 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     bool stop = false;
     for (long slot = 0; slots_loop && !stop && lo < max_sweeps; ++slot) {
         int nseg = 0, grid = 0;
+#ifdef LSF_EXPERIMENTS // never in the product library: profiles/micro builds its own copy with -DLSF_EXPERIMENTS
         // timing experiment only (results are wrong): every tile of a sweep in ONE launch = the pure work term
         static const bool nodeps = getenv("LSF_GS_NODEPS_EXPERIMENT") != nullptr;
+#else
+        constexpr bool nodeps = false;
+#endif
         for (int g = lo; g < max_sweeps && start_of(g) <= slot; ++g) {
             const long P = slot - start_of(g);
             if (P >= np) continue;
@@ -1021,6 +1044,15 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+#ifdef LSF_EXPERIMENTS
+    if (fa.dbg) {
+        unsigned long long hd[8];
+        HIPCHK(hipMemcpy(hd, fa.dbg, sizeof hd, hipMemcpyDeviceToHost));
+        if (hd[7])
+            fprintf(stderr, "[lsf] tile phases (us per tile, %llu tiles): row table %.2f, load %.2f, march %.2f, write back %.2f\n", hd[7],
+                    hd[3] / 100.0 / hd[7], hd[4] / 100.0 / hd[7], hd[5] / 100.0 / hd[7], hd[6] / 100.0 / hd[7]);
+    }
+#endif
     const int nsw = host_ctl[1];
     if (g_prof.on && g_prof.ev.size() >= 2) {
         float ms = 0;

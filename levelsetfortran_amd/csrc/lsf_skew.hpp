@@ -22,6 +22,10 @@
 
 #include "lsf_boxtile.hpp"
 
+#ifndef LSF_CELL_UNROLL
+#define LSF_CELL_UNROLL 8 // one lane per cell: marching steps per iteration of the march loop (code size vs. loop overhead)
+#endif
+
 namespace lsf {
 
 // A tile is WY x WZ adjacent 5 x 4 bundles (one wavefront each), marched in lock step: NYT = 5 WY by NZT = 4 WZ
@@ -37,12 +41,23 @@ namespace lsf {
 //   [ZD0, NR)     downstream z halo, r = ZD0 + (c' - nk) * NYT + b, c' = nk..nk+2 entries 4..21
 // (z groups padded to whole load instructions).  phiS of the bundle cells is not staged: the lanes of a cell read
 // their 16 values straight into registers.
-template <int TA, int WY, int WZ>
+//
+// Two lane maps (BY = rows of one wavefront in y; a wavefront always holds 4 rows in z):
+//   BY = 5   three lanes per cell (x, y, z derivative), 5 cells + 1 idle lane per 16-lane row: 20 cells per wavefront and step
+//   BY = 16  one lane per cell (all three derivatives): 64 cells per wavefront and step, a third of the LDS reads and none
+//            of the lane-to-lane traffic per cell, but 64 rows + halo per wavefront in LDS (two 16 x 16 tiles per CU)
+template <int TA, int WY, int WZ, int BY = 5>
 struct SkTile {
     static constexpr int W = WY * WZ;         // wavefronts per tile
     static_assert(W >= 1 && W <= 16, "1 to 16 wavefronts per tile");
-    static constexpr int NYT = 5 * WY, NZT = 4 * WZ; // rows of a tile in y and z
+    static_assert(BY == 5 || BY == 16, "three lanes per cell (5 rows) or one lane per cell (16 rows)");
+    static constexpr int BYW = BY;
+    static constexpr int NYT = BY * WY, NZT = 4 * WZ; // rows of a tile in y and z
     static constexpr int RA = TA + 6;
+    // one lane per cell: the 32 lanes of an LDS access group are 16 b x 2 c; b steps by RA = 22 doubles (the 16 b cover the
+    // even bank pairs), so an odd plane pitch puts the second c on the odd ones: conflict-free ds_read_b64 / ds_write_b64
+    static constexpr int PAD = BY == 16 ? 1 : 0;
+    static constexpr int HB = WY * BY * NZT * RA + NZT * PAD; // first halo entry
     static constexpr int RH = TA + 2;         // entries kept of a halo row
     static constexpr int NCORE = NZT * NYT;
     static constexpr int YH = 3 * NZT;
@@ -50,15 +65,17 @@ struct SkTile {
     static constexpr int YU0 = NCORE, ZU0 = YU0 + YH, YD0 = ZU0 + ZP, ZD0 = YD0 + YH;
     static constexpr int NR = (ZD0 + ZP + 4 * W - 1) / (4 * W) * (4 * W);
     static_assert(NCORE % (4 * W) == 0, "whole store instructions");
-    static constexpr int TOTAL = NCORE * RA + (NR - NCORE) * RH;
+    static constexpr int TOTAL = HB + (NR - NCORE) * RH;
+    // LDS index of entry 0 of bundle row r
+    __host__ __device__ static constexpr int core_at(int r) { return r * RA + (PAD ? (r / NYT) * PAD : 0); }
     // LDS index of entry k of row r (halo rows store entry 0 resp. 4 first)
     __host__ __device__ static constexpr int at(int r, int k)
     {
-        return r < NCORE ? r * RA + k : NCORE * RA + (r - NCORE) * RH + (r < YD0 ? k : k - 4);
+        return r < NCORE ? core_at(r) + k : HB + (r - NCORE) * RH + (r < YD0 ? k : k - 4);
     }
     __host__ __device__ static constexpr int row_at(int r)
     {
-        return r < NCORE ? r * RA : NCORE * RA + (r - NCORE) * RH - (r < YD0 ? 0 : 4);
+        return r < NCORE ? core_at(r) : HB + (r - NCORE) * RH - (r < YD0 ? 0 : 4);
     }
     // frame coordinates (bq, cq) of LDS row r of a tile with nj x nk rows (rows beyond a partial tile alias a valid row),
     // and its class: up = upstream halo, core = bundle row
@@ -90,7 +107,7 @@ struct SkTile {
     __host__ __device__ static int lane_off(int bc, int cc, int axis, bool pos, int nj, int nk, int mm)
     {
         const int dA = mm - 3, dF = pos ? dA : -dA;
-        int base = (cc * NYT + bc) * RA;
+        int base = core_at(cc * NYT + bc);
         if (axis == 1) {
             const int bq = bc + dF;
             base = row_at((bq >= 0 && bq < nj) ? cc * NYT + bq : (bq < 0 ? YU0 + cc * 3 + bq + 3 : YD0 + cc * 3 + bq - nj));
@@ -103,7 +120,7 @@ struct SkTile {
     // Tables for FULL tiles deep inside the grid (every row of the LDS image is an interior row: no clamping, no wall
     // flags), which are > 90 % of the tiles of a BASELINE-size grid.  They replace ~250 of the ~3000 vector instructions
     // a wavefront spends on a tile -- the kernel is bound by vector issue -- by two loads:
-    //   rel_tab[r][(sj > 0) * 2 + (sk > 0)] = rel_j | rel_k << 5 | (bq + cq + 3) << 10 | flags << 16   (rowtab entry of row r:
+    //   rel_tab[r][(sj > 0) * 2 + (sk > 0)] = rel_j | rel_k << 6 | (bq + cq + 3) << 12 | flags << 20   (rowtab entry of row r:
     //       offset = rel_j * sx + rel_k * sxy from the tile origin, flags as in rowtab)
     //   off_tab[tid][pos][8] (16 bit each) = lane_off(.., mm) of thread tid for a sweep running in the positive (pos = 1) or
     //       negative direction of the lane's axis
@@ -114,18 +131,21 @@ struct SkTile {
         int bq, cq, up, core;
         row_coords(r, NYT, NZT, &bq, &cq, &up, &core);
         const int rel_j = 3 + (sjpos ? bq : NYT - 1 - bq), rel_k = 3 + (skpos ? cq : NZT - 1 - cq);
-        return (uint32_t)rel_j | ((uint32_t)rel_k << 5) | ((uint32_t)(bq + cq + 3) << 10) | ((uint32_t)(up + 2 * (up | core)) << 16);
+        static_assert(NYT + 5 < 64 && NZT + 5 < 64 && NYT + NZT + 5 < 256, "fields of a rel_tab entry");
+        return (uint32_t)rel_j | ((uint32_t)rel_k << 6) | ((uint32_t)(bq + cq + 3) << 12) | ((uint32_t)(up + 2 * (up | core)) << 20);
     }
-    static constexpr int REL_WORDS = 4 * NR, OFF_WORDS = 2 * 64 * W * 4; // 32-bit words of the two tables
+    // 32-bit words of the two tables (one lane per cell: the offsets are computed, 19 per lane and tile)
+    static constexpr int REL_WORDS = 4 * NR, OFF_WORDS = BY == 5 ? 2 * 64 * W * 4 : 0;
 };
 
 // host side: fills the two tables of a tile shape (see SkTile); layout [rel_tab | off_tab]
-template <int TA, int WY, int WZ>
+template <int TA, int WY, int WZ, int BY>
 inline void sk_fill_tables(uint32_t* out)
 {
-    using T = SkTile<TA, WY, WZ>;
+    using T = SkTile<TA, WY, WZ, BY>;
     for (int r = 0; r < T::NR; ++r)
         for (int d = 0; d < 4; ++d) out[4 * r + d] = T::rel_entry(r, (d >> 1) != 0, (d & 1) != 0);
+    if (BY != 5) return;
     uint16_t* off = (uint16_t*)(out + T::REL_WORDS);
     const int NT = 64 * T::W;
     for (int pos = 0; pos < 2; ++pos)
@@ -143,17 +163,19 @@ inline void sk_fill_tables(uint32_t* out)
 struct SkPre {
     uint4 rel, off0, off1;
 };
-template <int TA, int WY, int WZ>
+template <int TA, int WY, int WZ, int BY>
 __device__ __forceinline__ SkPre sk_prefetch(const GsArgs& a)
 {
-    using T = SkTile<TA, WY, WZ>;
+    using T = SkTile<TA, WY, WZ, BY>;
     SkPre p;
     p.rel = p.off0 = p.off1 = make_uint4(0u, 0u, 0u, 0u);
     if (a.tables) {
         const int tid = threadIdx.x;
         p.rel = ((const uint4*)a.tables)[tid < T::NR ? tid : 0];
-        const uint4* o = (const uint4*)(a.tables + T::REL_WORDS) + 2 * tid;
-        p.off0 = o[0], p.off1 = o[1];
+        if constexpr (BY == 5) {
+            const uint4* o = (const uint4*)(a.tables + T::REL_WORDS) + 2 * tid;
+            p.off0 = o[0], p.off1 = o[1];
+        }
     }
     return p;
 }
@@ -163,12 +185,20 @@ __device__ __forceinline__ SkPre sk_prefetch(const GsArgs& a)
 // write-through and drained before the caller publishes the tile, phi is loaded past the non-coherent caches
 // (cdna_hip_programming.md G16).  Measured on the slot schedule: no cost (4.75 vs 4.82 ms per 512^3 sweep), whereas
 // an agent-scope acquire per tile (L2 invalidate) with plain loads made every tile 35 % slower.
-template <int TA, int WY, int WZ, bool STRICT, bool SC1>
-__device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int g, int si, int sj, int sk, const SkPre& pre)
+//
+// The load has two stages.  Stage 1 takes what the PREVIOUS sweep left (bundle rows, downstream halo, phiS): valid as soon
+// as that sweep has passed this tile's neighbourhood.  Stage 2 takes what THIS sweep's upstream tiles wrote (upstream halo,
+// entries 0..2 of the bundle rows).  wait_upstream() is called between the two with the stage-1 loads in flight: the
+// dataflow launch waits there for the upstream tiles (k_reinit_gs_persist), so that most of a tile's bytes travel while the
+// block would otherwise be idle; it returns false when the tile must be abandoned (stop flag, time-out).
+// Returns true when the tile has been computed and stored.
+template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, class WaitUp>
+__device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int g, int si, int sj, int sk, const SkPre& pre,
+                                          WaitUp&& wait_upstream)
 {
     static_assert(TA == 16, "row-per-16-lanes loader");
-    using T = SkTile<TA, WY, WZ>;
-    constexpr int RA = T::RA, NYT = T::NYT, NZT = T::NZT, W = T::W, NT = 64 * W;
+    using T = SkTile<TA, WY, WZ, BY>;
+    constexpr int NYT = T::NYT, NZT = T::NZT, W = T::W, NT = 64 * W;
     __shared__ double lds[T::TOTAL];
     __shared__ int2 rowtab[T::NR];
     __shared__ double wsum[W];
@@ -185,6 +215,13 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
         else *p_ = v_;
     };
 
+#ifdef LSF_EXPERIMENTS // phase times of a tile (thread 0; 100 MHz ticks) into dbg[3..]: row table, load, march, write back
+    unsigned long long ph_[6];
+#define LSF_PHASE(i_) ph_[i_] = __builtin_amdgcn_s_memrealtime()
+#else
+#define LSF_PHASE(i_)
+#endif
+    LSF_PHASE(0);
     const int m = packed & 0x3ff, fB = (packed >> 10) & 0x3ff, fC = (packed >> 20) & 0x3ff;
     const int tj = sj > 0 ? fB : a.nTj - 1 - fB, tk = sk > 0 ? fC : a.nTk - 1 - fC;
     const int j_lo = 1 + tj * NYT, k_lo = 1 + tk * NZT;
@@ -214,8 +251,8 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
         if (deep) {
             const uint32_t w = r == tid ? (dir == 0 ? pre.rel.x : (dir == 1 ? pre.rel.y : (dir == 2 ? pre.rel.z : pre.rel.w)))
                                         : a.tables[4 * r + dir];
-            const int o = (int)(w & 31u) * (int)sx + (int)((w >> 5) & 31u) * (int)sxy, bc_ = (int)((w >> 10) & 63u) - 3;
-            rowtab[r] = make_int2(o * 4 + (int)(w >> 16), si > 0 ? gi0 - bc_ : gi0 + bc_);
+            const int o = (int)(w & 63u) * (int)sx + (int)((w >> 6) & 63u) * (int)sxy, bc_ = (int)((w >> 12) & 255u) - 3;
+            rowtab[r] = make_int2(o * 4 + (int)(w >> 20), si > 0 ? gi0 - bc_ : gi0 + bc_);
             continue;
         }
         int bq, cq, up, core;
@@ -227,18 +264,25 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
         rowtab[r] = make_int2(o * 4 + (rin & up) + 2 * (rin & (up | core)), si > 0 ? gi0 - (bq + cq) : gi0 + (bq + cq));
     }
     __syncthreads();
+    LSF_PHASE(1);
 
     // ---- load: all global loads in flight before the first LDS write ------------------------------------
     // lane map of a wavefront: 3 lanes per cell inside each 16-lane row (5 cells + 1 idle lane), 4 rows = 4 c;
     // wavefront (wy, wz) of the tile owns rows b = 5 wy .. 5 wy + 4, c = 4 wz .. 4 wz + 3
+    // (one lane per cell, BY = 16: the 16 lanes of a row of lanes are the 16 b of the wavefront, axis is unused)
     const int t16 = lane & 15;
-    const int bl = t16 / 3, axis = t16 - 3 * bl; // t16 = 15: bl = 5, idle
-    const int b = 5 * (wave % WY) + bl, c = 4 * (wave / WY) + (lane >> 4);
-    const bool row_ok = bl < 5 && b < nj && c < nk;
+    const int bl = BY == 5 ? t16 / 3 : t16, axis = BY == 5 ? t16 - 3 * bl : 0; // BY = 5, t16 = 15: bl = 5, idle
+    const int b = BY * (wave % WY) + bl, c = 4 * (wave / WY) + (lane >> 4);
+    const bool row_ok = bl < BY && b < nj && c < nk;
     const int bc = row_ok ? b : 0, cc = row_ok ? c : 0;
     // phiS of the 16 cells this lane's cell row holds (the x lane of a cell uses them): 8 registers, refilled for
     // step t + 8 as soon as step t has used its value
-    double ps[TA / 2];
+    // (one lane per cell: CU values, refilled CU steps ahead, CU = steps per iteration of the march loop)
+    constexpr int CU = LSF_CELL_UNROLL;
+    static_assert(CU == 4 || CU == 8 || CU == 16, "steps per iteration of the one-lane-per-cell march");
+    constexpr int NPS = BY == 5 ? TA / 2 : CU;
+    double ps[NPS];
+    double colsum_prev = 0.0;
     const int2 e_ps = rowtab[cc * NYT + bc];
     auto ps_load = [&](int t) {
         return ps_t[(unsigned)(e_ps.x >> 2) + (unsigned)min(max(e_ps.y + (si > 0 ? t : -t), 0), nx)];
@@ -253,85 +297,93 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
         constexpr int NB = T::NCORE / RPI;                                // bundle rows: entries 3..18, old values
         constexpr int NU = (T::YD0 - T::YU0 + RPI - 1) / RPI;             // upstream halo: 2..17, this sweep's inside the interior
         constexpr int ND = (T::NR - T::YD0 + RPI - 1) / RPI;              // downstream halo: 4..19, old values
-        constexpr int XC = 6 * T::NCORE, XH = 2 * (T::NR - T::NCORE);     // the remaining 6 (bundle) / 2 (halo) entries
-        constexpr int NXC = (XC + NT - 1) / NT, NXH = (XH + NT - 1) / NT;
-        constexpr int NV = NB + NU + ND + NXC + NXH;
+        // the remaining entries: 0..2 (this sweep's) and 19..21 (old) of the bundle rows, 0..1 of the upstream and 20..21 of
+        // the downstream halo rows
+        constexpr int XC = 3 * T::NCORE, XHU = 2 * (T::YD0 - T::NCORE), XHD = 2 * (T::NR - T::YD0);
+        constexpr int NXC = (XC + NT - 1) / NT, NXHU = (XHU + NT - 1) / NT, NXHD = (XHD + NT - 1) / NT;
+        constexpr int NV = NB + NU + ND + 2 * NXC + NXHU + NXHD;
         double v[NV];
         int dst[NV];
         const int xx = tid & 15, rsub = tid >> 4;
         int n_ = 0;
         auto gi_of = [&](int2 e, int k) { return e.y + (si > 0 ? k - 3 : 3 - k); };
         auto off_of = [&](int2 e, int gi_r) { return (unsigned)(e.x >> 2) + (unsigned)min(max(gi_r, 0), nx); };
+        // ---- stage 1: what the previous sweep left
 #pragma unroll
         for (int u = 0; u < NB; ++u, ++n_) {
             const int r = RPI * u + rsub, k = 3 + xx;
             const int2 e = rowtab[r];
-            dst[n_] = r * RA + k;
+            dst[n_] = T::core_at(r) + k;
             v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
         }
+#pragma unroll
+        for (int u = 0; u < ND; ++u, ++n_) {
+            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = 4 + xx;
+            const int2 e = rowtab[r];
+            dst[n_] = T::HB + (r - T::NCORE) * T::RH + k - 4;
+            v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
+        }
+#pragma unroll
+        for (int u = 0; u < NXC; ++u, ++n_) { // bundle rows: entries 19..21
+            const int idx = min(tid + NT * u, XC - 1);
+            const int r = idx / 3, k = TA + 3 + idx - 3 * r;
+            const int2 e = rowtab[r];
+            dst[n_] = T::core_at(r) + k;
+            v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
+        }
+#pragma unroll
+        for (int u = 0; u < NXHD; ++u, ++n_) { // downstream halo rows: entries 20, 21
+            const int hh = min(tid + NT * u, XHD - 1);
+            const int r = T::YD0 + (hh >> 1), k = TA + 4 + (hh & 1);
+            const int2 e = rowtab[r];
+            dst[n_] = T::at(r, k);
+            v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
+        }
+#pragma unroll
+        for (int t = 0; t < NPS; ++t) ps[t] = ps_load(t);
+        if (!wait_upstream()) return false;
+        // the running RMS sum of this tile column, left by the previous tile of the column (one of the upstream tiles):
+        // requested now, used by thread 0 after the march (the dependent load used to sit between the tile's stores and its flag)
+        if (tid == 0 && m != (NYT * fB + NZT * fC) / TA) colsum_prev = ldp(a.colsum + (long)gb * ncol + (tj + (long)a.nTj * tk));
+        // ---- stage 2: what the upstream tiles of this sweep wrote (rows or entries outside the interior: the walls, from `in`)
 #pragma unroll
         for (int u = 0; u < NU; ++u, ++n_) {
             const int r = min(T::YU0 + RPI * u + rsub, T::YD0 - 1), k = 2 + xx;
             const int2 e = rowtab[r];
             const int gi_r = gi_of(e, k);
             const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 1);
-            dst[n_] = T::NCORE * RA + (r - T::NCORE) * T::RH + k;
+            dst[n_] = T::HB + (r - T::NCORE) * T::RH + k;
             v[n_] = ldp((fresh ? (const double*)out_t : in_t) + off_of(e, gi_r));
         }
 #pragma unroll
-        for (int u = 0; u < ND; ++u, ++n_) {
-            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = 4 + xx;
-            const int2 e = rowtab[r];
-            dst[n_] = T::NCORE * RA + (r - T::NCORE) * T::RH + k - 4;
-            v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
-        }
-#pragma unroll
-        for (int u = 0; u < NXC; ++u, ++n_) { // bundle rows: entries 0..2 (previous tile of the row: this sweep's) and 19..21
+        for (int u = 0; u < NXC; ++u, ++n_) { // bundle rows: entries 0..2 (the previous tile of the row)
             const int idx = min(tid + NT * u, XC - 1);
-            const int r = idx / 6, ee = idx - 6 * r;
-            const int k = ee < 3 ? ee : TA + ee;
+            const int r = idx / 3, k = idx - 3 * r;
             const int2 e = rowtab[r];
             const int gi_r = gi_of(e, k);
-            const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 2) & (ee < 3);
-            dst[n_] = r * RA + k;
+            const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 2);
+            dst[n_] = T::core_at(r) + k;
             v[n_] = ldp((fresh ? (const double*)out_t : in_t) + off_of(e, gi_r));
         }
 #pragma unroll
-        for (int u = 0; u < NXH; ++u, ++n_) { // halo rows: entries 0, 1 (upstream) or 20, 21 (downstream)
-            const int hh = min(tid + NT * u, XH - 1);
-            const int r = T::NCORE + (hh >> 1);
-            const bool upr = r < T::YD0;
-            const int k = (upr ? 0 : TA + 4) + (hh & 1);
+        for (int u = 0; u < NXHU; ++u, ++n_) { // upstream halo rows: entries 0, 1
+            const int hh = min(tid + NT * u, XHU - 1);
+            const int r = T::NCORE + (hh >> 1), k = hh & 1;
             const int2 e = rowtab[r];
             const int gi_r = gi_of(e, k);
-            const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 2) & upr;
+            const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 2);
             dst[n_] = T::at(r, k);
             v[n_] = ldp((fresh ? (const double*)out_t : in_t) + off_of(e, gi_r));
         }
 #pragma unroll
-        for (int t = 0; t < TA / 2; ++t) ps[t] = ps_load(t);
-#pragma unroll
         for (int u = 0; u < NV; ++u) lds[dst[u]] = v[u]; // duplicates (clamped indices) rewrite the same value
     }
     __syncthreads();
+    LSF_PHASE(2);
 
     // ---- per-lane constants ---------------------------------------------------------------------------------
     const int gj = j_lo + (sj > 0 ? bc : nj - 1 - bc), gk = k_lo + (sk > 0 ? cc : nk - 1 - cc);
     const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
-    const bool yquirk = axis == a.quirk_axis;
-    const int row_core = (cc * NYT + bc) * RA + 3;
-    int off[7];
-    {
-        const bool pos = (axis == 0 ? si : (axis == 1 ? sj : sk)) > 0;
-        if (deep) { // one 16-byte load instead of ~25 vector instructions per offset
-            const uint4 pk = pos ? pre.off1 : pre.off0;
-            off[0] = (int)(pk.x & 0xffffu), off[1] = (int)(pk.x >> 16), off[2] = (int)(pk.y & 0xffffu), off[3] = (int)(pk.y >> 16);
-            off[4] = (int)(pk.z & 0xffffu), off[5] = (int)(pk.z >> 16), off[6] = (int)(pk.w & 0xffffu);
-        } else {
-#pragma unroll
-            for (int mm = 0; mm < 7; ++mm) off[mm] = T::lane_off(bc, cc, axis, pos, nj, nk, mm);
-        }
-    }
     const int fx0 = X0 - bc - cc;
     double acc = 0.0;
     // per-lane bit t: the cell of step t exists (0 <= fx0 + t < nxi) / takes the WENO branch (3 < gi < nx - 4)
@@ -343,29 +395,88 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
     // 3 < gi < nx - 4 with gi = 1 + fx (si > 0: 2 < fx < nx - 5) or gi = nx - 1 - fx (si < 0: 3 < fx < nx - 4)
     const unsigned weno_bits = yz_weno ? step_mask((si > 0 ? 3 : 4) - fx0, (si > 0 ? nx - 5 : nx - 4) - fx0) : 0u;
 
-    // ---- march: TA steps, every lane busy; the wavefronts of a tile meet after every step ---------------------
+    if constexpr (BY == 5) {
+        const bool yquirk = axis == a.quirk_axis;
+        const int row_core = T::core_at(cc * NYT + bc) + 3;
+        int off[7];
+        {
+            const bool pos = (axis == 0 ? si : (axis == 1 ? sj : sk)) > 0;
+            if (deep) { // one 16-byte load instead of ~25 vector instructions per offset
+                const uint4 pk = pos ? pre.off1 : pre.off0;
+                off[0] = (int)(pk.x & 0xffffu), off[1] = (int)(pk.x >> 16), off[2] = (int)(pk.y & 0xffffu), off[3] = (int)(pk.y >> 16);
+                off[4] = (int)(pk.z & 0xffffu), off[5] = (int)(pk.z >> 16), off[6] = (int)(pk.w & 0xffffu);
+            } else {
 #pragma unroll
-    for (int t = 0; t < TA; ++t) {
-        const bool active = (act_bits >> t) & 1u;
-        double q[7];
-#pragma unroll
-        for (int mm = 0; mm < 7; ++mm) q[mm] = lds[off[mm] + t];
-        const double pS = ps[t & (TA / 2 - 1)];
-        if (t + TA / 2 < TA) ps[t & (TA / 2 - 1)] = ps_load(t + TA / 2);
-        const bool weno_ok = (weno_bits >> t) & 1u;
-        double dm, dp;
-        axis_pair<STRICT>(q, weno_ok, yquirk, dx, floor2, dm, dp);
-        const double gg = axis_godunov<STRICT>(q[3], dm, dp);
-        const double gX = gg, gY = dpp_mov<0x101>(gg), gZ = dpp_mov<0x102>(gg); // row_shl:1, row_shl:2
-        if (active && axis == 0) { // only the x lane of a cell needs the tail (|grad|, sign, Euler step)
-            const double newv = finish_update<STRICT>(q[3], gX, gY, gZ, pS, dx, inv_dx, h);
-            lds[row_core + t] = newv;
-            const double dlt = newv - q[3];
-            acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
+                for (int mm = 0; mm < 7; ++mm) off[mm] = T::lane_off(bc, cc, axis, pos, nj, nk, mm);
+            }
         }
-        __syncthreads();
+        // ---- march: TA steps, every lane busy; the wavefronts of a tile meet after every step -----------------
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            const bool active = (act_bits >> t) & 1u;
+            double q[7];
+#pragma unroll
+            for (int mm = 0; mm < 7; ++mm) q[mm] = lds[off[mm] + t];
+            const double pS = ps[t & (TA / 2 - 1)];
+            if (t + TA / 2 < TA) ps[t & (TA / 2 - 1)] = ps_load(t + TA / 2);
+            const bool weno_ok = (weno_bits >> t) & 1u;
+            double dm, dp;
+            axis_pair<STRICT>(q, weno_ok, yquirk, dx, floor2, dm, dp);
+            const double gg = axis_godunov<STRICT>(q[3], dm, dp);
+            const double gX = gg, gY = dpp_mov<0x101>(gg), gZ = dpp_mov<0x102>(gg); // row_shl:1, row_shl:2
+            if (active && axis == 0) { // only the x lane of a cell needs the tail (|grad|, sign, Euler step)
+                const double newv = finish_update<STRICT>(q[3], gX, gY, gZ, pS, dx, inv_dx, h);
+                lds[row_core + t] = newv;
+                const double dlt = newv - q[3];
+                acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---- one lane per cell: the lane evaluates the three axes of its cell; 19 LDS reads, one LDS write per cell ----
+        int ox[7], oy[7], oz[7]; // LDS index of the stencil value mm - 3 along x / y / z at step 0 (ox[3] = the cell itself)
+#pragma unroll
+        for (int mm = 0; mm < 7; ++mm) {
+            ox[mm] = T::lane_off(bc, cc, 0, si > 0, nj, nk, mm);
+            oy[mm] = T::lane_off(bc, cc, 1, sj > 0, nj, nk, mm);
+            oz[mm] = T::lane_off(bc, cc, 2, sk > 0, nj, nk, mm);
+        }
+        const bool quirk_x = a.quirk_axis == 0, quirk_y = a.quirk_axis == 1;
+#pragma unroll 1
+        for (int t0 = 0; t0 < TA; t0 += CU) {
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int t = t0 + u;
+                const bool active = (act_bits >> t) & 1u;
+                const bool weno_ok = (weno_bits >> t) & 1u;
+                double qx[7], qy[7], qz[7];
+#pragma unroll
+                for (int mm = 0; mm < 7; ++mm) qx[mm] = lds[ox[mm] + t];
+#pragma unroll
+                for (int mm = 0; mm < 7; ++mm) qy[mm] = mm == 3 ? qx[3] : lds[oy[mm] + t];
+#pragma unroll
+                for (int mm = 0; mm < 7; ++mm) qz[mm] = mm == 3 ? qx[3] : lds[oz[mm] + t];
+                const double pS = ps[u];
+                if (CU < TA && t0 + CU < TA) ps[u] = ps_load(t + CU);
+                if (active) {
+                    const double c0 = qx[3];
+                    double xm, xp, ym, yp, zm, zp;
+                    axis_pair<STRICT>(qx, weno_ok, quirk_x, dx, floor2, xm, xp);
+                    axis_pair<STRICT>(qy, weno_ok, quirk_y, dx, floor2, ym, yp);
+                    axis_pair<STRICT>(qz, weno_ok, false, dx, floor2, zm, zp);
+                    const double newv = finish_update<STRICT>(c0, axis_godunov<STRICT>(c0, xm, xp), axis_godunov<STRICT>(c0, ym, yp),
+                                                              axis_godunov<STRICT>(c0, zm, zp), pS, dx, inv_dx, h);
+                    lds[ox[3] + t] = newv;
+                    const double dlt = newv - c0;
+                    acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
+                }
+                // LDS hand-off between the wavefronts of the tile: nothing global has to be visible, do not drain the phiS loads
+                if (W > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        }
     }
 
+    LSF_PHASE(3);
     // ---- write back, fused extrapolation BC (subs.f90:859-897, closed form) --------------------------------
     const int fx_min = X0 - (nj - 1) - (nk - 1), fx_max = X0 + TA - 1;
     const bool near_wall = j_lo == 1 || j_lo + nj == ny || k_lo == 1 || k_lo + nk == nz ||
@@ -376,7 +487,7 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
         const int2 e = rowtab[r];
         const int gi = e.y + (si > 0 ? t : -t);
         const bool mine = bq < nj && cq < nk && (unsigned)(gi - 1) <= (unsigned)(nx - 2);
-        const double val0 = lds[r * RA + 3 + t];
+        const double val0 = lds[T::core_at(r) + 3 + t];
         if (mine) stp(out_t + ((unsigned)(e.x >> 2) + (unsigned)gi), val0);
         if (near_wall && mine) {
             const int gj2 = j_lo + (sj > 0 ? bq : nj - 1 - bq), gk2 = k_lo + (sk > 0 ? cq : nk - 1 - cq);
@@ -414,13 +525,22 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
     // ---- RMS: per-tile-column running sum along m (deterministic), epilogue by the last tile of the sweep ----
     if (tid == 0) {
         double* slot = a.colsum + (long)gb * ncol + (tj + (long)a.nTj * tk);
-        const int m_lo = (NYT * fB + NZT * fC) / TA;
-        stp(slot, ((m == m_lo) ? 0.0 : ldp(slot)) + acc);
+        stp(slot, colsum_prev + acc);
     }
     if (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // results are at the memory side before anyone is told
-    if (packed != a.last_packed) return;
+#ifdef LSF_EXPERIMENTS
+    if (a.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LSF_PHASE(4);
+        if (tid == 0) {
+            for (int i_ = 0; i_ < 4; ++i_) atomicAdd(a.dbg + 3 + i_, ph_[i_ + 1] - ph_[i_]);
+            atomicAdd(a.dbg + 7, 1ull);
+        }
+    }
+#endif
+    if (packed != a.last_packed) return true;
     __syncthreads();
-    if (wave != 0) return;
+    if (wave != 0) return true;
     const double* cs = a.colsum + (long)gb * ncol;
     double tsum = 0.0;
     for (int p = lane; p < ncol; p += 64) tsum += ldp(cs + p);
@@ -432,6 +552,7 @@ __device__ __forceinline__ void skew_tile(const GsArgs& a, uint32_t packed, int 
         if (rms < a.tol) st_flag(a.ctl + 0, 1);
         else if (rms != rms) { st_flag(a.ctl + 2, 1); st_flag(a.ctl + 0, 1); }
     }
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -495,15 +616,16 @@ __global__ __launch_bounds__(256) void k_build_order(uint2* __restrict__ order, 
 }
 
 // Slot schedule: one launch per time slot, one block per tile of the slot (dependencies resolved by launch order).
-template <int TA, int WY, int WZ, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY == 2 && WZ == 2 ? 5 : 1))) void k_reinit_gs_skew(GsArgs a)
+template <int TA, int WY, int WZ, int BY, bool STRICT>
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_skew(GsArgs a)
 {
     const int bx = (int)blockIdx.x;
     const int seg = (bx >= a.seg_end[0]) + (bx >= a.seg_end[1]) + (bx >= a.seg_end[2]);
     const uint32_t packed = a.seg_tiles[seg][bx - (seg ? a.seg_end[seg - 1] : 0)];
     if (ld_flag(a.ctl + 0) != 0) return; // converged or failed in an earlier launch
-    const SkPre pre = sk_prefetch<TA, WY, WZ>(a);
-    skew_tile<TA, WY, WZ, STRICT, false>(a, packed, a.seg_g[seg], a.seg_sign[seg][0], a.seg_sign[seg][1], a.seg_sign[seg][2], pre);
+    const SkPre pre = sk_prefetch<TA, WY, WZ, BY>(a);
+    skew_tile<TA, WY, WZ, BY, STRICT, false>(a, packed, a.seg_g[seg], a.seg_sign[seg][0], a.seg_sign[seg][1], a.seg_sign[seg][2], pre,
+                                             [] { return true; }); // every predecessor ran in an earlier launch
 }
 
 // Dataflow schedule: ONE launch per batch of sweeps, one block per tile.  The tiles of the batch form a list in slot
@@ -516,18 +638,24 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
 // is no deadlock whatever the dispatch order or the number of resident blocks; every spin is bounded (ctl[2] = 2 on
 // time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
 // plane_cnt[s][P]; the last tile of a hyperplane publishes planes_done[s] = P + 1.
-template <int TA, int WY, int WZ, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY == 2 && WZ == 2 ? 5 : 1))) void k_reinit_gs_persist(GsArgs a)
+template <int TA, int WY, int WZ, int BY, bool STRICT>
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_persist(GsArgs a)
 {
-    using T = SkTile<TA, WY, WZ>;
-    __shared__ int sh_task[8]; // packed tile, s | P << DF_SWEEP_BITS, go flag, raster signs of the sweep
+    using T = SkTile<TA, WY, WZ, BY>;
+    __shared__ int sh_task[8]; // packed tile, s | P << DF_SWEEP_BITS, go flag, raster signs of the sweep, go flag of stage 2
     const int tid = threadIdx.x;
     const int np = a.np;
     const int nM = a.nM;                       // tile_done[s] is indexed m + nM * (B + nTj * C)
     const long per_sweep = (long)nM * a.nTj * a.nTk;
     {
         const unsigned long long tsA = __builtin_amdgcn_s_memrealtime();
-        const SkPre pre = sk_prefetch<TA, WY, WZ>(a); // in flight while the block takes its ticket and waits for its tile
+        const SkPre pre = sk_prefetch<TA, WY, WZ, BY>(a); // in flight while the block takes its ticket and waits for its tile
+        // thread 0 only: the flags of the up to three upstream tiles (condition (a), awaited between the two load stages)
+        const int *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
+        unsigned long long t0 = 0;
+        auto give_up = [&]() { // converged, NaN or time-out elsewhere: skip, and let the blocks still to come leave at once
+            __hip_atomic_fetch_max(a.ticket, (int)a.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
         if (tid == 0) {
             const long t = (long)__hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int go = 0;
@@ -539,38 +667,36 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
                 auto m_lo = [&](int B_, int C_) { return (T::NYT * B_ + T::NZT * C_) / TA; };
                 auto m_hi = [&](int B_, int C_) { return (T::NYT * B_ + T::NYT - 1 + T::NZT * C_ + T::NZT - 1 + a.nx - 2) / TA; };
                 const int* td = a.tile_done + s * per_sweep;
-                const int* w0 = m - 1 >= m_lo(B, C) ? td + (m - 1) + (long)nM * (B + (long)a.nTj * C) : nullptr;
-                const int* w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : nullptr;
-                const int* w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : nullptr;
+                w0 = m - 1 >= m_lo(B, C) ? td + (m - 1) + (long)nM * (B + (long)a.nTj * C) : nullptr;
+                w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : nullptr;
+                w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : nullptr;
                 const int* pd = a.planes_done;
                 const int need1 = s == 0 ? 0 : min(P + a.sweep_tab[4 * s + 3], np);
                 const int need3 = s < a.nbuf ? 0 : np + 1;
                 // absent conditions point at a word that always passes (the stop flag's neighbour ctl[1] >= 0)
                 const int* always = a.ctl + 1;
-                const int* p0 = w0 ? w0 : nullptr;
                 const int* p3 = s == 0 ? always : pd + s - 1;
                 const int* p4 = s < a.nbuf ? always : pd + s - a.nbuf;
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                t0 = __builtin_amdgcn_s_memrealtime();
                 go = 1;
+                // stage 1: conditions (b) and (c) -- what this tile reads of the previous sweep is final
                 for (;;) {
-                    // five independent loads in flight at once, then one test
+                    // independent loads in flight at once, then one test
                     const int vstop = ld_flag(a.ctl + 0);
-                    const int v0 = p0 ? ld_flag(p0) : 1, v1 = w1 ? ld_flag(w1) : 1, v2 = w2 ? ld_flag(w2) : 1;
                     const int v3 = ld_flag(p3), v4 = ld_flag(p4);
-                    if (vstop != 0) { // converged, NaN or time-out elsewhere: skip, and let the blocks still to come leave at once
+                    if (vstop != 0) {
                         go = 2;
-                        __hip_atomic_fetch_max(a.ticket, (int)a.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        give_up();
                         break;
                     }
-                    const bool ok = (v0 != 0) & (v1 != 0) & (v2 != 0) & (v3 >= need1) & (v4 >= need3);
-                    if (ok) {
+                    if ((v3 >= need1) & (v4 >= need3)) {
                         // The verdict of the sweep whose result this one overwrites travels IN the word that releases
                         // it (np + 2 = that sweep, or an earlier one, raised the stop flag), so it cannot be missed by
                         // a stop-flag load that was issued before the epilogue's store and a planes_done load that was
-                        // issued after it (the five loads above are independent and relaxed).
+                        // issued after it (the loads above are independent and relaxed).
                         if (s >= a.nbuf && v4 == np + 2) {
                             go = 2;
-                            __hip_atomic_fetch_max(a.ticket, (int)a.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            give_up();
                         }
                         break;
                     }
@@ -590,12 +716,41 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(WY
         // wave-uniform values: keep them in scalar registers (an LDS read alone would make them look divergent)
         auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
         const uint32_t packed = (uint32_t)uni(sh_task[0]);
-        const int sP = uni(sh_task[1]), go = uni(sh_task[2]);
+        const int sP = uni(sh_task[1]);
+        int go = uni(sh_task[2]);
         const int s = sP & (DF_BATCH - 1), P = (int)((unsigned)sP >> DF_SWEEP_BITS);
         if (go == 0) return;
         const unsigned long long tsB = __builtin_amdgcn_s_memrealtime();
+        // stage 2, called by skew_tile with its stage-1 loads in flight: condition (a) -- the upstream tiles of this sweep
+        auto wait_upstream = [&]() -> bool {
+            if (tid == 0) {
+                int go2 = 1;
+                for (;;) {
+                    const int vstop = ld_flag(a.ctl + 0);
+                    const int v0 = w0 ? ld_flag(w0) : 1, v1 = w1 ? ld_flag(w1) : 1, v2 = w2 ? ld_flag(w2) : 1;
+                    if (vstop != 0) {
+                        go2 = 2;
+                        give_up();
+                        break;
+                    }
+                    if ((v0 != 0) & (v1 != 0) & (v2 != 0)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+                        st_flag(a.ctl + 2, 2);
+                        st_flag(a.ctl + 0, 1);
+                        go2 = 2;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                sh_task[6] = go2;
+            }
+            // LDS hand-off of the verdict only: the stage-1 loads stay in flight across the barrier
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            return uni(sh_task[6]) == 1;
+        };
         if (go == 1) {
-            skew_tile<TA, WY, WZ, STRICT, true>(a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre);
+            if (!skew_tile<TA, WY, WZ, BY, STRICT, true>(a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream))
+                go = 2;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads(); // every wave of the tile has drained its stores (and left the LDS image)

@@ -428,7 +428,8 @@ def test_dataflow_timeout_falls_back_to_slot_launches(lsf, synth, monkeypatch, c
     assert "repeating the call with slot launches" in capfd.readouterr().err
 
 
-@pytest.mark.parametrize("waves,schedule", [("2x2", None), ("2x2", "skew"), ("1", None), ("4x2", None)])
+@pytest.mark.parametrize("waves,schedule", [("2x2", None), ("2x2", "skew"), ("1", None), ("4x2", None), ("c1x4", None),
+                                            ("c1x4", "skew"), ("c1x1", None), ("c1x2", None), ("c1x3", "skew")])
 def test_reinit_odd_grid_shapes(lsf, oracle, monkeypatch, waves, schedule):
     """Grids whose extents are not multiples of the tile size (partial tiles at either end, extents below one tile,
     two interior cells per axis): every sweep direction once, bit-identical to the oracle.  2x2 tiles run the
@@ -451,7 +452,8 @@ def test_reinit_odd_grid_shapes(lsf, oracle, monkeypatch, waves, schedule):
         assert np.allclose(rep.rms, tr_ref[:9], rtol=1e-9, atol=0), npts
 
 
-@pytest.mark.parametrize("schedule", ["planes", "slots", "skew", "dataflow", "dataflow:1", "dataflow:4x2", "skew:1", "skew:2", "skew:4", "skew:1x2", "skew:2x2", "skew:4x2", "skew:2x4"])
+@pytest.mark.parametrize("schedule", ["planes", "slots", "skew", "dataflow", "dataflow:1", "dataflow:4x2", "skew:1", "skew:2", "skew:4", "skew:1x2", "skew:2x2", "skew:4x2", "skew:2x4", "dataflow:c1x4", "skew:c1x4",
+                                      "dataflow:c1x2", "skew:c1x1", "skew:c1x3"])
 def test_reinit_alternative_schedules(lsf, synth, cube40, monkeypatch, schedule):
     """The exact-GS tile graph has several executors (LSF_GS_SCHEDULE): the dataflow launch on skewed 2x2-wavefront
     tiles (one launch per batch of sweeps, dependencies resolved in the kernel; the default and what every other test
