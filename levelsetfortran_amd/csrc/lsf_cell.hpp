@@ -381,20 +381,16 @@ __device__ __forceinline__ void axis_pair(const double q[7], bool weno_ok, bool 
 template <bool STRICT>
 __device__ __forceinline__ double axis_godunov(double phic, double dm, double dp)
 {
-    if constexpr (STRICT) {
+    // phic > 0: max(max(dm, 0)^2, min(dp, 0)^2), else max(max(dp, 0)^2, min(dm, 0)^2) (subs.f90:684-692).  With
+    // sg = +-1 for phic > 0 / <= 0 both are m^2, m = max(sg dm, -sg dp, 0): min(x, 0)^2 = max(-x, 0)^2, and the larger of
+    // two squares of non-negative numbers is the square of the larger number -- the same double, so STRICT keeps its bits
+    // (products by +-1 are exact).  Seven instructions where the literal form took twelve (two of them canonicalising
+    // v_max x, x in front of the maxima of sign-flipped bit patterns).
 #pragma clang fp contract(off)
-        const double pa = smax(dm, 0.), pb = smax(dp, 0.), na = smin(dm, 0.), nb = smin(dp, 0.);
-        if (phic > 0.) return smax(pa * pa, nb * nb);
-        return smax(pb * pb, na * na);
-    } else {
-        // with sg = sign(phic): max(max(sg dm, 0)^2, min(sg dp, 0)^2) is both cases of the switch (squares are
-        // even); flipping a sign is one XOR on the high word instead of two selects per operand
-        const unsigned flip = phic > 0. ? 0u : 0x80000000u;
-        const double u = __hiloint2double(__double2hiint(dm) ^ (int)flip, __double2loint(dm));
-        const double v = __hiloint2double(__double2hiint(dp) ^ (int)flip, __double2loint(dp));
-        const double ua = __builtin_fmax(u, 0.), ub = __builtin_fmin(v, 0.);
-        return __builtin_fmax(ua * ua, ub * ub);
-    }
+    const double sg = phic > 0. ? 1.0 : -1.0;
+    const double u = dm * sg, w = dp * -sg;
+    const double m = STRICT ? smax(smax(u, w), 0.) : __builtin_fmax(__builtin_fmax(u, w), 0.);
+    return m * m;
 }
 
 // 1/sqrt(t) from v_rsq_f64 (5.2e-8 relative, measured) + one Newton step -> 4e-15 relative (FAST only)
@@ -420,10 +416,11 @@ __device__ __forceinline__ double finish_update(double phic, double gX, double g
         const double S = gX + gY + gZ; // unscaled: true value * dx^2
         // sqrt(S) = S y0 refined once with the residual (y0 = v_rsq_f64, 5e-8 relative -> ~1e-15): h (1 - gM) moves
         // phi by < 1e-18 of that
-        const double y0 = __builtin_amdgcn_rsq(S);
+        // (S = 0, a flat neighbourhood: y0 stays finite, g0 = 0 and g = 0 -- no select needed)
+        const double y0 = __builtin_amdgcn_rsq(__builtin_fmax(S, 1e-300));
         const double g0 = S * y0;
         const double g = __builtin_fma(__builtin_fma(-g0, g0, S), 0.5 * y0, g0);
-        const double gM = (S > 0. ? g : 0.) * inv_dx;
+        const double gM = g * inv_dx;
         const double sgn = pS * rsqrt_nr(__builtin_fma(pS, pS, dx * dx * gM));
         return __builtin_fma(h, sgn * (1. - gM), phic);
     }

@@ -20,8 +20,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "lsf_boxtile.hpp"
 
+// Build-time experiments on the three-lanes-per-cell march, both measured and left off (profiles/r03_gs_march_ab.txt):
+//   LSF_SKEW_ALLW = 1    a second instance of the march for tiles whose every cell takes the WENO branch (no step masks,
+//                        no first-order branch: -11 % vector instructions per step) -- 5 % SLOWER at 512^3 (2.81 against
+//                        2.67 ms per sweep): the kernel grows from 44 to 52 KB and two variants are live on a CU pair at once
+//   LSF_SKEW_UNROLL = 8  the march as a loop of two iterations of eight steps (half the code) -- 20 % slower
+#ifndef LSF_SKEW_ALLW
+#define LSF_SKEW_ALLW 0
+#endif
+#ifndef LSF_SKEW_UNROLL
+#define LSF_SKEW_UNROLL 16 // marching steps per iteration of the march loop
+#endif
 #ifndef LSF_CELL_UNROLL
 #define LSF_CELL_UNROLL 8 // one lane per cell: marching steps per iteration of the march loop (code size vs. loop overhead)
 #endif
@@ -411,27 +424,54 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
             }
         }
         // ---- march: TA steps, every lane busy; the wavefronts of a tile meet after every step -----------------
+        // Two instances.  ALLW: every cell of every step of the tile exists and takes the WENO branch (a full tile whose
+        // rows and x range lie inside 3 < index < n - 4: most tiles of a BASELINE-size grid): no per-step masks, no
+        // first-order branch, no clamp on the phiS index.  Otherwise the general form.
+        [[maybe_unused]] const bool allw = deep && j_lo + NYT - 1 < ny - 4 && k_lo + NZT - 1 < nz - 4 &&
+                          X0 - (NYT - 1) - (NZT - 1) >= (si > 0 ? 3 : 4) && X0 + TA - 1 < (si > 0 ? nx - 5 : nx - 4);
+        auto march = [&](auto allw_tag) {
+            constexpr bool ALLW = decltype(allw_tag)::value;
+            const bool x_lane = axis == 0 && bl < 5; // the lane that finishes the cell (bl = 5: the idle lane of a row of lanes)
+            unsigned ps_off = (unsigned)(e_ps.x >> 2) + (unsigned)(e_ps.y + (si > 0 ? TA / 2 : -(TA / 2))); // ALLW: index of step TA / 2
+            constexpr int SU = LSF_SKEW_UNROLL; // steps per iteration of the march loop (8: half the code of 16)
+            static_assert(SU == 8 || SU == 16, "the phiS registers are indexed by t mod 8");
+#pragma unroll 1
+            for (int t0 = 0; t0 < TA; t0 += SU)
 #pragma unroll
-        for (int t = 0; t < TA; ++t) {
-            const bool active = (act_bits >> t) & 1u;
-            double q[7];
+            for (int u_ = 0; u_ < SU; ++u_) {
+                const int t = t0 + u_;
+                const bool active = ALLW ? x_lane : (bool)((act_bits >> t) & 1u) && axis == 0;
+                double q[7];
 #pragma unroll
-            for (int mm = 0; mm < 7; ++mm) q[mm] = lds[off[mm] + t];
-            const double pS = ps[t & (TA / 2 - 1)];
-            if (t + TA / 2 < TA) ps[t & (TA / 2 - 1)] = ps_load(t + TA / 2);
-            const bool weno_ok = (weno_bits >> t) & 1u;
-            double dm, dp;
-            axis_pair<STRICT>(q, weno_ok, yquirk, dx, floor2, dm, dp);
-            const double gg = axis_godunov<STRICT>(q[3], dm, dp);
-            const double gX = gg, gY = dpp_mov<0x101>(gg), gZ = dpp_mov<0x102>(gg); // row_shl:1, row_shl:2
-            if (active && axis == 0) { // only the x lane of a cell needs the tail (|grad|, sign, Euler step)
-                const double newv = finish_update<STRICT>(q[3], gX, gY, gZ, pS, dx, inv_dx, h);
-                lds[row_core + t] = newv;
-                const double dlt = newv - q[3];
-                acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
+                for (int mm = 0; mm < 7; ++mm) q[mm] = lds[off[mm] + t];
+                const double pS = ps[u_ & (TA / 2 - 1)];
+                if (t + TA / 2 < TA) {
+                    if constexpr (ALLW) {
+                        ps[u_ & (TA / 2 - 1)] = ps_t[ps_off];
+                        ps_off += (unsigned)(si > 0 ? 1 : -1);
+                    } else {
+                        ps[u_ & (TA / 2 - 1)] = ps_load(t + TA / 2);
+                    }
+                }
+                const bool weno_ok = ALLW ? true : (bool)((weno_bits >> t) & 1u);
+                double dm, dp;
+                axis_pair<STRICT>(q, weno_ok, yquirk, dx, floor2, dm, dp);
+                const double gg = axis_godunov<STRICT>(q[3], dm, dp);
+                const double gX = gg, gY = dpp_mov<0x101>(gg), gZ = dpp_mov<0x102>(gg); // row_shl:1, row_shl:2
+                if (active) { // only the x lane of a cell needs the tail (|grad|, sign, Euler step)
+                    const double newv = finish_update<STRICT>(q[3], gX, gY, gZ, pS, dx, inv_dx, h);
+                    lds[row_core + t] = newv;
+                    const double dlt = newv - q[3];
+                    acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
+                }
+                __syncthreads();
             }
-            __syncthreads();
-        }
+        };
+#if LSF_SKEW_ALLW
+        if (allw) march(std::true_type{});
+        else
+#endif
+            march(std::false_type{});
     } else {
         // ---- one lane per cell: the lane evaluates the three axes of its cell; 19 LDS reads, one LDS write per cell ----
         int ox[7], oy[7], oz[7]; // LDS index of the stencil value mm - 3 along x / y / z at step 0 (ox[3] = the cell itself)
