@@ -338,8 +338,10 @@ def main() -> None:
             "arithmetic": args.arith,
             "parallelism": parallelism,
         },
-        "roofline": roofline(prof, per_gpu_cells_per_sweep),
+        "roofline": roofline(prof, per_gpu_cells_per_sweep) or _job_roofline(cells_total / seconds, world, bytes_per_cell),
     }
+    if world > 1:
+        out["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0  # world size as the RCCL backend reports it
     if not f32 and args.arith == "fast":
         # how long the FAST arithmetic of `value` stays within north_star's 1e-10 RMS of the reference's field, per BASELINE
         # configuration (profiles/micro/fast_valid.py on the GPU; STRICT holds it for any number of sweeps)
@@ -456,7 +458,9 @@ def main() -> None:
                 entries.append({"path": "one process per GPU, torch.distributed (RCCL)", "ordering": "jacobi", "dtype": "f64",
                                 "scaling": kind, "global_grid": r["global_grid"], "dims": r["dims"], "local_block": r["local_block"],
                                 "n_gpus": world, "value": r["cells_total"] / sec, "unit": "cell-updates/s",
-                                "ms_per_step": sec / K * 1e3, "note": note})
+                                "ms_per_step": sec / K * 1e3, "roofline": _job_roofline(r["cells_total"] / sec, world, BYTES_PER_CELL_UPDATE),
+                                "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0),
+                                "transport": dist.get_backend(), "note": note})
                 torch.cuda.empty_cache()
 
             dims = lsd.default_dims(world)
@@ -475,7 +479,7 @@ def main() -> None:
                 dist.barrier(group=host_group)
                 if rank == 0 and not shared_gpu and torch.cuda.device_count() >= world:
                     try:
-                        sp = _single_process_entries(lib, world, 64 if N < 128 else 512, K, W, args.arith)
+                        sp = _single_process_entries(lib, world, 64 if N < 128 else 512, K, W, args.arith, transports=("peer", "rccl"))
                     except Exception as e:  # noqa: BLE001
                         sp = [{"path": "one process, lsf_multi", "value": None, "error": repr(e)[:300]}]
                         failed = True
@@ -504,8 +508,18 @@ def main() -> None:
         sys.exit(3)
 
 
-def _single_process_entries(lib, world, G, K, W, arith):
-    """rank 0 only: the block-decomposed sweep through lsf_multi_* on 1, 2, 4, ... `world` devices, fixed G^3 grid."""
+def _job_roofline(cells_per_s, n_gpus, bytes_per_cell):
+    """north_star: every multi-GPU number "as absolute numbers and as fraction of the HBM roofline" -- the job's algorithmic
+    bytes per second against the sum of the HBM peaks of the GPUs it ran on (wall clock, halo exchange included)"""
+    ach = cells_per_s * bytes_per_cell / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS * n_gpus, "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * n_gpus),
+            "note": f"{bytes_per_cell:.0f} B x cell-updates/s of the whole job / ({n_gpus} x {HBM_PEAK_GBS:.0f} GB/s); wall clock of the "
+                    "K sweeps, not a kernel time"}
+
+
+def _single_process_entries(lib, world, G, K, W, arith, transports=("peer",)):
+    """rank 0 only: the block-decomposed sweep through lsf_multi_* on 1, 2, 4, ... `world` devices, fixed G^3 grid, once per
+    transport ("peer": peer copies; "rccl": ncclSend / ncclRecv behind the C ABI, needs a device per block)."""
     import numpy as np
     import torch
 
@@ -521,11 +535,14 @@ def _single_process_entries(lib, world, G, K, W, arith):
         counts.append(world)
     n = G - 1
     mode = _lib.LSF_ORDER_JACOBI | (_lib.LSF_ARITH_STRICT if arith == "strict" else _lib.LSF_ARITH_FAST)
-    for nd in counts:
+    for nd, tp in [(c, t) for t in transports for c in counts]:
+        if tp == "rccl" and nd == 1:
+            continue  # no neighbour, no message: the peer entry says it all
         devs = (ctypes.c_int * nd)(*range(nd))
         M = ctypes.c_void_p()
         _lib.check(lib.lsf_multi_create(n, n, n, devs, nd, None, 0, ctypes.byref(M)))
         try:
+            _lib.check(lib.lsf_multi_configure(M, 8, _lib.LSF_TRANSPORT_RCCL if tp == "rccl" else _lib.LSF_TRANSPORT_PEER))
             dx = h = None
             for r in range(nd):
                 g0, ext = (ctypes.c_int * 3)(), (ctypes.c_int * 3)()
@@ -545,10 +562,15 @@ def _single_process_entries(lib, world, G, K, W, arith):
             _lib.check(lib.lsf_multi_run(M, K - 1, dx, h, 0.0, mode, ctypes.byref(done), None, 0))
             sec = time.perf_counter() - t0
             assert done.value == K, (done.value, K)
-            dims = [1, 1, 1]
-            out.append({"path": "one process, lsf_multi (C ABI): thread + 2 streams per device, peer-copied halos", "ordering": "jacobi",
-                        "dtype": "f64", "scaling": "strong", "global_grid": [G, G, G], "n_gpus": nd,
-                        "value": float(n - 1) ** 3 * K / sec, "unit": "cell-updates/s", "ms_per_step": sec / K * 1e3,
+            rr, he, hc = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
+            _lib.check(lib.lsf_multi_info(M, None, None, ctypes.byref(rr), None, ctypes.byref(he), ctypes.byref(hc), None, None))
+            val = float(n - 1) ** 3 * K / sec
+            out.append({"path": "one process, lsf_multi (C ABI): thread + 2 streams per device, halos by "
+                                + ("RCCL ncclSend / ncclRecv" if tp == "rccl" else "peer copies"), "ordering": "jacobi",
+                        "dtype": "f64", "scaling": "strong", "global_grid": [G, G, G], "n_gpus": nd, "transport": tp,
+                        "rccl_ranks": rr.value, "value": val, "unit": "cell-updates/s", "ms_per_step": sec / K * 1e3,
+                        "roofline": _job_roofline(val, nd, BYTES_PER_CELL_UPDATE),
+                        "host_enqueue_ms_per_step": he.value / K * 1e3, "host_calls_ms_per_step": hc.value / K * 1e3,
                         "note": "the call returns after the last sweep has finished on every device (the run includes its own "
                                 "thread start-up and final synchronisation)"})
         finally:

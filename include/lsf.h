@@ -259,6 +259,32 @@ int lsf_multi_upload_block(lsf_multi *m, int r, const void *d_block);   /* devic
 int lsf_multi_run(lsf_multi *m, int iter, double dx, double h, double tol, int mode, int *sweeps_done, double *rms_trace,
                   int trace_cap);                                       /* continues from the current block fields */
 int lsf_multi_gather(lsf_multi *m, void *host_phi);                     /* owned points of every block -> host     */
+/* How the blocks talk and how often the host looks at the RMS.
+ *   check_every  1..64 sweeps per judging window (default 8): the host threads only enqueue inside a window and read
+ *                the window's block sums one window late; a run with tol > 0 keeps the field at the start of the last
+ *                two windows and, when a window holds the stop sweep, repeats the sweeps from its start to that sweep:
+ *                field, sweep count and RMS trace are those of a driver that looks after every sweep (subs.f90:915).
+ *   transport    LSF_TRANSPORT_PEER  one peer copy per neighbour and sweep (hipMemcpyPeerAsync, xGMI between the devices
+ *                                    of a node), events + a host hand-shake of the two neighbours' threads; works with
+ *                                    several blocks on one device (default)
+ *                LSF_TRANSPORT_RCCL  ncclGroupStart / ncclSend + ncclRecv per neighbour / ncclGroupEnd on the block's
+ *                                    communication stream, one communicator per block (ncclCommInitAll over the device
+ *                                    list; librccl.so is loaded on first use); needs a distinct device per block
+ *                LSF_TRANSPORT_MOCK  test aid: the RCCL schedule with a stand-in for the library (pull copies) that runs
+ *                                    with several blocks on one device
+ * lsf_multi_defaults sets what lsf_multi_create / lsf_reinit_multi start from (the environment variables
+ * LSF_MULTI_CHECK_EVERY and LSF_MULTI_TRANSPORT = peer | rccl | mock override it).  lsf_multi_info: NULL for what is not
+ * wanted; rccl_ranks = communicators held (0 unless the RCCL transport is on); host_enqueue_s = the longest any block's
+ * thread spent enqueuing during the last lsf_multi_run (waits for its neighbours' threads and, when blocks share a device,
+ * for that device's enqueue lock included), host_calls_s = the longest any thread spent inside the runtime / library calls
+ * themselves, wall_s = that run's wall clock. */
+#define LSF_TRANSPORT_PEER 0
+#define LSF_TRANSPORT_RCCL 1
+#define LSF_TRANSPORT_MOCK 2
+int lsf_multi_defaults(int check_every, int transport);
+int lsf_multi_configure(lsf_multi *m, int check_every, int transport);
+int lsf_multi_info(const lsf_multi *m, int *check_every, int *transport, int *rccl_ranks, int *rccl_version,
+                   double *host_enqueue_s, double *host_calls_s, double *wall_s, int *sweeps_enqueued);
 
 /* ---- single precision (BASELINE.json configuration 5: 1536^3 fp32 on 2x2x2 GPUs) -------------------
  * The reference is fp64 only (Makefile:4, -fdefault-real-8): there is no fp32 field to be identical to,

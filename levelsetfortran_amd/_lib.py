@@ -20,6 +20,7 @@ LSF_ARITH_FAST, LSF_ARITH_STRICT = 0x000, 0x100
 
 
 LSF_MIRROR_TRUST, LSF_MIRROR_LAZY = 1, 2  # include/lsf.h: lsf_mirror flags
+LSF_TRANSPORT_PEER, LSF_TRANSPORT_RCCL, LSF_TRANSPORT_MOCK = 0, 1, 2  # include/lsf.h: lsf_multi_configure
 
 
 class LsfBox(ctypes.Structure):
@@ -87,6 +88,10 @@ SIGNATURES = {
     "lsf_multi_upload_block": (c_int, [c_void_p, c_int, c_void_p]),
     "lsf_multi_run": (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_int, POINTER(c_int), c_void_p, c_int]),
     "lsf_multi_gather": (c_int, [c_void_p, c_void_p]),
+    "lsf_multi_defaults": (c_int, [c_int, c_int]),
+    "lsf_multi_configure": (c_int, [c_void_p, c_int, c_int]),
+    "lsf_multi_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_double),
+                                POINTER(c_double), POINTER(c_double), POINTER(c_int)]),
     "lsf_jacobi_sweep_box": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3,
                                      c_double, c_double, c_int, c_void_p, c_void_p]),
     "lsf_bc_box": (c_int, [c_void_p, c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_double, c_void_p,

@@ -2195,7 +2195,108 @@ int lsf_box_reserve(void* stream, size_t max_partials)
 // ---- one process, every GPU: lsf_multi_* / lsf_reinit_multi (lsf_multi.hpp) ------------------------------
 #include "lsf_multi.hpp"
 
+namespace lsfm {
+bool Rccl::load(std::string* err)
+{
+    if (lib) return true;
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+    }
+    if (!lib) {
+        *err = std::string("RCCL transport requested but librccl.so cannot be loaded: ") + dlerror();
+        return false;
+    }
+    auto sym = [&](const char* n) { return dlsym(lib, n); };
+    GetVersion = (int (*)(int*))sym("ncclGetVersion");
+    GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    CommInitAll = (int (*)(void**, int, const int*))sym("ncclCommInitAll");
+    CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+    GroupStart = (int (*)())sym("ncclGroupStart");
+    GroupEnd = (int (*)())sym("ncclGroupEnd");
+    Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
+    Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
+    if (!GetErrorString || !CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv) {
+        *err = "librccl.so lacks a symbol of the point-to-point API";
+        dlclose(lib);
+        lib = nullptr;
+        return false;
+    }
+    if (GetVersion) (void)GetVersion(&version);
+    return true;
+}
+Rccl::~Rccl()
+{
+    for (void* c : comms)
+        if (c && CommDestroy) (void)CommDestroy(c);
+    comms.clear();
+    // the library stays loaded: RCCL keeps threads and device state of its own
+}
+} // namespace lsfm
+
+// process-wide defaults of lsf_multi_create (lsf_multi_defaults; LSF_MULTI_TRANSPORT = peer | rccl | mock and
+// LSF_MULTI_CHECK_EVERY in the environment override them: the Fortran host has no other way in)
+static int g_multi_check_every = 8, g_multi_transport = LSF_TRANSPORT_PEER;
+
 extern "C" {
+
+int lsf_multi_defaults(int check_every, int transport)
+{
+    if (check_every < 1 || check_every > lsfm::MAX_CHECK) return fail(LSF_ERR_INVALID, "check_every must be 1..64");
+    if (transport != LSF_TRANSPORT_PEER && transport != LSF_TRANSPORT_RCCL && transport != LSF_TRANSPORT_MOCK)
+        return fail(LSF_ERR_INVALID, "unknown transport");
+    g_multi_check_every = check_every, g_multi_transport = transport;
+    return LSF_OK;
+}
+
+int lsf_multi_configure(lsf_multi* M, int check_every, int transport)
+{
+    if (!M) return fail(LSF_ERR_INVALID, "NULL pointer");
+    if (check_every < 1 || check_every > lsfm::MAX_CHECK) return fail(LSF_ERR_INVALID, "check_every must be 1..64");
+    if (transport != LSF_TRANSPORT_PEER && transport != LSF_TRANSPORT_RCCL && transport != LSF_TRANSPORT_MOCK)
+        return fail(LSF_ERR_INVALID, "unknown transport");
+    if (transport == LSF_TRANSPORT_RCCL && M->rccl.comms.empty()) {
+        // one communicator per block; RCCL wants every rank of a process on a device of its own
+        for (int a = 0; a < M->ndev; ++a)
+            for (int b = a + 1; b < M->ndev; ++b)
+                if (M->devs[a] == M->devs[b])
+                    return fail(LSF_ERR_INVALID, "the RCCL transport needs a distinct device per block (use the peer transport to share a device)");
+        std::string err;
+        if (!M->rccl.load(&err)) return fail(LSF_ERR_HIP, err);
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        M->rccl.comms.assign((size_t)M->ndev, nullptr);
+        const int rc = M->rccl.CommInitAll(M->rccl.comms.data(), M->ndev, M->devs.data());
+        if (cur >= 0) (void)hipSetDevice(cur);
+        if (rc != 0) {
+            M->rccl.comms.clear();
+            return fail(LSF_ERR_HIP, std::string("ncclCommInitAll: ") + M->rccl.GetErrorString(rc));
+        }
+    }
+    M->check_every = check_every, M->transport = transport;
+    return LSF_OK;
+}
+
+int lsf_multi_info(const lsf_multi* M, int* check_every, int* transport, int* rccl_ranks, int* rccl_version, double* host_enqueue_s,
+                   double* host_calls_s, double* wall_s, int* sweeps_enqueued)
+{
+    if (!M) return fail(LSF_ERR_INVALID, "NULL pointer");
+    if (check_every) *check_every = M->check_every;
+    if (transport) *transport = M->transport;
+    if (rccl_ranks) *rccl_ranks = (int)M->rccl.comms.size();
+    if (rccl_version) *rccl_version = M->rccl.version;
+    double he = 0.0;
+    for (auto& R : M->r64) he = std::max(he, R.host_enqueue_s);
+    for (auto& R : M->r32) he = std::max(he, R.host_enqueue_s);
+    double hc = 0.0;
+    for (auto& R : M->r64) hc = std::max(hc, R.host_calls_s);
+    for (auto& R : M->r32) hc = std::max(hc, R.host_calls_s);
+    if (host_calls_s) *host_calls_s = hc;
+    if (host_enqueue_s) *host_enqueue_s = he;
+    if (wall_s) *wall_s = M->last_wall_s;
+    if (sweeps_enqueued) *sweeps_enqueued = M->last_sweeps_enqueued;
+    return LSF_OK;
+}
 
 // the lsf_multi_* calls visit other devices: the calling thread gets its own device back (HIP's and the library's)
 struct DeviceRestore {
@@ -2260,6 +2361,14 @@ int lsf_multi_create(int nx, int ny, int nz, const int* devices, int ndev, const
         return LSF_OK;
     };
     rc = f32 ? build(M->r32) : build(M->r64);
+    if (!rc) {
+        int ce = g_multi_check_every, tp = g_multi_transport;
+        if (const char* e = getenv("LSF_MULTI_CHECK_EVERY")) ce = std::min(std::max(atoi(e), 1), (int)lsfm::MAX_CHECK);
+        if (const char* e = getenv("LSF_MULTI_TRANSPORT"))
+            tp = !std::strcmp(e, "rccl") ? LSF_TRANSPORT_RCCL : (!std::strcmp(e, "mock") ? LSF_TRANSPORT_MOCK : LSF_TRANSPORT_PEER);
+        if (const char* e = getenv("LSF_MULTI_GRAPHS")) M->graphs = atoi(e) != 0; // default off: measured slower, see lsf_multi.hpp
+        rc = lsf_multi_configure(M, ce, tp);
+    }
     if (rc) {
         const std::string keep = g_err;
         lsf_multi_destroy(M);

@@ -352,40 +352,75 @@ class DistributedReinit:
             self.dist.all_reduce(self.sumsq, op=self.dist.ReduceOp.SUM, group=self.group)
         return self.sumsq
 
-    def run(self, phi, iter: int, tol: float = 1.0e-5, check_every: int = 1):
+    def run(self, phi, iter: int, tol: float = 1.0e-5, check_every: int = 8):
         """reinit semantics (subs.f90:735-928) on the decomposed field: at most iter+1 sweeps, stop when
         RMS < tol.  phi is this rank's local box (ghost layers included); returns (result, sweeps, rms list).
 
-        The RMS of sweep s is read on the host while sweep s + 1 is already enqueued ("may be
-        checked one sweep late"), so the device never waits for the host; a sweep enqueued past the stop sweep writes the
-        buffer the result is not in.  check_every is kept for callers of the first version and ignored.
+        The host looks at the RMS once per window of `check_every` sweeps, one window late ("may be
+        checked ... late"): inside a window it only enqueues, the block sums of the window's sweeps go into one device
+        vector, ONE all_reduce and ONE device-to-host read per window.  A run that can stop (tol > 0) keeps the field at the
+        start of the last two windows; when a window turns out to hold the stop sweep, the sweeps from its start to that
+        sweep are run again: result, sweep count and trace are those of a driver that looks after every sweep (the same
+        scheme as lsf_multi_run, csrc/lsf_multi.hpp).
         """
         from ._lib import LsfNaNError
 
+        K = max(1, min(int(check_every), 64))
         phiS = phi.clone()
         bufs = [phi, phi.clone()]
-        rms_hist, pending = [], []
-        done_at = None
+        keep = tol > 0.0
+        snaps = [None, None]
+        rms_hist = []
+        live = self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1
 
-        def judge(upto):
-            nonlocal done_at
-            while pending and len(rms_hist) < upto and done_at is None:
-                q = float(pending.pop(0).item()) / self.den  # the wrapped INTEGER*4 product is negative for some grids:
+        def enqueue_window(c0, n, w):
+            sums = self.be.zeros(K)
+            if keep:
+                if snaps[w & 1] is None:
+                    snaps[w & 1] = bufs[c0 & 1].clone()
+                else:
+                    snaps[w & 1].copy_(bufs[c0 & 1])
+            for j in range(n):
+                s = c0 + j
+                self.sweep(bufs[s & 1], bufs[(s + 1) & 1], phiS)
+                sums[j:j + 1].copy_(self.sumsq)  # compute stream: behind the sweep's reduction
+            if live:
+                self.dist.all_reduce(sums, op=self.dist.ReduceOp.SUM, group=self.group)
+            return sums
+
+        def judge(sums, c0, n):
+            """first sweep of the window that ends the run, or None"""
+            vals = sums[:n].tolist()  # the one host read of the window
+            for j, v in enumerate(vals):
+                q = float(v) / self.den  # the wrapped INTEGER*4 product is negative for some grids:
                 rms = math.sqrt(q) if q >= 0 else float("nan")  # NaN like the single-domain path (and the reference)
                 rms_hist.append(rms)
                 if rms < tol or rms != rms:
-                    done_at = len(rms_hist)
+                    return c0 + j
+            return None
 
-        for s in range(iter + 1):
-            a_in, a_out = bufs[s & 1], bufs[(s + 1) & 1]
-            self.sweep(a_in, a_out, phiS)
-            pending.append(self.rms_async().clone())
-            judge(s)  # sweeps 0 .. s-1
-            if done_at is not None:
-                break
-        judge(iter + 1)
-        nsw = done_at if done_at is not None else len(rms_hist)
+        s, w, stop_at = 0, 0, None
+        pending = None  # (sums, c0, n) of the window enqueued last
+        max_sweeps = iter + 1
+        while s < max_sweeps and stop_at is None:
+            c0, n = s, min(K, max_sweeps - s)
+            cur = (enqueue_window(c0, n, w), c0, n)
+            s += n
+            if pending is not None:
+                stop_at = judge(*pending)  # one window late: window w is already in the queues
+            pending = cur
+            w += 1
+        if stop_at is None and pending is not None:
+            stop_at = judge(*pending)
         self.be.synchronize()
+        nsw = stop_at + 1 if stop_at is not None else len(rms_hist)
+        if stop_at is not None and nsw < s and keep:
+            # sweeps beyond the stop sweep have overwritten both buffers: back to the start of its window, repeat up to it
+            wv, c0 = stop_at // K, (stop_at // K) * K
+            bufs[c0 & 1].copy_(snaps[wv & 1])
+            for t in range(c0, stop_at + 1):
+                self.sweep(bufs[t & 1], bufs[(t + 1) & 1], phiS)
+            self.be.synchronize()
         if nsw and rms_hist[nsw - 1] != rms_hist[nsw - 1]:
             raise LsfNaNError(1, "RMS became NaN (the reference STOPs here, subs.f90:926)")
         return bufs[nsw & 1], nsw, rms_hist[:nsw]

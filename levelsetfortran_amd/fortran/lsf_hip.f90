@@ -43,6 +43,10 @@
 !                               !   see DESIGN.md section 2 for what that becomes over thousands of sweeps)
 !     devices = 0, 1, 2, 3      ! order = 'jacobi' only: reinit runs block-decomposed on these GPUs, one block each
 !                               !   (lsf_reinit_multi; a device may be listed more than once); unset: one GPU
+!     transport = 'peer'        ! how the blocks exchange their 3-cell halos: 'peer' (peer copies, default) | 'rccl'
+!                               !   (ncclSend / ncclRecv over xGMI; needs a distinct device per block)
+!     check_every = 8           ! sweeps between two looks of the host at the RMS of a block-decomposed run (1..64;
+!                               !   the stop sweep, the field and the printed residuals do not depend on it)
 !     resident = 2              ! 0: every seam copies its arrays in and out (default of the C ABI)
 !                               ! 1: skip the host-to-device copy of an array the last seam left on the device
 !                               ! 2: (default here) ... and leave results on the device until the host needs them:
@@ -51,7 +55,7 @@
 !
 ! Every entry is optional; environment variables of the same meaning (LSF_DX, LSF_DD,
 ! LSF_DD_{X,Y,Z}_{LO,HI}, LSF_REINIT_ITER, LSF_MINMAX_ITER, LSF_REINIT2_ITER, LSF_ORDER,
-! LSF_ARITH, LSF_RESIDENT, LSF_DEVICES="0,1,2,3") override the namelist.
+! LSF_ARITH, LSF_RESIDENT, LSF_DEVICES="0,1,2,3", LSF_MULTI_TRANSPORT, LSF_MULTI_CHECK_EVERY) override the namelist.
 !*************************************************************************************!
 MODULE lsf_hip
 
@@ -69,7 +73,8 @@ LOGICAL, SAVE :: nml_loaded = .FALSE.
 REAL, SAVE :: nml_dx = -1.
 INTEGER, SAVE :: nml_dd = -1, nml_dd_lo(3) = -1, nml_dd_hi(3) = -1
 INTEGER, SAVE :: nml_reinit_iter = -1, nml_minmax_iter = -1, nml_reinit2_iter = -1
-CHARACTER(LEN=16), SAVE :: nml_order = ' ', nml_arith = ' '
+CHARACTER(LEN=16), SAVE :: nml_order = ' ', nml_arith = ' ', nml_transport = ' '
+INTEGER, SAVE :: nml_check_every = 8
 INTEGER, SAVE :: nml_resident = -1
 INTEGER(c_int), SAVE :: nml_devices(16) = -1
 LOGICAL, SAVE :: mirror_set = .FALSE.
@@ -99,6 +104,12 @@ INTERFACE
       REAL(c_double), INTENT(OUT) :: rms_trace(*)
       INTEGER(c_int) :: rc
    END FUNCTION lsf_reinit_multi
+   ! int lsf_multi_defaults(int check_every, int transport)   transport: 0 peer copies, 1 RCCL
+   FUNCTION lsf_multi_defaults(check_every,transport) BIND(C,NAME='lsf_multi_defaults') RESULT(rc)
+      IMPORT :: c_int
+      INTEGER(c_int), VALUE :: check_every,transport
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_multi_defaults
    FUNCTION lsf_minmax(phi,phiNB,phiSB,nx,ny,nz,iter,dx,h1,tol,mode,iters_done,rms_trace,trace_cap) &
             BIND(C,NAME='lsf_minmax') RESULT(rc)
       IMPORT :: c_int, c_double
@@ -208,6 +219,10 @@ mode = 0
 v = nml_order
 CALL get_environment_variable('LSF_ORDER',v,STATUS=st)
 IF (st /= 0) v = nml_order
+IF (LEN_TRIM(v) > 0 .AND. TRIM(v) /= 'gs' .AND. TRIM(v) /= 'jacobi') THEN
+   PRINT*, " liblsf_hip: order must be 'gs' or 'jacobi', not ",TRIM(v)
+   STOP 1
+END IF
 IF (TRIM(v) == 'jacobi') mode = mode + LSF_ORDER_JACOBI
 CALL get_environment_variable('LSF_ARITH',v,STATUS=st)
 IF (st /= 0) v = nml_arith
@@ -224,11 +239,11 @@ END FUNCTION lsf_mode
 !*************************************************************************************!
 SUBROUTINE lsf_load_inputs()
 REAL :: dx
-INTEGER :: dd,dd_lo(3),dd_hi(3),reinit_iter,minmax_iter,reinit2_iter,ios,u,resident,devices(16)
-CHARACTER(LEN=16) :: order,arith
+INTEGER :: dd,dd_lo(3),dd_hi(3),reinit_iter,minmax_iter,reinit2_iter,ios,u,resident,devices(16),check_every
+CHARACTER(LEN=16) :: order,arith,transport
 CHARACTER(LEN=1024) :: path
 LOGICAL :: there
-NAMELIST /lsf_inputs/ dx,dd,dd_lo,dd_hi,reinit_iter,minmax_iter,reinit2_iter,order,arith,resident,devices
+NAMELIST /lsf_inputs/ dx,dd,dd_lo,dd_hi,reinit_iter,minmax_iter,reinit2_iter,order,arith,resident,devices,transport,check_every
 IF (nml_loaded) RETURN
 nml_loaded = .TRUE.
 path = ' '
@@ -245,6 +260,7 @@ END IF
 dx = nml_dx; dd = nml_dd; dd_lo = nml_dd_lo; dd_hi = nml_dd_hi
 reinit_iter = nml_reinit_iter; minmax_iter = nml_minmax_iter; reinit2_iter = nml_reinit2_iter
 order = nml_order; arith = nml_arith; resident = nml_resident; devices = nml_devices
+transport = nml_transport; check_every = nml_check_every
 u = 47
 OPEN(UNIT=u,FILE=TRIM(path),STATUS='old',ACTION='read',IOSTAT=ios)
 IF (ios == 0) READ(u,NML=lsf_inputs,IOSTAT=ios)
@@ -256,6 +272,7 @@ CLOSE(u)
 nml_dx = dx; nml_dd = dd; nml_dd_lo = dd_lo; nml_dd_hi = dd_hi
 nml_reinit_iter = reinit_iter; nml_minmax_iter = minmax_iter; nml_reinit2_iter = reinit2_iter
 nml_order = order; nml_arith = arith; nml_resident = resident; nml_devices = devices
+nml_transport = transport; nml_check_every = check_every
 PRINT*, " Run parameters read from ",TRIM(path)
 END SUBROUTINE lsf_load_inputs
 
@@ -326,6 +343,12 @@ CALL lsf_device_list(devs,nd)
 IF (nd >= 2 .AND. IAND(mode,LSF_ORDER_JACOBI) /= 0) THEN
    ! one block per listed GPU, halos peer to peer, same result as one GPU (include/lsf.h: lsf_reinit_multi)
    PRINT*, " Reinit block-decomposed over ",nd," devices "
+   IF (LEN_TRIM(nml_transport) > 0 .AND. TRIM(nml_transport) /= 'peer' .AND. TRIM(nml_transport) /= 'rccl') THEN
+      PRINT*, " liblsf_hip: transport must be 'peer' or 'rccl', not ",TRIM(nml_transport)
+      STOP 1
+   END IF
+   rc = lsf_multi_defaults(nml_check_every,MERGE(1,0,TRIM(nml_transport) == 'rccl'))
+   IF (rc /= LSF_OK) CALL lsf_fail('lsf_multi_defaults',rc)
    rc = lsf_reinit_multi(phi,nx,ny,nz,iter,dx,h,1.E-5,mode,devs,nd,C_NULL_PTR,done,trace,iter+1)
    IF (rc /= LSF_OK .AND. rc /= LSF_ERR_NAN) CALL lsf_fail('lsf_reinit_multi',rc)
 ELSE

@@ -263,13 +263,19 @@ def advectNodes(phi, phiSB, nx: int, ny: int, nz: int, dx: float, xLo, surfXX, i
     _lib.check(rc)
 
 
+TRANSPORTS = {"peer": _lib.LSF_TRANSPORT_PEER, "rccl": _lib.LSF_TRANSPORT_RCCL, "mock": _lib.LSF_TRANSPORT_MOCK}
+
+
 def reinit_multi(phi, nx: int, ny: int, nz: int, iter: int, dx: float, h: float, devices, *, dims=None,
-                 tol: float = REINIT_TOL, arith: str = "fast") -> SweepReport:
+                 tol: float = REINIT_TOL, arith: str = "fast", check_every: int = 8, transport: str = "peer") -> SweepReport:
     """reinit on every device of `devices` from ONE process (include/lsf.h: lsf_reinit_multi; the call site
     set3d.f90:308 for a host that wants all the GPUs of the node).  phi: Fortran-ordered numpy array, float64 or
     float32, updated in place.  Jacobi ordering (the ordering that shards); the result is bit-identical to
-    reinit(..., order="jacobi") on one device.  A device may be named more than once (several blocks share it)."""
+    reinit(..., order="jacobi") on one device.  A device may be named more than once (several blocks share it).
+    check_every: sweeps between two looks at the RMS (the stop sweep, the field and the trace do not depend on it);
+    transport: "peer" (peer copies), "rccl" (ncclSend / ncclRecv, a distinct device per block) or "mock" (test aid)."""
     lib = _lib.load()
+    _lib.check(lib.lsf_multi_defaults(int(check_every), TRANSPORTS[transport]))
     cap = int(iter) + 1
     trace = np.zeros(max(cap, 1), dtype=np.float64)
     done = ctypes.c_int(0)
@@ -279,8 +285,11 @@ def reinit_multi(phi, nx: int, ny: int, nz: int, iter: int, dx: float, h: float,
     f32 = isinstance(phi, np.ndarray) and phi.dtype == np.float32
     p = _host_ptr(phi, np.float32 if f32 else np.float64, nx, ny, nz, "phi")
     fn = lib.lsf_reinit_multi_f32 if f32 else lib.lsf_reinit_multi
-    rc = fn(p, nx, ny, nz, int(iter), float(dx), float(h), float(tol), mode, devs, len(devices), dm, ctypes.byref(done),
-            trace.ctypes.data, cap)
+    try:
+        rc = fn(p, nx, ny, nz, int(iter), float(dx), float(h), float(tol), mode, devs, len(devices), dm, ctypes.byref(done),
+                trace.ctypes.data, cap)
+    finally:
+        lib.lsf_multi_defaults(8, _lib.LSF_TRANSPORT_PEER)
     n = done.value
     rep = SweepReport(n, [float(v) for v in trace[:n]], bool(n and trace[n - 1] < tol))
     _lib.check(rc)

@@ -67,8 +67,11 @@ def test_decomposed_jacobi_equals_single_domain(oracle, tmp_path, dims):
     assert np.array_equal(got, ref)
 
 
-def test_distributed_stop_test(oracle, tmp_path):
-    """run() follows subs.f90:915: it stops after the first sweep whose global RMS is < tol."""
+@pytest.mark.parametrize("check_every", [1, 3, 8])
+def test_distributed_stop_test(oracle, tmp_path, check_every):
+    """run() follows subs.f90:915: it stops after the first sweep whose global RMS is < tol -- whatever the number of sweeps
+    between two looks at the RMS (one all_reduce and one host read per window; a window that holds the stop sweep is repeated
+    from its kept start): same sweep count, same field, same trace as the single-domain sweep."""
     from levelsetfortran_amd import fields
 
     npts = (30, 26, 24)
@@ -77,12 +80,18 @@ def test_distributed_stop_test(oracle, tmp_path):
     nx, ny, nz = (v - 1 for v in npts)
     rc, n_ref, tr = oracle.reinit(ref, nx, ny, nz, 50, dx, fields.reinit_step(dx), tol=4.55e-3, order=oracle.JACOBI)
     assert 1 < n_ref < 50
-    mp.spawn(_worker_tol, args=(2, _free_port(), (2, 1, 1), npts, 4.55e-3, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker_tol, args=(2, _free_port(), (2, 1, 1), npts, 4.55e-3, str(tmp_path), check_every), nprocs=2, join=True)
+    got = np.full_like(ref, np.nan)
     for r in range(2):
-        assert int(np.load(tmp_path / f"t{r}.npz")["nsw"]) == n_ref
+        z = np.load(tmp_path / f"t{r}.npz")
+        assert int(z["nsw"]) == n_ref
+        assert np.allclose(z["rms"], tr[:n_ref], rtol=1e-12, atol=0)
+        sl = tuple(slice(int(s), int(e)) for s, e in z["own"])
+        got[sl] = z["data"]
+    assert np.array_equal(got, ref)
 
 
-def _worker_tol(rank, world, port, dims, npts, tol, outdir):
+def _worker_tol(rank, world, port, dims, npts, tol, outdir, check_every):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -98,6 +107,7 @@ def _worker_tol(rank, world, port, dims, npts, tol, outdir):
     phi_np, dx = fields.two_sphere_phi0(npts, ranges=rng)
     be = OracleBackend()
     dr = D.DistributedReinit(be, b, dx, fields.reinit_step(dx))
-    out, nsw, rms = dr.run(be.from_numpy(phi_np), 50, tol=tol)
-    np.savez(os.path.join(outdir, f"t{rank}.npz"), nsw=nsw)
+    out, nsw, rms = dr.run(be.from_numpy(phi_np), 50, tol=tol, check_every=check_every)
+    own = tuple(slice(lo, hi) for lo, hi in b.own_local)
+    np.savez(os.path.join(outdir, f"t{rank}.npz"), nsw=nsw, own=np.array(b.own), data=be.to_numpy(out, b.ext)[own], rms=np.array(rms))
     dist.destroy_process_group()

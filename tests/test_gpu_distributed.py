@@ -118,6 +118,11 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     # ranks cut: the unit-stride axis x is cut last)
     assert len(strong) == 1 and strong[0]["global_grid"] == [96, 96, 96] and strong[0]["local_block"] == [96, 96, 51]
     assert strong[0]["value"] > 0 and "error" not in d["decomposed"]
+    # every decomposed entry states its share of the job's HBM roofline and what moved its halos (gloo in this rehearsal:
+    # no RCCL rank; on a node with a GPU per rank rccl_ranks = the world size as the RCCL backend reports it)
+    for e in weak + strong:
+        assert 0 < e["roofline"]["frac"] < 1 and e["roofline"]["peak"] == 2 * 8000.0 and e["rccl_ranks"] == 0 and e["transport"] == "gloo"
+    assert d["rccl_ranks"] == 0
 
 
 def test_bench_strong_scaling_headline_on_one_gpu():
@@ -136,6 +141,8 @@ def test_bench_strong_scaling_headline_on_one_gpu():
     assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["grid"] == [64, 64, 64]
     cells = 3 * 62.0 ** 3
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 3 - cells) < 1e-6 * cells
+    assert d["roofline"]["peak"] == 4 * 8000.0 and abs(d["roofline"]["achieved"] - d["value"] * 24.0 / 1e9) < 1e-6 * d["roofline"]["achieved"]
+    assert d["rccl_ranks"] == 0  # gloo rehearsal
 
 
 def test_sumsq_bracket_equals_per_call_reduction():
