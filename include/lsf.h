@@ -56,7 +56,15 @@ extern "C" {
                                   the surface (isolated cells up to 1e-5 apart)  */
 #define LSF_ARITH_STRICT 0x100 /* every operation as written in subs.f90, no contraction:           \
                                   bit-identical to the reference for LSF_ORDER_GS (the default of  \
-                                  the Fortran shim); 1.9 x the time of LSF_ARITH_FAST              */
+                                  the Fortran shim); 1.8 x the time of LSF_ARITH_FAST              */
+/* Operand range of the bit-identity promise of LSF_ARITH_STRICT.  The divisions by dx (subs.f90:509-530) and the weight
+ * divisions (:536-546) are carried out by the hardware's division sequence WITHOUT its rescaling frame, which is the IEEE
+ * quotient as long as numerator, divisor and quotient are normal numbers away from the ends of the exponent range: pinned
+ * for fields and grid spacings scaled from 1e-140 to 1e140 (tests/test_gpu_parity.py, ..._at_the_ends_of_the_exponent_range)
+ * and by 1.7e10 random quotients (profiles/micro/divcheck.hip); the weight divisions fall back to the framed division when
+ * eps + IS >= 1e120.  Outside that range -- a difference of phi values divided by dx whose quotient is subnormal or
+ * overflows, an infinite phi -- the last bit, or inf against NaN, may differ from the reference; such a field is already
+ * outside anything a distance function holds (|phi| <= a few domain lengths, dx >= 1e-100 of it). */
 
 /* ---- library / device ------------------------------------------------------------------- */
 int lsf_version(void);
@@ -168,6 +176,14 @@ int lsf_advect_nodes_device(const double *d_phi, const int32_t *d_phiSB, int nx,
 int lsf_mirror(int flags);
 /* copies the twin of `host` (phi, phiNB or phiSB of an earlier seam call) back if the host copy is stale */
 int lsf_mirror_sync(void *host);
+/* Drops the twin of `host` without copying anything.  A twin keeps the HOST ADDRESS of its array: under LSF_MIRROR_LAZY
+ * an un-synced result is written through that address by lsf_release_workspace, by lsf_mirror() when LAZY is switched
+ * off and by a later seam call that needs the slot for another array -- so an array with a twin must be synced
+ * (lsf_mirror_sync) or forgotten (lsf_mirror_forget) BEFORE it is freed, and a new array that happens to get the same
+ * address must not be taken for the old one (forget, or keep LSF_MIRROR_TRUST off).  A seam call that FAILS drops the
+ * twins it touched: nothing of a failed call is ever copied to the host, and an un-synced earlier result in those slots is
+ * lost with it (the error is the caller's signal). */
+int lsf_mirror_forget(const void *host);
 int lsf_snapshot(const double *phi, double *phiO, int nx, int ny, int nz);
 int lsf_sumsq_diff(const double *phi, const double *phiO, int nx, int ny, int nz, double *sum);
 /* Writes `phi` as VTK ImageData (raw appended Float64, i fastest) with the reference's header text.  The reference

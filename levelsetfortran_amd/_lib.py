@@ -71,6 +71,7 @@ SIGNATURES = {
                                         c_int, c_void_p]),
     "lsf_mirror": (c_int, [c_int]),
     "lsf_mirror_sync": (c_int, [c_void_p]),
+    "lsf_mirror_forget": (c_int, [c_void_p]),
     "lsf_snapshot": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int]),
     "lsf_sumsq_diff": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_double)]),
     "lsf_write_vti": (c_int, [ctypes.c_char_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p]),

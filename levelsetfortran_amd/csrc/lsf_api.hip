@@ -1420,14 +1420,26 @@ int f32_mode_ok(int mode)
 
 // ---- twins of the host seams (include/lsf.h: lsf_mirror) ---------------------------------------
 // bring the host array into its device slot unless the twin is current and may be trusted
+// Every writer of a twinned slot (S_HPHI, S_HNB, S_HSB, S_SNAP) comes through here FIRST: a result that lives only in the
+// slot (LSF_MIRROR_LAZY, host_stale) and belongs to another host array -- or to the same address with another size -- is
+// written home before the slot is resized (ws may free it) or overwritten; then the slot is sized for the new owner and the
+// twin forgotten (the caller tags it again through twin_in / twin_out when it has put something there).
+int twin_claim(Ctx& c, Twin& t, Slot slot, const void* host, size_t bytes)
+{
+    if (t.host_stale && t.host && c.slot[slot].p && !(t.host == host && t.bytes == bytes))
+        HIPCHK(hipMemcpy(const_cast<void*>(t.host), c.slot[slot].p, t.bytes, hipMemcpyDeviceToHost));
+    if (!(t.host == host && t.bytes == bytes)) t = Twin{};
+    return ws(c.slot[slot], bytes);
+}
+// a seam call has failed: what it left in the slot is undefined and nothing of it may ever reach the host
+void twin_drop(Twin& t) { t = Twin{}; }
+
 int twin_in(Ctx& c, Twin& t, Slot slot, const void* host, size_t bytes)
 {
-    int rc = ws(c.slot[slot], bytes);
+    int rc = twin_claim(c, t, slot, host, bytes);
     if (rc) return rc;
     const bool hit = (c.mirror & (LSF_MIRROR_TRUST | LSF_MIRROR_LAZY)) && t.current && t.host == host && t.bytes == bytes;
     if (!hit) {
-        if (t.host_stale && t.host && t.host != host) // another array's lazy result would be lost
-            HIPCHK(hipMemcpy(const_cast<void*>(t.host), c.slot[slot].p, t.bytes, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(c.slot[slot].p, host, bytes, hipMemcpyHostToDevice));
         t.host_stale = false;
     }
@@ -1589,7 +1601,7 @@ int lsf_reinit(double* phi, int nx, int ny, int nz, int iter, double dx, double 
         if (rc2) return rc2;
         g_err = keep;
     } else
-        c.twin_phi.current = false;
+        twin_drop(c.twin_phi);
     return rc;
 }
 
@@ -1629,7 +1641,7 @@ int lsf_minmax(double* phi, int32_t* phiNB, int32_t* phiSB, int nx, int ny, int 
         if (rc2) return rc2;
         g_err = keep;
     } else
-        c.twin_phi.current = c.twin_nb.current = c.twin_sb.current = false;
+        twin_drop(c.twin_phi), twin_drop(c.twin_nb), twin_drop(c.twin_sb);
     return rc;
 }
 
@@ -1657,10 +1669,10 @@ int lsf_narrowband(const double* phi, int32_t* phiNB, int32_t* phiSB, int nx, in
     Ctx& c = ctx();
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
     if ((rc = twin_in(c, c.twin_phi, S_HPHI, phi, n * sizeof(double)))) return rc;
-    if ((rc = ws(c.slot[S_HNB], n * sizeof(int32_t)))) return rc;
-    if ((rc = ws(c.slot[S_HSB], n * sizeof(int32_t)))) return rc;
-    c.twin_nb.current = c.twin_sb.current = false; // overwritten below (a lazy older result of another array is dropped:
-                                                   // the masks are outputs here)
+    // the masks are outputs here: un-synced masks of OTHER host arrays go home first, then the slots are ours
+    if ((rc = twin_claim(c, c.twin_nb, S_HNB, phiNB, n * sizeof(int32_t)))) return rc;
+    if ((rc = twin_claim(c, c.twin_sb, S_HSB, phiSB, n * sizeof(int32_t)))) return rc;
+    twin_drop(c.twin_nb), twin_drop(c.twin_sb);
     if ((rc = narrowband_core((const double*)c.slot[S_HPHI].p, (int32_t*)c.slot[S_HNB].p, (int32_t*)c.slot[S_HSB].p, n,
                               dx, nullptr)))
         return rc;
@@ -1732,8 +1744,8 @@ int lsf_phi0(double* phi, int nx, int ny, int nz, double dx, const double xLo[3]
     if (!phi) return fail(LSF_ERR_INVALID, "phi is NULL");
     Ctx& c = ctx();
     const size_t bytes = (size_t)(nx + 1) * (ny + 1) * (nz + 1) * sizeof(double);
-    if ((rc = ws(c.slot[S_HPHI], bytes))) return rc;
-    c.twin_phi.current = false; // phi is an output here
+    if ((rc = twin_claim(c, c.twin_phi, S_HPHI, phi, bytes))) return rc; // (an un-synced result of another array goes home first)
+    twin_drop(c.twin_phi);                                                // phi is an output here
     rc = lsf_phi0_device((double*)c.slot[S_HPHI].p, nx, ny, nz, dx, xLo, minX, maxX, surfX, nSurfNode, surfElem,
                          nSurfElem, nullptr);
     if (rc) return rc;
@@ -1827,6 +1839,17 @@ int lsf_mirror_sync(void* host)
     return LSF_OK;
 }
 
+int lsf_mirror_forget(const void* host)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!host) return fail(LSF_ERR_INVALID, "NULL pointer");
+    Ctx& c = ctx();
+    for (Twin* t : {&c.twin_phi, &c.twin_nb, &c.twin_sb, &c.twin_snap})
+        if (t->host == host) twin_drop(*t);
+    return LSF_OK;
+}
+
 int lsf_snapshot(const double* phi, double* phiO, int nx, int ny, int nz)
 {
     Trace trace_("lsf_snapshot");
@@ -1839,10 +1862,10 @@ int lsf_snapshot(const double* phi, double* phiO, int nx, int ny, int nz)
     const void* d = (c.mirror & (LSF_MIRROR_TRUST | LSF_MIRROR_LAZY)) ? twin_of(c, phi, bytes) : nullptr;
     if (!d) { // no usable twin: the plain host copy of set3d.f90:311
         std::memcpy(phiO, phi, bytes);
-        c.twin_snap.current = false;
+        if (c.twin_snap.host == phiO) twin_drop(c.twin_snap); // the host copy just written is the newer one
         return LSF_OK;
     }
-    if ((rc = ws(c.slot[S_SNAP], bytes))) return rc;
+    if ((rc = twin_claim(c, c.twin_snap, S_SNAP, phiO, bytes))) return rc;
     HIPCHK(hipMemcpy(c.slot[S_SNAP].p, d, bytes, hipMemcpyDeviceToDevice));
     return twin_out(c, c.twin_snap, S_SNAP, phiO, bytes);
 }
@@ -2064,7 +2087,10 @@ int lsf_reinit_f32(float* phi, int nx, int ny, int nz, int iter, double dx, doub
     if (!phi) return fail(LSF_ERR_INVALID, "phi is NULL");
     Ctx& c = ctx();
     const size_t bytes = (size_t)(nx + 1) * (ny + 1) * (nz + 1) * sizeof(float);
-    if ((rc = ws(c.slot[S_HPHI], bytes))) return rc;
+    // the fp32 seam borrows the slot of the fp64 field twin: whatever twin lives there is written home if need be and
+    // forgotten (float data must never be taken for the doubles of an earlier array at this address)
+    if ((rc = twin_claim(c, c.twin_phi, S_HPHI, nullptr, bytes))) return rc;
+    twin_drop(c.twin_phi);
     float* d = (float*)c.slot[S_HPHI].p;
     HIPCHK(hipMemcpy(d, phi, bytes, hipMemcpyHostToDevice));
     rc = reinit_f32_core(d, nullptr, nx, ny, nz, iter, dx, h, tol, sweeps_done, rms_trace, trace_cap, nullptr);

@@ -63,7 +63,7 @@ USE, INTRINSIC :: iso_c_binding
 IMPLICIT NONE
 PRIVATE
 PUBLIC :: reinit, narrowBand, minmaxFlow, phi0Init, advectNodes, lsf_env_real, lsf_env_int, lsf_pad_cells
-PUBLIC :: writeVti, snapshotPhi, sumSqDiff, syncHost, syncHostInt, stlRead
+PUBLIC :: writeVti, snapshotPhi, sumSqDiff, syncHost, syncHostInt, forgetHost, stlRead
 
 INTEGER(c_int), PARAMETER :: LSF_OK = 0, LSF_ERR_NAN = 1
 INTEGER(c_int), PARAMETER :: LSF_ORDER_JACOBI = 1, LSF_ARITH_STRICT = 256
@@ -159,6 +159,11 @@ INTERFACE
       TYPE(c_ptr), VALUE :: host
       INTEGER(c_int) :: rc
    END FUNCTION lsf_mirror_sync
+   FUNCTION lsf_mirror_forget(host) BIND(C,NAME='lsf_mirror_forget') RESULT(rc)
+      IMPORT :: c_int, c_ptr
+      TYPE(c_ptr), VALUE :: host
+      INTEGER(c_int) :: rc
+   END FUNCTION lsf_mirror_forget
    FUNCTION lsf_snapshot(phi,phiO,nx,ny,nz) BIND(C,NAME='lsf_snapshot') RESULT(rc)
       IMPORT :: c_int, c_double
       REAL(c_double), INTENT(IN) :: phi(*)
@@ -601,6 +606,14 @@ INTEGER(c_int) :: rc
 rc = lsf_mirror_sync(c_loc(a))
 IF (rc /= LSF_OK) CALL lsf_fail('lsf_mirror_sync',rc)
 END SUBROUTINE syncHost
+
+! the array is about to be freed (or its device copy is of no further use): drop its twin without a copy
+SUBROUTINE forgetHost(a)
+REAL, INTENT(INOUT), TARGET :: a(*)
+INTEGER(c_int) :: rc
+rc = lsf_mirror_forget(c_loc(a))
+IF (rc /= LSF_OK) CALL lsf_fail('lsf_mirror_forget',rc)
+END SUBROUTINE forgetHost
 
 SUBROUTINE syncHostInt(a)
 INTEGER, INTENT(INOUT), TARGET :: a(*)

@@ -611,6 +611,92 @@ def test_host_seams_with_device_twins(lsf, cube40, tmp_path):
         _lib.check(lib.lsf_release_workspace())
 
 
+@pytest.mark.parametrize("flags", ["trust", "lazy"])
+def test_device_twins_survive_interleaved_arrays_sizes_and_precisions(lsf, flags):
+    """The twin slots are shared by every host array that comes through a seam.  An un-synced (LAZY) result of array A must
+    reach A when array B -- larger, smaller, the same address with another size, or the float field of the fp32 seam --
+    takes the slot; a float field must never be trusted as the doubles of an earlier array; a FAILED call leaves nothing
+    behind that a later sync could copy; a forgotten twin is never written through."""
+    from levelsetfortran_amd import _lib, fields
+
+    lib = _lib.load()
+    fl = _lib.LSF_MIRROR_TRUST | (_lib.LSF_MIRROR_LAZY if flags == "lazy" else 0)
+    lazy = flags == "lazy"
+
+    def field(npts):
+        phi0, dx = fields.two_sphere_phi0(npts)
+        n = tuple(v - 1 for v in npts)
+        return phi0, n, dx, fields.reinit_step(dx)
+
+    def want(phi0, n, dx, h, sweeps, order="jacobi"):
+        w = phi0.copy(order="F")
+        _lib.check(lib.lsf_mirror(0))
+        lsf.reinit(w, None, None, n[0], n[1], n[2], sweeps - 1, dx, h, tol=0.0, order=order, arith="strict")
+        _lib.check(lib.lsf_mirror(fl))
+        return w
+
+    A0, nA, dxA, hA = field((40, 36, 30))
+    B0, nB, dxB, hB = field((52, 44, 38))  # larger: the slot is reallocated
+    C0, nC, dxC, hC = field((24, 20, 22))  # smaller
+    try:
+        wA, wB, wC = want(A0, nA, dxA, hA, 3), want(B0, nB, dxB, hB, 2), want(C0, nC, dxC, hC, 4)
+        _lib.check(lib.lsf_mirror(fl))
+        A, B, C = A0.copy(order="F"), B0.copy(order="F"), C0.copy(order="F")
+        lsf.reinit(A, None, None, *nA, 2, dxA, hA, tol=0.0, order="jacobi", arith="strict")
+        assert np.array_equal(A, A0 if lazy else wA)
+        lsf.reinit(B, None, None, *nB, 1, dxB, hB, tol=0.0, order="jacobi", arith="strict")  # takes A's slot: A goes home first
+        assert np.array_equal(A, wA)
+        lsf.reinit(C, None, None, *nC, 3, dxC, hC, tol=0.0, order="jacobi", arith="strict")
+        assert np.array_equal(B, wB)
+        # the fp32 seam borrows the same slot: C goes home, and afterwards C's twin is gone (a trusted hit would read floats)
+        F32 = np.asfortranarray(C0.astype(np.float32))
+        lsf.reinit(F32, None, None, *nC, 1, dxC, hC, tol=0.0, order="jacobi", arith="fast")
+        assert np.array_equal(C, wC)
+        nb = np.zeros(C.shape, dtype=np.int32, order="F")
+        sb = np.zeros(C.shape, dtype=np.int32, order="F")
+        lsf.narrowBand(*nC, dxC, C, nb, sb)  # must upload C again
+        if lazy:
+            for a_ in (nb, sb):
+                _lib.check(lib.lsf_mirror_sync(a_.ctypes.data))
+        assert np.array_equal(nb != 0, np.abs(C) < 4.1 * dxC) and np.array_equal(sb != 0, np.abs(C) < 8.1 * dxC)
+        # the same address with another size is another array
+        big = np.zeros(60 * 50 * 44, dtype=np.float64)
+        v1 = big[:A0.size].reshape(A0.shape, order="F")
+        v1[...] = A0
+        lsf.reinit(v1, None, None, *nA, 2, dxA, hA, tol=0.0, order="jacobi", arith="strict")
+        v2 = big[:C0.size].reshape(C0.shape, order="F")  # same address, smaller
+        keep = v1.copy(order="F") if not lazy else None
+        if lazy:
+            _lib.check(lib.lsf_mirror_sync(v1.ctypes.data))
+            assert np.array_equal(v1, wA)
+        v2[...] = C0
+        lsf.reinit(v2, None, None, *nC, 3, dxC, hC, tol=0.0, order="jacobi", arith="strict")
+        if lazy:
+            _lib.check(lib.lsf_mirror_sync(v2.ctypes.data))
+        assert np.array_equal(v2, wC) and (keep is None or np.array_equal(keep, wA))
+        # a failed call: the twin it touched is dropped, a later sync copies nothing
+        D = A0.copy(order="F")
+        lsf.reinit(D, None, None, *nA, 2, dxA, hA, tol=0.0, order="jacobi", arith="strict")
+        if lazy:
+            assert np.array_equal(D, A0)
+        with pytest.raises(lsf.LsfError):
+            lsf.reinit(D, None, None, *nA, -1, dxA, hA, tol=0.0, order="jacobi", arith="strict")  # iter < 0
+        before = D.copy(order="F")
+        _lib.check(lib.lsf_mirror_sync(D.ctypes.data))
+        assert np.array_equal(D, before)
+        # forget: the twin of an array that is about to be freed is never written through
+        E = A0.copy(order="F")
+        lsf.reinit(E, None, None, *nA, 2, dxA, hA, tol=0.0, order="jacobi", arith="strict")
+        _lib.check(lib.lsf_mirror_forget(E.ctypes.data))
+        E[...] = 7.0
+        _lib.check(lib.lsf_mirror_sync(E.ctypes.data))
+        lsf.reinit(B, None, None, *nB, 0, dxB, hB, tol=0.0, order="jacobi", arith="strict")
+        assert float(E.min()) == float(E.max()) == 7.0
+    finally:
+        _lib.check(lib.lsf_mirror(0))
+        _lib.check(lib.lsf_release_workspace())
+
+
 # ---------------------------------------------------------------------------------- advection (SURVEY.md 8f rank 3)
 def test_node_advection_matches_reference(lsf, cube40):
     """set3d.f90:464-501 on the GPU: bit-identical advected nodes (host and device seam)."""
