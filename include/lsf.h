@@ -188,7 +188,8 @@ int lsf_snapshot(const double *phi, double *phiO, int nx, int ny, int nz);
 int lsf_sumsq_diff(const double *phi, const double *phiO, int nx, int ny, int nz, double *sum);
 /* Writes `phi` as VTK ImageData (raw appended Float64, i fastest) with the reference's header text.  The reference
  * writes an INTEGER*4 byte count that is 3 x too large and overflows at >= 448^3 points (set3d.f90:330); this writer
- * stores the true count, as UInt32 when it fits and with header_type="UInt64" otherwise.  The payload streams from the
+ * stores the true count, as UInt32 when it fits and with header_type="UInt64" otherwise (or whenever the environment
+ * holds LSF_VTI_WIDE=1).  The payload streams from the
  * device twin through two pinned staging buffers (copy of chunk n + 1 overlaps the write of chunk n). */
 int lsf_write_vti(const char *path, const double *phi, int nx, int ny, int nz, double dx, const double xLo[3]);
 

@@ -1906,7 +1906,9 @@ int lsf_write_vti(const char* path, const double* phi, int nx, int ny, int nz, d
     snprintf(extent, sizeof extent, " 0 %6d 0 %6d 0 %6d", nx, ny, nz);
     snprintf(origin, sizeof origin, "%20.8f %20.8f %20.8f", xLo[0], xLo[1], xLo[2]);
     snprintf(spacing, sizeof spacing, "%20.8f %20.8f %20.8f", dx, dx, dx);
-    const bool wide = bytes > 0xffffffffull;
+    // LSF_VTI_WIDE=1 writes the 64-bit count for any size (include/lsf.h): the wide header can be exercised without a 4 GB field
+    const char* wide_env = getenv("LSF_VTI_WIDE");
+    const bool wide = bytes > 0xffffffffull || (wide_env && atoi(wide_env) != 0);
     fprintf(f, "<?xml version=\"1.0\"?>\n");
     fprintf(f, "<VTKFile type=\"ImageData\" version=\"0.1\" byte_order=\"LittleEndian\"%s>\n", wide ? " header_type=\"UInt64\"" : "");
     fprintf(f, "<ImageData WholeExtent=\"%s\" Origin=\"%s\" Spacing=\"%s\">\n", extent, origin, spacing);

@@ -72,12 +72,16 @@ __device__ __forceinline__ void weno_axis_strict(const double q[7], double dx, b
     const double cp = div_dx(r1 - 2. * c0 + m1, dx, rdx);
     const double cm = cp, dpp = bm, dmm = bp;
 
+    // 13.*(x)*(x) is ((13 x) x): the same double for x and -x, so the first term of IS2m (x = cm - dmm = cp - bp) is that
+    // of IS1p (x = bp - cp), and the first term of IS2p (cp - dpp = cp - bm) that of IS1m (bm - cm = bm - cp): two of the
+    // twelve quadratic terms of subs.f90:518-523 are evaluated once (the rest differ in value, not only in sign)
+    const double T1p = 13. * (bp - cp) * (bp - cp), T1m = 13. * (bm - cm) * (bm - cm);
     const double IS0p = 13. * (ap - bp) * (ap - bp) + 3. * (ap - 3. * bp) * (ap - 3. * bp);
     const double IS0m = 13. * (am - bm) * (am - bm) + 3. * (am - 3. * bm) * (am - 3. * bm);
-    const double IS1p = 13. * (bp - cp) * (bp - cp) + 3. * (bp + cp) * (bp + cp);
-    const double IS1m = 13. * (bm - cm) * (bm - cm) + 3. * (bm + cm) * (bm + cm);
-    const double IS2p = 13. * (cp - dpp) * (cp - dpp) + 3. * (3. * cp - dpp) * (3. * cp - dpp);
-    const double IS2m = 13. * (cm - dmm) * (cm - dmm) + 3. * (3. * cm - dmm) * (3. * cm - dmm);
+    const double IS1p = T1p + 3. * (bp + cp) * (bp + cp);
+    const double IS1m = T1m + 3. * (bm + cm) * (bm + cm);
+    const double IS2p = T1m + 3. * (3. * cp - dpp) * (3. * cp - dpp);
+    const double IS2m = T1p + 3. * (3. * cm - dmm) * (3. * cm - dmm);
 
     const double p0 = div_dx(m2 - m3, dx, rdx);
     const double p1 = div_dx(m1 - m2, dx, rdx);
@@ -145,6 +149,15 @@ __device__ __forceinline__ double godunov_strict(double phic, double a, double b
     return __builtin_sqrt(gX + gY + gZ);
 }
 
+template <bool STRICT>
+__device__ __forceinline__ void axis_pair(const double q[7], bool weno_ok, bool yquirk, double dx, double floor2,
+                                          double& dm, double& dp);
+template <bool STRICT>
+__device__ __forceinline__ double axis_godunov(double phic, double dm, double dp);
+template <bool STRICT>
+__device__ __forceinline__ double finish_update(double phic, double gX, double gY, double gZ, double pS, double dx,
+                                                double inv_dx, double h);
+
 // STRICT cell update: returns phi_new.  qx/qy/qz: -3..+3 stencils (only [2..4] are read when
 // !weno_ok, the first-order branch subs.f90:657-662).
 __device__ __forceinline__ double cell_update_strict(const double qx[7], const double qy[7],
@@ -167,10 +180,10 @@ __device__ __forceinline__ double cell_update_strict(const double qx[7], const d
         e = div_dx(phic - qz[2], dx, rdx);
         f = div_dx(qz[4] - phic, dx, rdx);
     }
-    const double gM = godunov_strict(phic, a, b, c, d, e, f);
-    const double sgn = pS / __builtin_sqrt(pS * pS + dx * dx * gM); // subs.f90:169
-    const double k1 = sgn * (1. - gM);                              // subs.f90:749
-    return phic + h * k1;                                           // subs.f90:750
+    // Godunov switch, |grad|, smeared sign, Euler step (subs.f90:667-702, :169, :749-750): the per-axis pieces below, which
+    // return the bits of the literal forms (godunov_strict above is kept as their written-out statement)
+    return finish_update<true>(phic, axis_godunov<true>(phic, a, b), axis_godunov<true>(phic, c, d), axis_godunov<true>(phic, e, f),
+                               pS, dx, 0.0, h);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -309,14 +322,6 @@ __device__ __forceinline__ void weno_axis_from_ifaces(const double q[7], double 
     dp = __builtin_fma(1.0 / 12.0, cen_c, pwp_c);
 }
 
-template <bool STRICT>
-__device__ __forceinline__ void axis_pair(const double q[7], bool weno_ok, bool yquirk, double dx, double floor2,
-                                          double& dm, double& dp);
-template <bool STRICT>
-__device__ __forceinline__ double axis_godunov(double phic, double dm, double dp);
-template <bool STRICT>
-__device__ __forceinline__ double finish_update(double phic, double gX, double gY, double gZ, double pS, double dx,
-                                                double inv_dx, double h);
 
 __device__ __forceinline__ double cell_update_fast(const double qx[7], const double qy[7],
                                                    const double qz[7], bool weno_ok, double pS, double dx,
@@ -393,6 +398,23 @@ __device__ __forceinline__ double axis_godunov(double phic, double dm, double dp
     return m * m;
 }
 
+// IEEE sqrt(x) by the sequence the compiler emits for it (v_rsq_f64, one coupled Newton step on root and half reciprocal
+// root, two residual corrections) WITHOUT its frame (scaling by 2^256 below 2^-767, pass-through of zeros and infinity):
+// the same instructions in the same order, hence the same bits, for every x in [1e-230, DBL_MAX] (profiles/micro/divcheck.hip
+// checks it by brute force).  STRICT only; callers test the range and take __builtin_sqrt otherwise.
+__device__ __forceinline__ double sqrt_unframed(double x)
+{
+#pragma clang fp contract(off)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, hh = y * 0.5;
+    const double r = __builtin_fma(-hh, g, 0.5);
+    g = __builtin_fma(g, r, g), hh = __builtin_fma(hh, r, hh);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, hh, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, hh, g);
+}
+
 // 1/sqrt(t) from v_rsq_f64 (5.2e-8 relative, measured) + one Newton step -> 4e-15 relative (FAST only)
 __device__ __forceinline__ double rsqrt_nr(double t)
 {
@@ -408,7 +430,21 @@ __device__ __forceinline__ double finish_update(double phic, double gX, double g
 {
     if constexpr (STRICT) {
 #pragma clang fp contract(off)
-        const double gM = __builtin_sqrt(gX + gY + gZ);
+        // subs.f90:702, :169, :749-750.  Two square roots and one division per cell, by the hardware sequences without
+        // their frames where the operands allow it (see sqrt_unframed, div_by): 27 instructions where the framed forms take
+        // 47.  A flat neighbourhood (S = 0), a vanishing sign field, NaN or anything near the ends of the exponent range
+        // takes the plain operators -- the 0 / 0 of subs.f90:169 included.
+        const double S = gX + gY + gZ;
+        const double pp = pS * pS, dd = dx * dx;
+        if (__builtin_expect(S >= 1.0e-200 && S <= 1.0e200 && pp >= 1.0e-200 && pp <= 1.0e200 && dd >= 1.0e-200 && dd <= 1.0e200, 1)) {
+            const double gM = sqrt_unframed(S);
+            const double t = pp + dd * gM;                  // >= pp: in [1e-200, ~1e200]
+            const double den = sqrt_unframed(t);            // >= |pS|: the quotient is at most 1 in magnitude, at least ~1e-100
+            const double sgn = div_by(pS, den, recip_refined(den));
+            const double k1 = sgn * (1. - gM);
+            return phic + h * k1;
+        }
+        const double gM = __builtin_sqrt(S);
         const double sgn = pS / __builtin_sqrt(pS * pS + dx * dx * gM);
         const double k1 = sgn * (1. - gM);
         return phic + h * k1;

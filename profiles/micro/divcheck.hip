@@ -23,6 +23,9 @@ __global__ void k(unsigned long long* bad, int rounds, int dexp)
         const double rd = 1. / d;
         a += __double_as_longlong(lsf::div_by(n, d, lsf::recip_refined(d))) != __double_as_longlong(q);
         b += __double_as_longlong(lsf::div_by(n, d, rd)) != __double_as_longlong(q);
+        // the unframed square root of finish_update<STRICT> against the compiler's: |d| has exponents up to +-dexp
+        const double x = __builtin_fabs(d);
+        if (x >= 1.0e-200 && x <= 1.0e200) c += __double_as_longlong(lsf::sqrt_unframed(x)) != __double_as_longlong(__builtin_sqrt(x));
     }
     atomicAdd(bad + 0, a), atomicAdd(bad + 1, b), atomicAdd(bad + 2, c);
 }
@@ -34,8 +37,9 @@ int main()
         const int rounds = 4096, blocks = 8192;
         k<<<blocks, 256>>>(d_bad, rounds, dexp);
         unsigned long long h[3]; (void)hipMemcpy(h, d_bad, 24, hipMemcpyDeviceToHost);
-        printf("divisor exponents +-%d: %.3g quotients; mismatches vs n / d:  A (refined reciprocal, 1 correction) %llu   B (1./d, 1 correction) %llu\n",
-               dexp, (double)rounds * blocks * 256, h[0], h[1]);
+        printf("divisor exponents +-%d: %.3g quotients; mismatches vs n / d:  A (refined reciprocal, 1 correction) %llu   B (1./d, 1 correction) %llu"
+               "   unframed sqrt vs sqrt %llu\n",
+               dexp, (double)rounds * blocks * 256, h[0], h[1], h[2]);
     }
     return 0;
 }

@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI) with the reference -- via the committed golden outputs
 of the reference itself and via the oracle on the same seeded inputs.  Integer/sign results and the
 STRICT arithmetic are compared with `==`; the FAST arithmetic within 1e-12 RMS (north_star: 1e-10)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -589,6 +591,16 @@ def test_host_seams_with_device_twins(lsf, cube40, tmp_path):
             _lib.check(lib.lsf_write_vti(f1, phi.ctypes.data, nx, ny, nz, dx, xlo.ctypes.data))
             assert np.array_equal(stl_io.vti_read_phi(f1.decode(), shape), want_re)
             assert stl_io.vti_header_count(f1.decode()) == (8 * phi.size, False)
+            if flags == 0:  # the UInt64 header of fields above 4 GB, forced onto this small one: same payload, 8-byte count
+                os.environ["LSF_VTI_WIDE"] = "1"
+                try:
+                    f1w = str(tmp_path / "signed_wide.vti").encode()
+                    _lib.check(lib.lsf_write_vti(f1w, phi.ctypes.data, nx, ny, nz, dx, xlo.ctypes.data))
+                finally:
+                    del os.environ["LSF_VTI_WIDE"]
+                assert np.array_equal(stl_io.vti_read_phi(f1w.decode(), shape), want_re)
+                assert stl_io.vti_header_count(f1w.decode()) == (8 * phi.size, True)
+                assert os.path.getsize(f1w.decode()) == os.path.getsize(f1.decode()) + 4 + len(' header_type="UInt64"')
             lsf.narrowBand(nx, ny, nz, dx, phi, nb, sb)
             rm = lsf.minmaxFlow(phi, nb, sb, nx, ny, nz, 10000, dx, float(cube40["h1"]))
             assert rm.count == 406
