@@ -23,13 +23,16 @@ def cdiv(a, b):
     return -(-a // b)
 
 
-WAVES = ((1, 1), (2, 1), (4, 1), (8, 1), (2, 2), (4, 2), (4, 4))  # (WY, WZ) shapes the library instantiates
+# (WY, WZ[, BY]) shapes: bundles of BY x 4 rows per wavefront, BY = 5 (three lanes per cell, the default) or 16 (one lane
+# per cell: LSF_GS_SKEW_W=c1x4 ..., chosen by the library itself on grids of 900 cells and more across)
+WAVES = ((1, 1), (2, 1), (4, 1), (8, 1), (2, 2), (4, 2), (4, 4), (1, 1, 16), (1, 2, 16), (1, 3, 16), (1, 4, 16))
 
 
 def layout(w):
-    """SkTile<16, WY, WZ>: rows of a tile in y and z, first row of each LDS row group, number of rows"""
-    wy, wz = w
-    nyt, nzt = 5 * wy, 4 * wz
+    """SkTile<16, WY, WZ, BY>: rows of a tile in y and z, first row of each LDS row group, number of rows"""
+    wy, wz = w[:2]
+    by = w[2] if len(w) > 2 else 5
+    nyt, nzt = by * wy, 4 * wz
     ncore, yh, zp = nzt * nyt, 3 * nzt, (3 * nyt + 3) // 4 * 4
     yu0, zu0 = ncore, ncore + yh
     yd0 = zu0 + zp
@@ -174,7 +177,7 @@ def spacing_closed_form(da, db, nx, ny, nz, NY, NZ):
 @pytest.mark.parametrize("dims", GRIDS + [(64, 64, 64), (100, 37, 51)])
 def test_launch_order_respects_the_in_place_sweep(dims, w):
     nx, ny, nz = dims
-    NY, NZ = 5 * w[0], 4 * w[1]
+    NY, NZ = layout(w)[:2]
     maps = [plane_maps(nx, ny, nz, d, NY, NZ) for d in RASTER]
     for direction, (plane, step, tile) in zip(RASTER, maps):
         for axis, sgn in zip((2, 1, 0), direction):  # arrays are [k, j, i]
