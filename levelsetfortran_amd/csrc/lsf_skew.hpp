@@ -35,6 +35,15 @@
 #ifndef LSF_SKEW_UNROLL
 #define LSF_SKEW_UNROLL 16 // marching steps per iteration of the march loop
 #endif
+// 16-byte loads and stores for tiles whose whole LDS image lies inside the grid (see skew_tile, "wide path"): 0 = never,
+// 1 = one lane per cell only (default), 2 = both lane maps.  Measured at 512^3 (profiles/r03_wide_ab.txt, one box): one lane
+// per cell 2.89 against 2.97 ms per sweep, HBM traffic unchanged (2.76 x algorithmic); three lanes per cell 2.68 against
+// 2.65 ms and MORE traffic (3.43 x against 3.10 x: unaligned 16-byte write-through stores cost 35 % more write traffic, the
+// loads 7 % more) -- the over-fetch of this kernel is halo rows and 128-byte lines around 144..176-byte row segments that
+// start anywhere, not the width of its requests.
+#ifndef LSF_SKEW_WIDE
+#define LSF_SKEW_WIDE 1
+#endif
 #ifndef LSF_CELL_UNROLL
 #define LSF_CELL_UNROLL 8 // one lane per cell: marching steps per iteration of the march loop (code size vs. loop overhead)
 #endif
@@ -300,7 +309,74 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     auto ps_load = [&](int t) {
         return ps_t[(unsigned)(e_ps.x >> 2) + (unsigned)min(max(e_ps.y + (si > 0 ? t : -t), 0), nx)];
     };
-    {
+    // Wide path: a deep tile (full, every row of its image an interior row) whose image also stays inside the grid along the
+    // march axis -- entries 0 .. 22 of every row are interior cells -- needs no clamp, no interior test and no choice between
+    // `in` and `out` per entry: its rows travel as 16-byte buffer loads (two entries per lane, 10 / 9 lanes per row; the pair is
+    // swapped on its way into LDS when the sweep runs against the memory order) and its results leave as 16-byte stores.  One
+    // request per 16 bytes instead of one per 8 (an 8-byte write-through store is a fabric write of its own), and the six
+    // odd entries per bundle row no longer cost separate scattered requests.
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    constexpr int AUX_SC1 = SC1 ? 16 : 0; // cache policy of the buffer instructions: sc1 = bit 4
+    const bool widex = (LSF_SKEW_WIDE == 2 || (LSF_SKEW_WIDE == 1 && BY == 16)) && deep && X0 - (NYT + NZT + 4) >= 0 && X0 + 22 <= nxi - 1 &&
+                       (double)(NZT + 7) * (double)sxy * 8.0 < 4.0e9;
+    if (widex) {
+        const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(in_t), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out_t, 0, 0x7fffffff, 0x00020000);
+        constexpr int RPI = 4 * W;
+        constexpr int NB = T::NCORE / RPI, NU = (T::YD0 - T::YU0 + RPI - 1) / RPI, ND = (T::NR - T::YD0 + RPI - 1) / RPI;
+        constexpr int XC = 3 * T::NCORE, NXC = (XC + NT - 1) / NT;
+        u4_t w[NB + ND + NU];
+        int dw[NB + ND + NU];
+        double v3[NXC];
+        int d3[NXC];
+        const int xx = tid & 15, rsub = tid >> 4;
+        int n_ = 0;
+        // entries k, k + 1 of a row: one 16-byte load at the lower of their two addresses
+        auto pair_at = [&](const __amdgpu_buffer_rsrc_t& rs, int2 e, int k) {
+            const unsigned el = (unsigned)(e.x >> 2) + (unsigned)(e.y + (si > 0 ? k - 3 : 2 - k));
+            return __builtin_amdgcn_raw_buffer_load_b128(rs, 8u * el, 0, AUX_SC1);
+        };
+        // ---- stage 1: what the previous sweep left (bundle rows entries 3 .. 21 (+ 22, dropped), downstream halo 4 .. 21)
+#pragma unroll
+        for (int u = 0; u < NB; ++u, ++n_) {
+            const int r = RPI * u + rsub, k = 3 + 2 * min(xx, 9);
+            dw[n_] = T::core_at(r) + k;
+            w[n_] = pair_at(r_in, rowtab[r], k);
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u, ++n_) {
+            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = 4 + 2 * min(xx, 8);
+            dw[n_] = T::HB + (r - T::NCORE) * T::RH + k - 4;
+            w[n_] = pair_at(r_in, rowtab[r], k);
+        }
+#pragma unroll
+        for (int t = 0; t < NPS; ++t) ps[t] = ps_load(t);
+        if (!wait_upstream()) return false;
+        if (tid == 0 && m != (NYT * fB + NZT * fC) / TA) colsum_prev = ldp(a.colsum + (long)gb * ncol + (tj + (long)a.nTj * tk));
+        // ---- stage 2: what the upstream tiles of this sweep wrote (upstream halo 0 .. 17, bundle rows entries 0 .. 2)
+#pragma unroll
+        for (int u = 0; u < NU; ++u, ++n_) {
+            const int r = min(T::YU0 + RPI * u + rsub, T::YD0 - 1), k = 2 * min(xx, 8);
+            dw[n_] = T::HB + (r - T::NCORE) * T::RH + k;
+            w[n_] = pair_at(r_out, rowtab[r], k);
+        }
+#pragma unroll
+        for (int u = 0; u < NXC; ++u) {
+            const int idx = min(tid + NT * u, XC - 1);
+            const int r = idx / 3, k = idx - 3 * r;
+            const int2 e = rowtab[r];
+            d3[u] = T::core_at(r) + k;
+            v3[u] = ldp((const double*)out_t + ((unsigned)(e.x >> 2) + (unsigned)(e.y + (si > 0 ? k - 3 : 3 - k))));
+        }
+#pragma unroll
+        for (int u = 0; u < NB + ND + NU; ++u) {
+            const double lo = __hiloint2double((int)w[u].y, (int)w[u].x), hi = __hiloint2double((int)w[u].w, (int)w[u].z);
+            lds[dw[u]] = si > 0 ? lo : hi;                              // entry k
+            if (u >= NB || xx < 9) lds[dw[u] + 1] = si > 0 ? hi : lo;   // entry k + 1 (a bundle row has no entry 22)
+        }
+#pragma unroll
+        for (int u = 0; u < NXC; ++u) lds[d3[u]] = v3[u];
+    } else {
         // 16 entries of one row per 16 lanes, 4 W rows per load instruction.  Rows are taken CLASS BY CLASS (bundle /
         // upstream halo / downstream halo) so that everything that depends on the class -- first entry, where the row
         // lives in the LDS image, whether a value of this sweep has to be fetched from `out` -- is a compile-time
@@ -521,6 +597,23 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     const int fx_min = X0 - (nj - 1) - (nk - 1), fx_max = X0 + TA - 1;
     const bool near_wall = j_lo == 1 || j_lo + nj == ny || k_lo == 1 || k_lo + nk == nz ||
                            (fx_min <= 0 && fx_max >= 0) || (fx_min <= nxi - 1 && fx_max >= nxi - 1);
+    if (widex) { // every cell of the tile exists and none touches a wall: 16-byte stores, two results per lane
+        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out_t, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < (T::NCORE + 8 * W - 1) / (8 * W); ++u) {
+            const int r = 8 * W * u + (tid >> 3), t = 2 * (tid & 7);
+            if (r < T::NCORE) {
+                const int2 e = rowtab[r];
+                const double v0 = lds[T::core_at(r) + 3 + t], v1 = lds[T::core_at(r) + 4 + t];
+                const double lo = si > 0 ? v0 : v1, hi = si > 0 ? v1 : v0;
+                u4_t pk;
+                pk.x = (unsigned)__double2loint(lo), pk.y = (unsigned)__double2hiint(lo);
+                pk.z = (unsigned)__double2loint(hi), pk.w = (unsigned)__double2hiint(hi);
+                const unsigned el = (unsigned)(e.x >> 2) + (unsigned)(e.y + (si > 0 ? t : -t - 1));
+                __builtin_amdgcn_raw_buffer_store_b128(pk, r_out, 8u * el, 0, AUX_SC1);
+            }
+        }
+    } else
 #pragma unroll
     for (int u = 0; u < T::NCORE / (4 * W); ++u) {
         const int r = 4 * W * u + (tid >> 4), cq = r / NYT, bq = r - NYT * cq, t = tid & 15;
