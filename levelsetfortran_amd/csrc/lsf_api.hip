@@ -71,13 +71,15 @@ int gs_ta()
 // wavefronts per skewed tile (lsf_skew.hpp): WY x WZ adjacent bundles marched in lock step, "WYxWZ" or "WY"; a leading
 // 'c' selects the one-lane-per-cell map (bundles of 16 x 4 rows: "c1x4" = 16 x 16 rows), otherwise three lanes per cell
 // (bundles of 5 x 4 rows).  *by = rows of a bundle in y (5 or 16).
-// Unset: three lanes per cell, 2 x 2 wavefronts; one lane per cell (16 x 16 rows) on grids whose cross-section has at least
-// 900 cells per axis, where a sweep offers enough independent 16 x 16 tiles to keep two per CU busy (measured, ms per sweep,
-// 2x2 / c1x4: 512^3 2.71 / 3.02, 640^3 5.25 / 5.52, 768^3 8.96 / 8.92, 1024^3 22.1 / 21.2; profiles/r03_tile_shapes.txt).
-void gs_skew_w(int ny, int nz, int* wy, int* wz, int* by)
+// Unset: three lanes per cell, 2 x 2 wavefronts; one lane per cell (16 x 16 rows) on grids large enough for a sweep to offer
+// the independent 16 x 16 tiles that keep two per CU busy.  Measured, ms per sweep, 2x2 / c1x4 (profiles/r03_tile_shapes.txt):
+//   FAST    512^3 2.69 / 2.89   640^3 5.25 / 5.5   768^3 8.96 / 8.92   1024^3 22.1 / 21.2     -> from 700 cells across
+//   STRICT  384^3 2.14 / 2.63   512^3 4.61 / 4.54  640^3 8.87 / 8.06                          -> from 500 cells across
+// (the longer march of the reference's own arithmetic hides more of a tile's memory phases)
+void gs_skew_w(int ny, int nz, bool strict, int* wy, int* wz, int* by)
 {
     const char* e = getenv("LSF_GS_SKEW_W");
-    if (!e && std::min(ny, nz) >= 900) e = "c1x4";
+    if (!e && std::min(ny, nz) >= (strict ? 500 : 700)) e = "c1x4";
     const bool cell = e && (e[0] == 'c' || e[0] == 'C');
     if (cell) ++e;
     int y = 2, z = 2; // measured best at 256^3, 512^3 and 1024^3
@@ -741,7 +743,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     persist = persist && skew;
     int wy = 1, wz = 1, by = 5, nzc = 4;
     if (skew) {
-        gs_skew_w(std::min(nx, ny), nz, &wy, &wz, &by); // (the dataflow launch may swap x and y)
+        gs_skew_w(std::min(nx, ny), nz, strict, &wy, &wz, &by); // (the dataflow launch may swap x and y)
         nyc = by * wy, nzc = 4 * wz; // rows of a tile in y and z
     }
     // Dataflow launch: the kernel marches along ITS x axis; run it on the x <-> y transposed field so that the march axis

@@ -551,11 +551,33 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     } else {
         // ---- one lane per cell: the lane evaluates the three axes of its cell; 19 LDS reads, one LDS write per cell ----
         int ox[7], oy[7], oz[7]; // LDS index of the stencil value mm - 3 along x / y / z at step 0 (ox[3] = the cell itself)
+        if (nj == NYT && nk == NZT) {
+            // full tile: the 19 offsets in ~90 instructions instead of 19 calls of lane_off (~25 each): the row d places up or down
+            // the bundle is d rows (planes) further in the same row group, or in the halo group of that side
+            constexpr int RA_ = T::RA, RH_ = T::RH, PS_ = NYT * T::RA + T::PAD;
+            const int base = T::core_at(cc * NYT + bc) + 3; // the cell itself at step 0
+            const int yu = T::HB + (T::YU0 - T::NCORE + cc * 3 + 3 + bc) * RH_ + 3, yd = T::HB + (T::YD0 - T::NCORE + cc * 3 + bc - NYT) * RH_ - 1;
+            const int zu = T::HB + (T::ZU0 - T::NCORE + (cc + 3) * NYT + bc) * RH_ + 3, zd = T::HB + (T::ZD0 - T::NCORE + (cc - NZT) * NYT + bc) * RH_ - 1;
+            int fy[7], fz[7]; // by frame offset d + 3
 #pragma unroll
-        for (int mm = 0; mm < 7; ++mm) {
-            ox[mm] = T::lane_off(bc, cc, 0, si > 0, nj, nk, mm);
-            oy[mm] = T::lane_off(bc, cc, 1, sj > 0, nj, nk, mm);
-            oz[mm] = T::lane_off(bc, cc, 2, sk > 0, nj, nk, mm);
+            for (int d = -3; d <= 3; ++d) {
+                const int bq = bc + d, cq = cc + d;
+                fy[d + 3] = bq < 0 ? yu + d * (RH_ + 1) : (bq >= NYT ? yd + d * (RH_ + 1) : base + d * (RA_ + 1));
+                fz[d + 3] = cq < 0 ? zu + d * (NYT * RH_ + 1) : (cq >= NZT ? zd + d * (NYT * RH_ + 1) : base + d * (PS_ + 1));
+            }
+#pragma unroll
+            for (int mm = 0; mm < 7; ++mm) {
+                ox[mm] = base + (si > 0 ? mm - 3 : 3 - mm);
+                oy[mm] = sj > 0 ? fy[mm] : fy[6 - mm];
+                oz[mm] = sk > 0 ? fz[mm] : fz[6 - mm];
+            }
+        } else {
+#pragma unroll
+            for (int mm = 0; mm < 7; ++mm) {
+                ox[mm] = T::lane_off(bc, cc, 0, si > 0, nj, nk, mm);
+                oy[mm] = T::lane_off(bc, cc, 1, sj > 0, nj, nk, mm);
+                oz[mm] = T::lane_off(bc, cc, 2, sk > 0, nj, nk, mm);
+            }
         }
         const bool quirk_x = a.quirk_axis == 0, quirk_y = a.quirk_axis == 1;
 #pragma unroll 1
