@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSF_VERSION 102 /* 0.1.2: device-resident chain (lsf_mirror, lsf_write_vti, ...) */
+#define LSF_VERSION 103 /* 0.1.3: lsf_multi_configure / _info / _defaults (transports, judging window), lsf_mirror_forget */
 
 /* ---- return codes ---------------------------------------------------------------------- */
 #define LSF_OK 0
