@@ -341,7 +341,7 @@ def main() -> None:
         "roofline": roofline(prof, per_gpu_cells_per_sweep) or _job_roofline(cells_total / seconds, world, bytes_per_cell),
     }
     if world > 1:
-        out["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0  # world size as the RCCL backend reports it
+        out["rccl_ranks"] = _rccl_ranks(dist)  # world size as the RCCL backend reports it
     if not f32 and args.arith == "fast":
         # how long the FAST arithmetic of `value` stays within north_star's 1e-10 RMS of the reference's field, per BASELINE
         # configuration (profiles/micro/fast_valid.py on the GPU; STRICT holds it for any number of sweeps)
@@ -459,8 +459,8 @@ def main() -> None:
                                 "scaling": kind, "global_grid": r["global_grid"], "dims": r["dims"], "local_block": r["local_block"],
                                 "n_gpus": world, "value": r["cells_total"] / sec, "unit": "cell-updates/s",
                                 "ms_per_step": sec / K * 1e3, "roofline": _job_roofline(r["cells_total"] / sec, world, BYTES_PER_CELL_UPDATE),
-                                "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0),
-                                "transport": dist.get_backend(), "note": note})
+                                "rccl_ranks": _rccl_ranks(dist), "transport": (dist.get_backend() if dist.is_initialized() else "none"),
+                                "note": note})
                 torch.cuda.empty_cache()
 
             dims = lsd.default_dims(world)
@@ -479,11 +479,12 @@ def main() -> None:
                 dist.barrier(group=host_group)
                 if rank == 0 and not shared_gpu and torch.cuda.device_count() >= world:
                     try:
-                        sp = _single_process_entries(lib, world, 64 if N < 128 else 512, K, W, args.arith, transports=("peer", "rccl"))
+                        # appended to `entries` one by one (the peer-copy entries first): an RCCL entry that hangs on a node this code
+                        # has never seen takes only itself into the watchdog's error record
+                        _single_process_entries(lib, world, 64 if N < 128 else 512, K, W, args.arith, transports=("peer", "rccl"), sink=entries)
                     except Exception as e:  # noqa: BLE001
-                        sp = [{"path": "one process, lsf_multi", "value": None, "error": repr(e)[:300]}]
+                        entries.append({"path": "one process, lsf_multi", "value": None, "error": repr(e)[:300]})
                         failed = True
-                entries.extend(sp)
                 dist.barrier(group=host_group)
             decomposed = {"entries": entries,
                           "note": "Jacobi ordering (not reference-equal; bit-identical to the single-GPU Jacobi sweep), whole-job "
@@ -508,6 +509,11 @@ def main() -> None:
         sys.exit(3)
 
 
+def _rccl_ranks(dist):
+    """ranks of the job's RCCL communicator (torch.distributed backend "nccl" is RCCL on ROCm); 0 under gloo or without a group"""
+    return dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0
+
+
 def _job_roofline(cells_per_s, n_gpus, bytes_per_cell):
     """north_star: every multi-GPU number "as absolute numbers and as fraction of the HBM roofline" -- the job's algorithmic
     bytes per second against the sum of the HBM peaks of the GPUs it ran on (wall clock, halo exchange included)"""
@@ -517,7 +523,7 @@ def _job_roofline(cells_per_s, n_gpus, bytes_per_cell):
                     "K sweeps, not a kernel time"}
 
 
-def _single_process_entries(lib, world, G, K, W, arith, transports=("peer",)):
+def _single_process_entries(lib, world, G, K, W, arith, transports=("peer",), sink=None):
     """rank 0 only: the block-decomposed sweep through lsf_multi_* on 1, 2, 4, ... `world` devices, fixed G^3 grid, once per
     transport ("peer": peer copies; "rccl": ncclSend / ncclRecv behind the C ABI, needs a device per block)."""
     import numpy as np
@@ -525,7 +531,7 @@ def _single_process_entries(lib, world, G, K, W, arith, transports=("peer",)):
 
     from levelsetfortran_amd import _lib, fields
 
-    out = []
+    out = sink if sink is not None else []  # (a caller's list: what is measured survives a watchdog bail-out of a later entry)
     nd = 1
     counts = []
     while nd <= world:
@@ -535,9 +541,10 @@ def _single_process_entries(lib, world, G, K, W, arith, transports=("peer",)):
         counts.append(world)
     n = G - 1
     mode = _lib.LSF_ORDER_JACOBI | (_lib.LSF_ARITH_STRICT if arith == "strict" else _lib.LSF_ARITH_FAST)
-    for nd, tp in [(c, t) for t in transports for c in counts]:
-        if tp == "rccl" and nd == 1:
-            continue  # no neighbour, no message: the peer entry says it all
+
+    def measure(nd, tp):
+        if tp == "rccl" and (nd == 1 or nd != counts[-1]):
+            return  # one RCCL entry per job, on all of its devices (a single device has no neighbour, no message)
         devs = (ctypes.c_int * nd)(*range(nd))
         M = ctypes.c_void_p()
         _lib.check(lib.lsf_multi_create(n, n, n, devs, nd, None, 0, ctypes.byref(M)))
@@ -575,6 +582,16 @@ def _single_process_entries(lib, world, G, K, W, arith, transports=("peer",)):
                                 "thread start-up and final synchronisation)"})
         finally:
             _lib.check(lib.lsf_multi_destroy(M))
+
+    for nd, tp in [(c, t) for t in transports for c in counts]:
+        try:
+            measure(nd, tp)
+        except Exception as e:  # noqa: BLE001
+            if tp != "rccl":
+                raise
+            # the RCCL transport has never run on more than one device where this code was written: report, do not fail the job
+            out.append({"path": "one process, lsf_multi (C ABI), halos by RCCL ncclSend / ncclRecv", "n_gpus": nd, "transport": tp,
+                        "value": None, "error": repr(e)[:300]})
     return out
 
 
