@@ -155,11 +155,23 @@ def main() -> None:
     ap.add_argument("--decomposed-timeout", type=float, default=240.0,
                     help="seconds the decomposed measurement may take before the headline line is printed without it")
     ap.add_argument("--cpu-worker", default=None)
+    ap.add_argument("--multi-worker", default=None,
+                    help="internal: measure the one-process driver with the RCCL transport on --gpus devices and write the "
+                         "entries to this file (a child process of rank 0: a transport that has never run on more than one "
+                         "device where it was written must not be able to take the job with it)")
+    ap.add_argument("--multi-grid", type=int, default=512)
     ap.add_argument("--cpu-slab", type=int, default=20)
     ap.add_argument("--cpu-sweeps", type=int, default=8)
     args = ap.parse_args()
     if args.cpu_worker:
         _cpu_worker(args.cpu_worker, args.size, args.cpu_slab, args.cpu_sweeps)
+        return
+    if args.multi_worker:
+        from levelsetfortran_amd import _lib
+
+        ent = _single_process_entries(_lib.load(), args.gpus, args.multi_grid, args.steps, args.warmup, args.arith, transports=("rccl",))
+        with open(args.multi_worker, "w") as fh:
+            json.dump(ent, fh)
         return
     f32 = args.dtype == "f32"
     if f32:
@@ -481,7 +493,9 @@ def main() -> None:
                     try:
                         # appended to `entries` one by one (the peer-copy entries first): an RCCL entry that hangs on a node this code
                         # has never seen takes only itself into the watchdog's error record
-                        _single_process_entries(lib, world, 64 if N < 128 else 512, K, W, args.arith, transports=("peer", "rccl"), sink=entries)
+                        Gs = 64 if N < 128 else 512
+                        _single_process_entries(lib, world, Gs, K, W, args.arith, transports=("peer",), sink=entries)
+                        entries.extend(_rccl_entries_in_a_child(world, Gs, K, W, args.arith))
                     except Exception as e:  # noqa: BLE001
                         entries.append({"path": "one process, lsf_multi", "value": None, "error": repr(e)[:300]})
                         failed = True
@@ -507,6 +521,23 @@ def main() -> None:
         watchdog.cancel()
     if failed:
         sys.exit(3)
+
+
+def _rccl_entries_in_a_child(world, G, K, W, arith, timeout=150.0):
+    """the one-process driver with the RCCL transport (include/lsf.h: LSF_TRANSPORT_RCCL) on `world` devices, measured by a child
+    process with a time limit: whatever happens in there ends up as an entry (a number, or an error), never as a hung job"""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "rccl.json")
+        cmd = [sys.executable, os.path.abspath(__file__), "--multi-worker", out, "--gpus", str(world), "--multi-grid", str(G),
+               "--steps", str(K), "--warmup", str(W), "--arith", arith]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                 "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+        try:
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=timeout, env=env)
+            return json.load(open(out))
+        except Exception as e:  # noqa: BLE001
+            return [{"path": "one process, lsf_multi (C ABI), halos by RCCL ncclSend / ncclRecv", "n_gpus": world, "transport": "rccl",
+                     "value": None, "error": repr(e)[:300]}]
 
 
 def _rccl_ranks(dist):
