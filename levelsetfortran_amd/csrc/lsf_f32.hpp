@@ -138,10 +138,11 @@ __device__ __forceinline__ void weno_axis_from_ifaces_f32(const f2 q[7], f2& dm,
 // sg = sign(phic) (+1 / -1): max(max(sg dm, 0)^2, min(sg dp, 0)^2) is the reference's switch in one expression.
 __device__ __forceinline__ f2 godunov_f32(f2 sg, f2 dm, f2 dp)
 {
-    const f2 u = sg * dm, v = sg * dp;
-    const f2 ua = mk2(__builtin_fmaxf(u.x, 0.f), __builtin_fmaxf(u.y, 0.f));
-    const f2 ub = mk2(__builtin_fminf(v.x, 0.f), __builtin_fminf(v.y, 0.f));
-    return max2(ua * ua, ub * ub);
+    // = m^2 with m = max(sg dm, -sg dp, 0): the larger of two squares of non-negative numbers is the square of the larger
+    // number (lsf_cell.hpp: axis_godunov)
+    const f2 u = sg * dm, w = -sg * dp;
+    const f2 m = mk2(__builtin_fmaxf(__builtin_fmaxf(u.x, w.x), 0.f), __builtin_fmaxf(__builtin_fmaxf(u.y, w.y), 0.f));
+    return m * m;
 }
 
 // gM, smeared sign and Euler step (subs.f90:702, :169, :749-750) for the pair; S = gX+gY+gZ unscaled
