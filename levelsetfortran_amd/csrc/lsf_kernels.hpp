@@ -186,6 +186,9 @@ __global__ __launch_bounds__(64 * WX * BY) __attribute__((amdgpu_waves_per_eu(5)
         const bool cell = xl >= 1 && li < hi0 && lj < hi1;     // the lane owns a cell of this launch
         const int gi = li + bx.gx0, gj = lj + bx.gy0;
         const bool ij_weno = gi > 3 && gi < bx.nx - 4 && gj > 3 && gj < bx.ny - 4;
+        // every lane of this wavefront takes the WENO branch as far as i and j go (six wavefronts of eight at 512^3): its
+        // first-order fix-ups are then skipped by a scalar branch instead of being evaluated and selected away per lane
+        const bool wave_ij_weno = __builtin_amdgcn_ballot_w64(ij_weno) == ~0ull;
         const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
         // Addressing: one buffer descriptor per k-plane (rebuilt on the scalar unit every step, base = the plane) + 32-bit
         // byte offsets inside the plane that do not change along the march.  No load of the loop sits behind a branch:
@@ -254,16 +257,18 @@ __global__ __launch_bounds__(64 * WX * BY) __attribute__((amdgpu_waves_per_eu(5)
             }
             // ---- y (per-cell form), Godunov, sign, Euler step
             double a, b, c, d, e, f;
-            if (weno_ok) {
-                a = __builtin_fma(1.0 / 12.0, cen_x, -pwm_l);
-                b = __builtin_fma(1.0 / 12.0, cen_x, pwp_x);
-                e = __builtin_fma(1.0 / 12.0, cen_z, -pwm_z);
-                f = __builtin_fma(1.0 / 12.0, cen_z, pwp_z);
-            } else {
-                a = phic - vx[1], b = vx[3] - phic;
-                e = phic - qz[2], f = qz[4] - phic;
+            a = __builtin_fma(1.0 / 12.0, cen_x, -pwm_l);
+            b = __builtin_fma(1.0 / 12.0, cen_x, pwp_x);
+            e = __builtin_fma(1.0 / 12.0, cen_z, -pwm_z);
+            f = __builtin_fma(1.0 / 12.0, cen_z, pwp_z);
+            weno_axis_fast(qy, floor2, true, c, d);
+            if (!(wave_ij_weno && gk > 3 && gk < bx.nz - 4)) { // wavefront-uniform: some lane is within three cells of a wall
+                if (!weno_ok) {                                 // first-order one-sided differences (subs.f90:657-662)
+                    a = phic - vx[1], b = vx[3] - phic;
+                    c = phic - qy[2], d = qy[4] - phic;
+                    e = phic - qz[2], f = qz[4] - phic;
+                }
             }
-            axis_pair<false>(qy, weno_ok, true, dx, floor2, c, d);
             const double newv = finish_update<false>(phic, axis_godunov<false>(phic, a, b), axis_godunov<false>(phic, c, d),
                                                      axis_godunov<false>(phic, e, f), pS, dx, inv_dx, h);
             if (cell) {
