@@ -335,6 +335,8 @@ __global__ __launch_bounds__(64 * WX) void k_reinit_jacobi_f32_sh(const float* _
         const bool i_weno = gi > 3 && gi < bx.nx - 4;
         const bool jA = i_weno && gj > 3 && gj < bx.ny - 4;
         const bool jB = i_weno && two && gj + 1 > 3 && gj + 1 < bx.ny - 4;
+        // every lane of this wavefront takes the WENO branch as far as i and j go (a lane without a second row: its unused half)
+        const bool wave_weno = __builtin_amdgcn_ballot_w64(jA && (jB || !two)) == ~0ull;
         const float inv_dx = 1.0f / dx, dx2 = dx * dx;
         const bool on_xwall = xwall && cell && (gi == 1 || gi == bx.nx - 1);
         // byte offsets inside a k-plane, fixed along the march: the lane's two points, their x neighbours (colA/B - 8 +
@@ -392,20 +394,22 @@ __global__ __launch_bounds__(64 * WX) void k_reinit_jacobi_f32_sh(const float* _
                 if (lane == 0 && wx > 0) pwm_l = xch[pb][wx - 1];
                 pb ^= 1;
             }
-            // first-order one-sided differences (subs.f90:657-662), always valid; WENO where the branch test holds
-            f2 a = c - vx[1], b = vx[3] - c;
-            f2 cc = c - mk2(r2, c.x), d = mk2(c.y, r5) - c;
-            f2 e = c - qz[2], f = qz[4] - c;
+            // WENO everywhere; first-order one-sided differences (subs.f90:657-662) where the branch test fails -- behind a
+            // wavefront-uniform branch, so that a wavefront whose cells all take the WENO branch neither evaluates nor selects them
+            const f2 twelfth = splat(1.0f / 12.0f);
+            f2 a = fma2(twelfth, cen_x, -pwm_l), b = fma2(twelfth, cen_x, pwp_x);
+            f2 e = fma2(twelfth, cen_z, -pwm_z), f = fma2(twelfth, cen_z, pwp_z);
+            f2 cc, d;
             {
-                const f2 twelfth = splat(1.0f / 12.0f);
-                const f2 wa = fma2(twelfth, cen_x, -pwm_l), wb = fma2(twelfth, cen_x, pwp_x);
-                const f2 we = fma2(twelfth, cen_z, -pwm_z), wf = fma2(twelfth, cen_z, pwp_z);
-                f2 qy[7], wc, wd;
+                f2 qy[7];
                 qy[0] = mk2(r0, r1), qy[1] = mk2(r1, r2), qy[2] = mk2(r2, c.x), qy[3] = c;
                 qy[4] = mk2(c.y, r5), qy[5] = mk2(r5, r6), qy[6] = mk2(r6, r7);
-                weno_axis_f32(qy, true, wc, wd);
-                if (wA) a.x = wa.x, b.x = wb.x, cc.x = wc.x, d.x = wd.x, e.x = we.x, f.x = wf.x;
-                if (wB) a.y = wa.y, b.y = wb.y, cc.y = wc.y, d.y = wd.y, e.y = we.y, f.y = wf.y;
+                weno_axis_f32(qy, true, cc, d);
+            }
+            if (!(wave_weno && k_weno)) {
+                const f2 a1 = c - vx[1], b1 = vx[3] - c, c1 = c - mk2(r2, c.x), d1 = mk2(c.y, r5) - c, e1 = c - qz[2], f1 = qz[4] - c;
+                if (!wA) a.x = a1.x, b.x = b1.x, cc.x = c1.x, d.x = d1.x, e.x = e1.x, f.x = f1.x;
+                if (!wB) a.y = a1.y, b.y = b1.y, cc.y = c1.y, d.y = d1.y, e.y = e1.y, f.y = f1.y;
             }
             const f2 sg = mk2(c.x > 0.f ? 1.f : -1.f, c.y > 0.f ? 1.f : -1.f);
             const f2 S = godunov_f32(sg, a, b) + godunov_f32(sg, cc, d) + godunov_f32(sg, e, f);
