@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSF_VERSION 103 /* 0.1.3: lsf_multi_configure / _info / _defaults (transports, judging window), lsf_mirror_forget */
+#define LSF_VERSION 104 /* 0.1.4: lsf_reinit_multi takes LSF_ORDER_GS (the reference's ordering over z slabs), lsf_slabs_info */
 
 /* ---- return codes ---------------------------------------------------------------------- */
 #define LSF_OK 0
@@ -252,15 +252,28 @@ int lsf_stl_get(double *surfX, int32_t *surfElem);
  * lsf_reinit_multi has lsf_reinit's arguments plus a device list.  The field is split into dims[0] x dims[1] x dims[2]
  * blocks (dims NULL: 1x1x2, 1x2x2, 2x2x2 for 2, 4, 8 devices -- BASELINE configurations 4 and 5; x, the unit-stride
  * axis, is cut last -- otherwise the prime factors dealt to z, y, x in turn), one block per entry of `devices`; the
- * library runs the Jacobi sweep (LSF_ORDER_JACOBI only: the reference's in-place ordering does not shard, SURVEY.md
- * section 8e) with 3-cell face halos copied peer to peer
+ * library runs the Jacobi sweep (LSF_ORDER_JACOBI; for LSF_ORDER_GS see below) with 3-cell face halos copied peer to peer
  * over xGMI on a communication stream per device while the interior cells are updated on the compute stream, and one
  * host thread per device that only enqueues; the RMS of sweep s is judged while sweep s + 1 runs.  The result is bit-
  * identical to lsf_reinit with the same mode on one device.  `devices` may name a device more than once (several blocks
  * share it): that is how the path is tested on a one-GPU machine.  `phi` is a HOST array; a device twin of it left by
  * an earlier seam call (lsf_mirror) is brought home first and dropped afterwards.  The lsf_multi_* calls are the same
- * thing in pieces, for callers that keep the blocks resident (bench.py). */
+ * thing in pieces, for callers that keep the blocks resident (bench.py).
+ *
+ * LSF_ORDER_GS (fp64; dims NULL or {1, 1, ndev}): the reference's in-place ordering (subs.f90:743-852) itself, over ndev
+ * slabs of tile layers in z, devices[0] at k = 0.  Every slab runs the dataflow launch of lsf_reinit on its own tile columns
+ * of the SAME tile graph; the three planes next to a cut, a flag per tile next to it, a hyperplane counter per sweep and the
+ * sweep's stop verdict are stored by the producing kernel straight into the neighbour's memory (peer stores over xGMI,
+ * system scope, drained before the flag that announces them).  Field, sweep count and RMS trace are those of lsf_reinit
+ * with the same mode, bit for bit -- with LSF_ARITH_STRICT the reference's.  Field memory per device is its slab plus three
+ * planes per cut.  Needs peer access between neighbouring devices; slabs that share a device (the one-GPU rehearsal) need
+ * their launches resident together: at most three per device unless GPU_MAX_HW_QUEUES is raised.  A tile that waits longer
+ * than 4 s for a predecessor ends the call with LSF_ERR_HIP on every slab (bounded spins, no hang).  lsf_slabs_info: the
+ * last such call of this thread -- slabs, resident blocks per slab, whether the shared buffers were fine-grained
+ * allocations (LSF_SLAB_FINEGRAINED = 0 / 1 overrides: on when the devices differ), sweeps, and the time the longest of the
+ * slabs' launches took (device events; uploads, transpositions and downloads excluded). */
 typedef struct lsf_multi lsf_multi;
+int lsf_slabs_info(int *slabs, int *blocks_per_slab, int *finegrained, int *sweeps, double *kernel_s);
 int lsf_reinit_multi(double *phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,
                      const int *devices, int ndev, const int dims[3], int *sweeps_done, double *rms_trace, int trace_cap);
 int lsf_reinit_multi_f32(float *phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,

@@ -89,6 +89,7 @@ SIGNATURES = {
     "lsf_multi_upload_block": (c_int, [c_void_p, c_int, c_void_p]),
     "lsf_multi_run": (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_int, POINTER(c_int), c_void_p, c_int]),
     "lsf_multi_gather": (c_int, [c_void_p, c_void_p]),
+    "lsf_slabs_info": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_double)]),
     "lsf_multi_defaults": (c_int, [c_int, c_int]),
     "lsf_multi_configure": (c_int, [c_void_p, c_int, c_int]),
     "lsf_multi_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_double),

@@ -2268,6 +2268,20 @@ Rccl::~Rccl()
 // LSF_MULTI_CHECK_EVERY in the environment override them: the Fortran host has no other way in)
 static int g_multi_check_every = 8, g_multi_transport = LSF_TRANSPORT_PEER;
 
+// the lsf_multi_* calls visit other devices: the calling thread gets its own device back (HIP's and the library's)
+struct DeviceRestore {
+    int hip_dev = -1, lsf_dev = 0;
+    DeviceRestore() : lsf_dev(g_device) { if (hipGetDevice(&hip_dev) != hipSuccess) hip_dev = -1; (void)hipGetLastError(); }
+    ~DeviceRestore()
+    {
+        g_device = lsf_dev;
+        if (hip_dev >= 0) (void)hipSetDevice(hip_dev);
+    }
+};
+
+// ---- the exact ordering across z slabs, one launch per device (lsf_reinit_multi with LSF_ORDER_GS) --------------------
+#include "lsf_gs_slabs.hpp"
+
 extern "C" {
 
 int lsf_multi_defaults(int check_every, int transport)
@@ -2327,17 +2341,6 @@ int lsf_multi_info(const lsf_multi* M, int* check_every, int* transport, int* rc
     if (sweeps_enqueued) *sweeps_enqueued = M->last_sweeps_enqueued;
     return LSF_OK;
 }
-
-// the lsf_multi_* calls visit other devices: the calling thread gets its own device back (HIP's and the library's)
-struct DeviceRestore {
-    int hip_dev = -1, lsf_dev = 0;
-    DeviceRestore() : lsf_dev(g_device) { if (hipGetDevice(&hip_dev) != hipSuccess) hip_dev = -1; (void)hipGetLastError(); }
-    ~DeviceRestore()
-    {
-        g_device = lsf_dev;
-        if (hip_dev >= 0) (void)hipSetDevice(hip_dev);
-    }
-};
 
 int lsf_multi_create(int nx, int ny, int nz, const int* devices, int ndev, const int dims_in[3], int f32, lsf_multi** out)
 {
@@ -2496,6 +2499,11 @@ static int reinit_multi_any(void* phi, int f32, int nx, int ny, int nz, int iter
                             const int* devices, int ndev, const int dims[3], int* sweeps_done, double* rms_trace, int trace_cap)
 {
     if (!phi) return fail(LSF_ERR_INVALID, "phi is NULL");
+    if (!devices || ndev < 1) return fail(LSF_ERR_INVALID, "empty device list");
+    const bool exact = (mode & LSF_ORDER_MASK) == LSF_ORDER_GS;
+    if (exact && f32) return fail(LSF_ERR_INVALID, "single precision: LSF_ORDER_JACOBI | LSF_ARITH_FAST only");
+    if (exact && dims && (dims[0] != 1 || dims[1] != 1 || dims[2] != ndev))
+        return fail(LSF_ERR_INVALID, "LSF_ORDER_GS shards into z slabs: dims must be NULL or {1, 1, ndev}");
     lsf_multi* M = nullptr;
     int rc = LSF_OK;
     // The blocks are scattered from and gathered into the HOST array.  If an earlier seam call left the latest content of
@@ -2508,6 +2516,11 @@ static int reinit_multi_any(void* phi, int f32, int nx, int ny, int nz, int iter
             HIPCHK(hipMemcpy(phi, ctx().slot[sl].p, tw->bytes, hipMemcpyDeviceToHost));
             tw->host_stale = false;
         }
+    }
+    if (exact) { // the reference's ordering, slab by slab (lsf_gs_slabs.hpp): same field as lsf_reinit, bit for bit
+        if (tw) tw->current = false;
+        if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
+        return reinit_gs_slabs((double*)phi, nx, ny, nz, iter, dx, h, tol, mode, devices, ndev, sweeps_done, rms_trace, trace_cap);
     }
     rc = lsf_multi_create(nx, ny, nz, devices, ndev, dims, f32, &M);
     if (rc) return rc;
@@ -2531,6 +2544,17 @@ int lsf_reinit_multi(double* phi, int nx, int ny, int nz, int iter, double dx, d
 {
     Trace trace_("lsf_reinit_multi");
     return reinit_multi_any(phi, 0, nx, ny, nz, iter, dx, h, tol, mode, devices, ndev, dims, sweeps_done, rms_trace, trace_cap);
+}
+
+int lsf_slabs_info(int* slabs, int* blocks_per_slab, int* finegrained, int* sweeps, double* kernel_s)
+{
+    const lsfs::SlabReport& r = lsfs::g_slab_report;
+    if (slabs) *slabs = r.slabs;
+    if (blocks_per_slab) *blocks_per_slab = r.grid;
+    if (finegrained) *finegrained = r.fine;
+    if (sweeps) *sweeps = r.sweeps;
+    if (kernel_s) *kernel_s = r.kernel_ms * 1e-3;
+    return LSF_OK;
 }
 
 int lsf_reinit_multi_f32(float* phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode, const int* devices,

@@ -62,6 +62,20 @@ struct GsArgs {
     unsigned long long timeout_ticks; // bound of every spin of the dataflow launch (100 MHz ticks)
     const uint32_t* tables;  // skewed tiles: lookup tables of the tile shape (SkTile: rel_tab | off_tab), or NULL
     unsigned long long* dbg; // optional phase timers (s_memrealtime ticks): wait, load, march, publish, tasks
+    // exact ordering across z slabs (k_reinit_gs_slab, lsf_gs_slabs.hpp): this launch owns the tile columns tk_lo <= tk < tk_hi of
+    // the same global tile graph; every slab holds field buffers with the global address map, of which its own planes and the
+    // three planes beyond each cut are kept current (the neighbour stores them there)
+    int slab, nslab, tk_lo, tk_hi;
+    double* nb_buf[2][4];          // field buffers of the lower / upper neighbour slab, NULL at the ends of the grid
+    int* nb_tile_done[2];          // its tile_done (same indexing)
+    int* nb_pd[2];                 // the row of the neighbour's planes_done mirror that follows THIS slab
+    const int* pd_of_nb[2];        // this slab's mirror of the neighbour's planes_done (unused where nb_pd is NULL)
+    int* verdict;                  // [nsweeps] 0 = unknown, 1 = go on, 2 = stop: condition (c) across slabs
+    int* all_ctl[8];               // ctl / verdict / trace / colsum of every slab, this one included (set by the sweep epilogue
+    int* all_verdict[8];           // resp. by the tiles of the slabs that do not run it)
+    double* all_trace[8];
+    double* all_colsum[8];
+    const int* plane_size_neg;     // tiles of this slab per hyperplane in sweeps that run against z (plane_size: along z)
 };
 
 __device__ __forceinline__ double ld_sc1(const double* p)
@@ -71,6 +85,23 @@ __device__ __forceinline__ double ld_sc1(const double* p)
 __device__ __forceinline__ void st_sc1(double* p, double v)
 {
     __hip_atomic_store((long long*)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// system scope: the other side of the access may be another device (slabs of the exact ordering)
+__device__ __forceinline__ double ld_sys(const double* p)
+{
+    return __longlong_as_double(__hip_atomic_load((const long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__device__ __forceinline__ void st_sys(double* p, double v)
+{
+    __hip_atomic_store((long long*)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ int ld_flag_sys(const int* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_flag_sys(int* p, int v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ int ld_flag(const int* p)
 {

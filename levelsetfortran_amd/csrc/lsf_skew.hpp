@@ -214,7 +214,12 @@ __device__ __forceinline__ SkPre sk_prefetch(const GsArgs& a)
 // dataflow launch waits there for the upstream tiles (k_reinit_gs_persist), so that most of a tile's bytes travel while the
 // block would otherwise be idle; it returns false when the tile must be abandoned (stop flag, time-out).
 // Returns true when the tile has been computed and stored.
-template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, class WaitUp>
+//
+// PUSH (slabs of the exact ordering, k_reinit_gs_slab): the tile belongs to one of several launches that share the tile graph,
+// each with field buffers of its own.  Results within three planes of a cut are stored into the neighbour's buffer as well
+// (same address map), the column's running RMS sum into the colsum of the slab that runs this sweep's epilogue, and the
+// epilogue's verdict into every slab's control words; all of that and every load at system scope.
+template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, bool PUSH = false, class WaitUp>
 __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int g, int si, int sj, int sk, const SkPre& pre,
                                           WaitUp&& wait_upstream)
 {
@@ -231,9 +236,10 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
     const int ncol = a.nTj * a.nTk;
 
-    auto ldp = [](const double* p_) { return SC1 ? ld_sc1(p_) : *p_; };
+    auto ldp = [](const double* p_) { return PUSH ? ld_sys(p_) : (SC1 ? ld_sc1(p_) : *p_); };
     auto stp = [](double* p_, double v_) {
-        if (SC1) st_sc1(p_, v_);
+        if (PUSH) st_sys(p_, v_);
+        else if (SC1) st_sc1(p_, v_);
         else *p_ = v_;
     };
 
@@ -317,7 +323,7 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     // odd entries per bundle row no longer cost separate scattered requests.
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));
     constexpr int AUX_SC1 = SC1 ? 16 : 0; // cache policy of the buffer instructions: sc1 = bit 4
-    const bool widex = (LSF_SKEW_WIDE == 2 || (LSF_SKEW_WIDE == 1 && BY == 16)) && deep && X0 - (NYT + NZT + 4) >= 0 && X0 + 22 <= nxi - 1 &&
+    const bool widex = !PUSH && (LSF_SKEW_WIDE == 2 || (LSF_SKEW_WIDE == 1 && BY == 16)) && deep && X0 - (NYT + NZT + 4) >= 0 && X0 + 22 <= nxi - 1 &&
                        (double)(NZT + 7) * (double)sxy * 8.0 < 4.0e9;
     if (widex) {
         const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(in_t), 0, 0x7fffffff, 0x00020000);
@@ -635,7 +641,15 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
                 __builtin_amdgcn_raw_buffer_store_b128(pk, r_out, 8u * el, 0, AUX_SC1);
             }
         }
-    } else
+    } else {
+    // slabs: the planes [k_own_lo, k_own_lo + 3) also live in the lower neighbour's buffer, [k_own_hi - 3, k_own_hi) in the upper one's
+    [[maybe_unused]] double *nb_lo = nullptr, *nb_hi = nullptr;
+    [[maybe_unused]] int k_push_lo = 0, k_push_hi = 0;
+    if constexpr (PUSH) {
+        const int ob = gb + 1 == a.nbuf ? 0 : gb + 1;
+        nb_lo = a.nb_buf[0][ob], nb_hi = a.nb_buf[1][ob];
+        k_push_lo = 1 + a.tk_lo * NZT + 3, k_push_hi = min(1 + a.tk_hi * NZT, nz) - 3;
+    }
 #pragma unroll
     for (int u = 0; u < T::NCORE / (4 * W); ++u) {
         const int r = 4 * W * u + (tid >> 4), cq = r / NYT, bq = r - NYT * cq, t = tid & 15;
@@ -644,6 +658,11 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
         const bool mine = bq < nj && cq < nk && (unsigned)(gi - 1) <= (unsigned)(nx - 2);
         const double val0 = lds[T::core_at(r) + 3 + t];
         if (mine) stp(out_t + ((unsigned)(e.x >> 2) + (unsigned)gi), val0);
+        if constexpr (PUSH) {
+            const int gk2 = k_lo + (sk > 0 ? cq : nk - 1 - cq);
+            if (mine && nb_lo && gk2 < k_push_lo) st_sys(nb_lo + org + ((unsigned)(e.x >> 2) + (unsigned)gi), val0);
+            if (mine && nb_hi && gk2 >= k_push_hi) st_sys(nb_hi + org + ((unsigned)(e.x >> 2) + (unsigned)gi), val0);
+        }
         if (near_wall && mine) {
             const int gj2 = j_lo + (sj > 0 ? bq : nj - 1 - bq), gk2 = k_lo + (sk > 0 ? cq : nk - 1 - cq);
             // wall points that clamp to this cell: move outward along any non-empty subset of its wall-adjacent axes
@@ -664,10 +683,15 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
                     const long p = wi + sx * wj + sxy * wk;
                     const double dlt = val - ldp(in + p);
                     stp(out + p, val);
+                    if constexpr (PUSH) {
+                        if (nb_lo && wk < k_push_lo) st_sys(nb_lo + p, val);
+                        if (nb_hi && wk >= k_push_hi) st_sys(nb_hi + p, val);
+                    }
                     acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
                 }
             }
         }
+    }
     }
     acc = wave_sum(acc);
     if (W > 1) { // fixed-order sum over the wavefronts of the tile
@@ -681,6 +705,10 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     if (tid == 0) {
         double* slot = a.colsum + (long)gb * ncol + (tj + (long)a.nTj * tk);
         stp(slot, colsum_prev + acc);
+        if constexpr (PUSH) { // the sweep's last tile (frame C = nTk - 1) sums the columns of every slab
+            const int epi = sk > 0 ? a.nslab - 1 : 0;
+            if (epi != a.slab) st_sys(a.all_colsum[epi] + (long)gb * ncol + (tj + (long)a.nTj * tk), colsum_prev + acc);
+        }
     }
     if (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // results are at the memory side before anyone is told
 #ifdef LSF_EXPERIMENTS
@@ -702,10 +730,23 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     tsum = wave_sum(tsum);
     if (lane == 0) {
         const double rms = __builtin_sqrt(tsum / a.den);
-        if (g < a.trace_cap) a.trace[g] = rms;
-        st_flag(a.ctl + 1, g + 1);
-        if (rms < a.tol) st_flag(a.ctl + 0, 1);
-        else if (rms != rms) { st_flag(a.ctl + 2, 1); st_flag(a.ctl + 0, 1); }
+        if constexpr (PUSH) {
+            // the epilogues of consecutive sweeps are ordered (the last tile of a sweep waits for every hyperplane of the sweep
+            // before), so a stop raised earlier -- here or on another slab, which stored it here before it finished -- is seen
+            const bool stop = rms < a.tol || rms != rms || ld_flag_sys(a.ctl + 0) != 0;
+            for (int q = 0; q < a.nslab; ++q) {
+                if (g < a.trace_cap) st_sys(a.all_trace[q] + g, rms);
+                st_flag_sys(a.all_ctl[q] + 1, g + 1);
+                if (rms != rms) st_flag_sys(a.all_ctl[q] + 2, 1);
+                if (stop) st_flag_sys(a.all_ctl[q] + 0, 1);
+                st_flag_sys(a.all_verdict[q] + (g - a.g0), stop ? 2 : 1); // the verdict travels in the word the waiters poll
+            }
+        } else {
+            if (g < a.trace_cap) a.trace[g] = rms;
+            st_flag(a.ctl + 1, g + 1);
+            if (rms < a.tol) st_flag(a.ctl + 0, 1);
+            else if (rms != rms) { st_flag(a.ctl + 2, 1); st_flag(a.ctl + 0, 1); }
+        }
     }
     return true;
 }
@@ -937,6 +978,173 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 atomicAdd(a.dbg + 2, 1ull);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Exact ordering across z slabs: the dataflow schedule above, one launch PER SLAB (one device each; several on one device
+// for the rehearsal), all working on the same tile graph.  A slab owns the tile columns tk_lo <= tk < tk_hi; its task list
+// is the global list (slot order) restricted to them, so every tile a block waits for -- on this slab or on a neighbour --
+// precedes it in the global order and has been taken by a resident block of its slab: no deadlock as long as every launch
+// is resident at once, which is why this kernel is a loop over tickets with a grid the host sizes to the device's share
+// (k_reinit_gs_persist is one block per tile).  Differences from the single launch:
+//   (a)  the flag of an upstream tile across the cut is raised HERE by the neighbour's block, after it has stored the three
+//        planes next to the cut into this slab's buffer and drained them (skew_tile<PUSH>);
+//   (b)  "sweep s - 1 has completed the hyperplanes within reach" is asked of this slab's own hyperplane counter AND of the
+//        mirrors of its two neighbours' counters (a tile reaches at most into the adjacent slab), pushed by atomic max;
+//   (c)  the stop verdict of sweep s - nbuf is its own word per sweep, stored on every slab by the epilogue;
+//   the stop flag, the NaN / time-out status, the sweep count and the RMS trace are stored on every slab as well.
+// Every cross-slab word and value is stored and loaded at system scope (write-through to the fabric, loads past the caches);
+// stores are drained (s_waitcnt vmcnt(0)) before the flag that announces them is raised.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_order_slab(uint2* __restrict__ order, const uint32_t* __restrict__ tiles_pos,
+                                                          const uint32_t* __restrict__ tiles_neg, const int* __restrict__ off_pos,
+                                                          const int* __restrict__ off_neg, const int* __restrict__ sweep_tab,
+                                                          const int* __restrict__ start, const unsigned* __restrict__ slot_base, int ns, int np)
+{
+    const int slot = blockIdx.x;
+    unsigned base = slot_base[slot];
+    for (int q = 0; q < ns; ++q) {
+        const int P = slot - start[q];
+        if (P < 0) break; // start[] is increasing
+        if (P >= np) continue;
+        const bool pos = sweep_tab[4 * q + 2] > 0;
+        const int* po = pos ? off_pos : off_neg;
+        const uint32_t* tl = pos ? tiles_pos : tiles_neg;
+        const int o = po[P], cnt = po[P + 1] - o;
+        const unsigned tag = (unsigned)q | ((unsigned)P << DF_SWEEP_BITS);
+        for (int i = threadIdx.x; i < cnt; i += 256) order[base + i] = make_uint2(tl[o + i], tag);
+        base += (unsigned)cnt;
+    }
+}
+
+template <int TA, int WY, int WZ, int BY, bool STRICT>
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_slab(GsArgs a)
+{
+    using T = SkTile<TA, WY, WZ, BY>;
+    __shared__ int sh_task[8]; // as in k_reinit_gs_persist
+    const int tid = threadIdx.x;
+    const int np = a.np;
+    const int nM = a.nM;
+    const long per_sweep = (long)nM * a.nTj * a.nTk;
+    const SkPre pre = sk_prefetch<TA, WY, WZ, BY>(a);
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    for (;;) {
+        const int *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
+        unsigned long long t0 = 0;
+        auto give_up = [&]() { __hip_atomic_fetch_max(a.ticket, (int)a.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        auto time_out = [&]() { // tell every slab, so that none of them spins on for a tile that will not come
+            for (int q = 0; q < a.nslab; ++q) st_flag_sys(a.all_ctl[q] + 2, 2), st_flag_sys(a.all_ctl[q] + 0, 1);
+        };
+        if (tid == 0) {
+            const long t = (long)__hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int go = 0;
+            uint2 e = make_uint2(0u, 0u);
+            if (t < a.total) {
+                e = a.order[t];
+                const int s = (int)(e.y & (unsigned)(DF_BATCH - 1)), P = (int)(e.y >> DF_SWEEP_BITS);
+                const int m = e.x & 0x3ff, B = (e.x >> 10) & 0x3ff, C = (e.x >> 20) & 0x3ff;
+                auto m_lo = [&](int B_, int C_) { return (T::NYT * B_ + T::NZT * C_) / TA; };
+                auto m_hi = [&](int B_, int C_) { return (T::NYT * B_ + T::NYT - 1 + T::NZT * C_ + T::NZT - 1 + a.nx - 2) / TA; };
+                const int* td = a.tile_done + s * per_sweep; // the neighbour raises the flags of its tiles next to the cut here
+                w0 = m - 1 >= m_lo(B, C) ? td + (m - 1) + (long)nM * (B + (long)a.nTj * C) : nullptr;
+                w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : nullptr;
+                w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : nullptr;
+                const int need1 = s == 0 ? 0 : min(P + a.sweep_tab[4 * s + 3], np);
+                const int* always = a.ctl + 4; // INT_MAX (host)
+                const int* p3 = s == 0 ? always : a.planes_done + s - 1;
+                const int* p3l = (s == 0 || !a.nb_pd[0]) ? always : a.pd_of_nb[0] + s - 1;
+                const int* p3h = (s == 0 || !a.nb_pd[1]) ? always : a.pd_of_nb[1] + s - 1;
+                const int* p4 = s < a.nbuf ? always : a.verdict + s - a.nbuf;
+                t0 = __builtin_amdgcn_s_memrealtime();
+                go = 1;
+                for (;;) { // stage 1: conditions (b) and (c)
+                    const int vstop = ld_flag_sys(a.ctl + 0);
+                    const int v3 = ld_flag(p3), v3l = ld_flag_sys(p3l), v3h = ld_flag_sys(p3h), v4 = ld_flag_sys(p4);
+                    if (vstop != 0) {
+                        go = 2;
+                        give_up();
+                        break;
+                    }
+                    if ((v3 >= need1) & (v3l >= need1) & (v3h >= need1) & (v4 != 0)) {
+                        if (s >= a.nbuf && v4 == 2) { // the sweep whose result this one would overwrite was the last one
+                            go = 2;
+                            give_up();
+                        }
+                        break;
+                    }
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+                        time_out();
+                        go = 2;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                sh_task[3] = a.sweep_tab[4 * s], sh_task[4] = a.sweep_tab[4 * s + 1], sh_task[5] = a.sweep_tab[4 * s + 2];
+            }
+            sh_task[0] = (int)e.x, sh_task[1] = (int)e.y, sh_task[2] = go;
+        }
+        __syncthreads();
+        const uint32_t packed = (uint32_t)uni(sh_task[0]);
+        const int sP = uni(sh_task[1]);
+        int go = uni(sh_task[2]);
+        const int s = sP & (DF_BATCH - 1), P = (int)((unsigned)sP >> DF_SWEEP_BITS);
+        if (go == 0) return; // the list is exhausted (or was cut short: stop, time-out)
+        const int sk = uni(sh_task[5]);
+        auto wait_upstream = [&]() -> bool { // stage 2: condition (a)
+            if (tid == 0) {
+                int go2 = 1;
+                for (;;) {
+                    const int vstop = ld_flag_sys(a.ctl + 0);
+                    const int v0 = w0 ? ld_flag(w0) : 1, v1 = w1 ? ld_flag(w1) : 1, v2 = w2 ? ld_flag_sys(w2) : 1;
+                    if (vstop != 0) {
+                        go2 = 2;
+                        give_up();
+                        break;
+                    }
+                    if ((v0 != 0) & (v1 != 0) & (v2 != 0)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+                        time_out();
+                        go2 = 2;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                sh_task[6] = go2;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            return uni(sh_task[6]) == 1;
+        };
+        if (go == 1) {
+            if (!skew_tile<TA, WY, WZ, BY, STRICT, true, true>(a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), sk, pre, wait_upstream))
+                go = 2;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads(); // every wave of the tile has drained its stores, the neighbours' copies included
+        if (tid == 0 && go == 1) {
+            const int m = packed & 0x3ff, B = (packed >> 10) & 0x3ff, C = (packed >> 20) & 0x3ff;
+            const long fl = s * per_sweep + m + (long)nM * (B + (long)a.nTj * C);
+            st_flag(a.tile_done + fl, 1);
+            const int tk = sk > 0 ? C : a.nTk - 1 - C;
+            if (tk == a.tk_lo && a.nb_tile_done[0]) st_flag_sys(a.nb_tile_done[0] + fl, 1);
+            if (tk == a.tk_hi - 1 && a.nb_tile_done[1]) st_flag_sys(a.nb_tile_done[1] + fl, 1);
+            const int* psz = sk > 0 ? a.plane_size : a.plane_size_neg;
+            const int done = __hip_atomic_fetch_add(a.plane_cnt + s * np + P, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            if (done == psz[P]) {
+                // leading complete hyperplanes of THIS slab (hyperplanes in which it has no tile count as complete)
+                for (;;) {
+                    int lead = ld_flag(a.planes_done + s);
+                    if (lead >= np || ld_flag(a.plane_cnt + s * np + lead) < psz[lead]) break;
+                    const int next = lead + 1;
+                    if (__hip_atomic_compare_exchange_strong(a.planes_done + s, &lead, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)) {
+                        for (int q = 0; q < 2; ++q)
+                            if (a.nb_pd[q]) __hip_atomic_fetch_max(a.nb_pd[q] + s, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+        }
+        // thread 0 rewrites sh_task only after the barrier above, which every wave reaches after its last read of it
     }
 }
 

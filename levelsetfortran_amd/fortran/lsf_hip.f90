@@ -41,8 +41,9 @@
 !     arith = 'strict'          ! 'strict' (default: every operation as subs.f90 writes it, the reference's bits) |
 !                               ! 'fast' (same mathematics restructured for the GPU, 2 x faster, ~1e-16 per sweep away;
 !                               !   see DESIGN.md section 2 for what that becomes over thousands of sweeps)
-!     devices = 0, 1, 2, 3      ! order = 'jacobi' only: reinit runs block-decomposed on these GPUs, one block each
-!                               !   (lsf_reinit_multi; a device may be listed more than once); unset: one GPU
+!     devices = 0, 1, 2, 3      ! reinit runs on these GPUs (lsf_reinit_multi; a device may be listed more than once):
+!                               !   order = 'jacobi': block-decomposed, one block each; order = 'gs': the reference's
+!                               !   ordering over one z slab each, same field as one GPU bit for bit; unset: one GPU
 !     transport = 'peer'        ! how the blocks exchange their 3-cell halos: 'peer' (peer copies, default) | 'rccl'
 !                               !   (ncclSend / ncclRecv over xGMI; needs a distinct device per block)
 !     check_every = 8           ! sweeps between two looks of the host at the RMS of a block-decomposed run (1..64;
@@ -356,8 +357,12 @@ IF (nd >= 2 .AND. IAND(mode,LSF_ORDER_JACOBI) /= 0) THEN
    IF (rc /= LSF_OK) CALL lsf_fail('lsf_multi_defaults',rc)
    rc = lsf_reinit_multi(phi,nx,ny,nz,iter,dx,h,1.E-5,mode,devs,nd,C_NULL_PTR,done,trace,iter+1)
    IF (rc /= LSF_OK .AND. rc /= LSF_ERR_NAN) CALL lsf_fail('lsf_reinit_multi',rc)
+ELSE IF (nd >= 2) THEN
+   ! the reference's own ordering, one slab of z per listed GPU: the field of one GPU, bit for bit (include/lsf.h)
+   PRINT*, " Reinit in the reference's ordering over ",nd," z slabs "
+   rc = lsf_reinit_multi(phi,nx,ny,nz,iter,dx,h,1.E-5,mode,devs,nd,C_NULL_PTR,done,trace,iter+1)
+   IF (rc /= LSF_OK .AND. rc /= LSF_ERR_NAN) CALL lsf_fail('lsf_reinit_multi',rc)
 ELSE
-   IF (nd >= 2) PRINT*, " liblsf_hip: devices ignored, the reference's in-place ordering does not shard (order = 'jacobi' does) "
    rc = lsf_reinit(phi,nx,ny,nz,iter,dx,h,1.E-5,mode,done,trace,iter+1)
    IF (rc /= LSF_OK .AND. rc /= LSF_ERR_NAN) CALL lsf_fail('lsf_reinit',rc)
 END IF

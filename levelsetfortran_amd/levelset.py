@@ -267,11 +267,14 @@ TRANSPORTS = {"peer": _lib.LSF_TRANSPORT_PEER, "rccl": _lib.LSF_TRANSPORT_RCCL, 
 
 
 def reinit_multi(phi, nx: int, ny: int, nz: int, iter: int, dx: float, h: float, devices, *, dims=None,
-                 tol: float = REINIT_TOL, arith: str = "fast", check_every: int = 8, transport: str = "peer") -> SweepReport:
+                 tol: float = REINIT_TOL, arith: str = "fast", check_every: int = 8, transport: str = "peer",
+                 order: str = "jacobi") -> SweepReport:
     """reinit on every device of `devices` from ONE process (include/lsf.h: lsf_reinit_multi; the call site
     set3d.f90:308 for a host that wants all the GPUs of the node).  phi: Fortran-ordered numpy array, float64 or
-    float32, updated in place.  Jacobi ordering (the ordering that shards); the result is bit-identical to
-    reinit(..., order="jacobi") on one device.  A device may be named more than once (several blocks share it).
+    float32, updated in place.  order="jacobi": blocks with ghost layers, bit-identical to reinit(..., order="jacobi")
+    on one device.  order="gs" (float64): the reference's in-place ordering (subs.f90:743-852) over z slabs, one per
+    device, bit-identical to reinit(..., order="gs") and so, with arith="strict", to the reference; dims, check_every
+    and transport do not apply.  A device may be named more than once (several blocks / slabs share it).
     check_every: sweeps between two looks at the RMS (the stop sweep, the field and the trace do not depend on it);
     transport: "peer" (peer copies), "rccl" (ncclSend / ncclRecv, a distinct device per block) or "mock" (test aid)."""
     lib = _lib.load()
@@ -279,7 +282,7 @@ def reinit_multi(phi, nx: int, ny: int, nz: int, iter: int, dx: float, h: float,
     cap = int(iter) + 1
     trace = np.zeros(max(cap, 1), dtype=np.float64)
     done = ctypes.c_int(0)
-    mode = mode_word("jacobi", arith)
+    mode = mode_word(order, arith)
     devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
     dm = (ctypes.c_int * 3)(*[int(d) for d in dims]) if dims is not None else None
     f32 = isinstance(phi, np.ndarray) and phi.dtype == np.float32
