@@ -66,16 +66,20 @@ struct GsArgs {
     // the same global tile graph; every slab holds field buffers with the global address map, of which its own planes and the
     // three planes beyond each cut are kept current (the neighbour stores them there)
     int slab, nslab, tk_lo, tk_hi;
-    double* nb_buf[2][4];          // field buffers of the lower / upper neighbour slab, NULL at the ends of the grid
-    int* nb_tile_done[2];          // its tile_done (same indexing)
+    int* nb_tile_done[2];          // tile_done of the lower / upper neighbour slab (same indexing), NULL at the ends of the grid
     int* nb_pd[2];                 // the row of the neighbour's planes_done mirror that follows THIS slab
     const int* pd_of_nb[2];        // this slab's mirror of the neighbour's planes_done (unused where nb_pd is NULL)
     int* verdict;                  // [nsweeps] 0 = unknown, 1 = go on, 2 = stop: condition (c) across slabs
+    const int* plane_size_neg;     // tiles of this slab per hyperplane in sweeps that run against z (plane_size: along z)
+    const struct SlabPeers* peers; // the other slabs' addresses (device memory: 56 pointers in the kernel's arguments are 112
+                                   // scalar registers the compiler keeps live across the ticket loop -- measured: 73 spilled)
+};
+struct SlabPeers {
+    double* nb_buf[2][4];          // field buffers of the lower / upper neighbour slab, NULL at the ends of the grid
     int* all_ctl[8];               // ctl / verdict / trace / colsum of every slab, this one included (set by the sweep epilogue
     int* all_verdict[8];           // resp. by the tiles of the slabs that do not run it)
     double* all_trace[8];
     double* all_colsum[8];
-    const int* plane_size_neg;     // tiles of this slab per hyperplane in sweeps that run against z (plane_size: along z)
 };
 
 __device__ __forceinline__ double ld_sc1(const double* p)

@@ -205,6 +205,8 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
         Slab& b = S.s[d];
         GsArgs& a = fa[d];
         std::memset(&a, 0, sizeof a);
+        SlabPeers pe;
+        std::memset(&pe, 0, sizeof pe);
         auto base = [&](const Slab& x, double* p) { return p - (size_t)x.ka * pl; }; // global address map: plane 0 of the grid
         for (int q = 0; q < nbuf; ++q) a.buf[q] = base(b, b.fld[q]);
         a.nbuf = nbuf, a.quirk_axis = tr ? 0 : 1;
@@ -228,16 +230,24 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
             a.pd_of_nb[side] = b.ctlblk + 4; // INT_MAX: no neighbour, always passes
             if (nbr < 0 || nbr >= ndev) continue;
             Slab& n = S.s[nbr];
-            for (int q = 0; q < nbuf; ++q) a.nb_buf[side][q] = base(n, n.fld[q]);
+            for (int q = 0; q < nbuf; ++q) pe.nb_buf[side][q] = base(n, n.fld[q]);
             a.nb_tile_done[side] = n.tile_done;
             // the neighbour's mirror rows: [1] follows ITS lower neighbour, [2] its upper one
             a.nb_pd[side] = n.ctlblk + 16 + DF_BATCH + (side == 0 ? 2 : 1) * DF_BATCH;
             a.pd_of_nb[side] = b.ctlblk + 16 + DF_BATCH + (side == 0 ? 1 : 2) * DF_BATCH;
         }
         for (int q = 0; q < ndev; ++q) {
-            a.all_ctl[q] = S.s[q].ctlblk, a.all_verdict[q] = S.s[q].ctlblk + 16;
-            a.all_trace[q] = S.s[q].trace, a.all_colsum[q] = S.s[q].colsum;
+            pe.all_ctl[q] = S.s[q].ctlblk, pe.all_verdict[q] = S.s[q].ctlblk + 16;
+            pe.all_trace[q] = S.s[q].trace, pe.all_colsum[q] = S.s[q].colsum;
         }
+        HIPCHK(hipSetDevice(b.device));
+        SlabPeers* d_pe = nullptr;
+        if ((rc = slab_alloc(b, (void**)&d_pe, sizeof pe, false))) return rc;
+        HIPCHK(hipMemcpy(d_pe, &pe, sizeof pe, hipMemcpyHostToDevice));
+        a.peers = d_pe;
+#ifdef LSF_EXPERIMENTS
+        if (getenv("LSF_SLAB_ONE_SHOT") && ndev == 1) a.seg_g[0] = 1; // one tile per block (see k_reinit_gs_slab)
+#endif
         a.timeout_ticks = FLOW_TIMEOUT_TICKS;
         if (const char* e = getenv("LSF_GS_TIMEOUT_TICKS")) a.timeout_ticks = strtoull(e, nullptr, 10);
     }
@@ -330,6 +340,7 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
         HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b.device));                                 \
         grid = share[b.device] > 1 ? std::max(1, per_cu * cus * 9 / 10 / share[b.device]) : std::max(1, per_cu * cus);        \
         if (const char* e = getenv("LSF_SLAB_GRID")) grid = std::max(1, atoi(e));                                             \
+        if (a.seg_g[0] == 1) grid = (int)a.total;                                                                                     \
         grid = (int)std::min<long>(grid, std::max<long>(a.total, 1));                                                         \
         HIPCHK(hipEventRecord(b.ev0, b.st));                                                                                  \
         if (strict) hipLaunchKernelGGL((k_reinit_gs_slab<16, WY_, WZ_, BY_, true>), dim3(grid), dim3(64 * WY_ * WZ_), 0, b.st, a); \

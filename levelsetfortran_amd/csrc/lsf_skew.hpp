@@ -186,13 +186,12 @@ struct SkPre {
     uint4 rel, off0, off1;
 };
 template <int TA, int WY, int WZ, int BY>
-__device__ __forceinline__ SkPre sk_prefetch(const GsArgs& a)
+__device__ __forceinline__ SkPre sk_prefetch(const GsArgs& a, int tid = threadIdx.x)
 {
     using T = SkTile<TA, WY, WZ, BY>;
     SkPre p;
     p.rel = p.off0 = p.off1 = make_uint4(0u, 0u, 0u, 0u);
     if (a.tables) {
-        const int tid = threadIdx.x;
         p.rel = ((const uint4*)a.tables)[tid < T::NR ? tid : 0];
         if constexpr (BY == 5) {
             const uint4* o = (const uint4*)(a.tables + T::REL_WORDS) + 2 * tid;
@@ -229,16 +228,24 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     __shared__ double lds[T::TOTAL];
     __shared__ int2 rowtab[T::NR];
     __shared__ double wsum[W];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid_ = threadIdx.x;
+    // called from a loop over tiles (k_reinit_gs_slab): what depends on the thread index only would be computed in front of the
+    // loop and kept in vector registers across it (measured: 60 of them spilled to scratch) -- make it a value of this call
+    if constexpr (PUSH) asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1);
     const double dx = a.dx, h = a.h;
     const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
     const int ncol = a.nTj * a.nTk;
 
-    auto ldp = [](const double* p_) { return PUSH ? ld_sys(p_) : (SC1 ? ld_sc1(p_) : *p_); };
+#ifndef LSF_SLAB_AGENT_SCOPE
+#define LSF_SLAB_AGENT_SCOPE 0
+#endif
+    constexpr bool SYS = PUSH && !LSF_SLAB_AGENT_SCOPE;
+    auto ldp = [](const double* p_) { return SYS ? ld_sys(p_) : (SC1 ? ld_sc1(p_) : *p_); };
     auto stp = [](double* p_, double v_) {
-        if (PUSH) st_sys(p_, v_);
+        if (SYS) st_sys(p_, v_);
         else if (SC1) st_sc1(p_, v_);
         else *p_ = v_;
     };
@@ -647,7 +654,7 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     [[maybe_unused]] int k_push_lo = 0, k_push_hi = 0;
     if constexpr (PUSH) {
         const int ob = gb + 1 == a.nbuf ? 0 : gb + 1;
-        nb_lo = a.nb_buf[0][ob], nb_hi = a.nb_buf[1][ob];
+        nb_lo = a.peers->nb_buf[0][ob], nb_hi = a.peers->nb_buf[1][ob];
         k_push_lo = 1 + a.tk_lo * NZT + 3, k_push_hi = min(1 + a.tk_hi * NZT, nz) - 3;
     }
 #pragma unroll
@@ -707,7 +714,7 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
         stp(slot, colsum_prev + acc);
         if constexpr (PUSH) { // the sweep's last tile (frame C = nTk - 1) sums the columns of every slab
             const int epi = sk > 0 ? a.nslab - 1 : 0;
-            if (epi != a.slab) st_sys(a.all_colsum[epi] + (long)gb * ncol + (tj + (long)a.nTj * tk), colsum_prev + acc);
+            if (epi != a.slab) st_sys(a.peers->all_colsum[epi] + (long)gb * ncol + (tj + (long)a.nTj * tk), colsum_prev + acc);
         }
     }
     if (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // results are at the memory side before anyone is told
@@ -734,12 +741,13 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
             // the epilogues of consecutive sweeps are ordered (the last tile of a sweep waits for every hyperplane of the sweep
             // before), so a stop raised earlier -- here or on another slab, which stored it here before it finished -- is seen
             const bool stop = rms < a.tol || rms != rms || ld_flag_sys(a.ctl + 0) != 0;
+            const SlabPeers* pe = a.peers;
             for (int q = 0; q < a.nslab; ++q) {
-                if (g < a.trace_cap) st_sys(a.all_trace[q] + g, rms);
-                st_flag_sys(a.all_ctl[q] + 1, g + 1);
-                if (rms != rms) st_flag_sys(a.all_ctl[q] + 2, 1);
-                if (stop) st_flag_sys(a.all_ctl[q] + 0, 1);
-                st_flag_sys(a.all_verdict[q] + (g - a.g0), stop ? 2 : 1); // the verdict travels in the word the waiters poll
+                if (g < a.trace_cap) st_sys(pe->all_trace[q] + g, rms);
+                st_flag_sys(pe->all_ctl[q] + 1, g + 1);
+                if (rms != rms) st_flag_sys(pe->all_ctl[q] + 2, 1);
+                if (stop) st_flag_sys(pe->all_ctl[q] + 0, 1);
+                st_flag_sys(pe->all_verdict[q] + (g - a.g0), stop ? 2 : 1); // the verdict travels in the word the waiters poll
             }
         } else {
             if (g < a.trace_cap) a.trace[g] = rms;
@@ -1019,22 +1027,36 @@ __global__ __launch_bounds__(256) void k_build_order_slab(uint2* __restrict__ or
 }
 
 template <int TA, int WY, int WZ, int BY, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_slab(GsArgs a)
+// 2 x 2 wavefronts, three lanes per cell: four tiles per CU (128 registers), not the five of k_reinit_gs_persist -- inside the
+// ticket loop the compiler needs ~106 registers, at five per CU (96) it spills ten to scratch: 3.09 against 2.95 ms per
+// 512^3 sweep on one box (k_reinit_gs_persist: 2.75)
+#ifndef LSF_SLAB_WAVES
+#define LSF_SLAB_WAVES 4
+#endif
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? LSF_SLAB_WAVES : 1)))) void k_reinit_gs_slab(GsArgs args_)
 {
     using T = SkTile<TA, WY, WZ, BY>;
     __shared__ int sh_task[8]; // as in k_reinit_gs_persist
-    const int tid = threadIdx.x;
-    const int np = a.np;
-    const int nM = a.nM;
-    const long per_sweep = (long)nM * a.nTj * a.nTk;
-    const SkPre pre = sk_prefetch<TA, WY, WZ, BY>(a);
+    __shared__ unsigned long long sh_wait[4]; // thread 0's upstream flags and start time: parked here while the tile loads (registers)
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     for (;;) {
-        const int *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
-        unsigned long long t0 = 0;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid)); // (and nothing that depends on the thread index only either: see skew_tile)
+        // The arguments are read afresh in every iteration, through a pointer the compiler cannot see through: left to itself it
+        // loads all of them in front of the loop and keeps them in registers across it -- 73 scalar registers spilled to vector
+        // lanes, those to 272 bytes of scratch per lane, 38 % more time per tile than k_reinit_gs_persist.  (GsArgs is the
+        // kernel's only argument: it starts the kernarg segment.)
+        typedef const __attribute__((address_space(4))) GsArgs* KArg;
+        KArg kp = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        const GsArgs& a = *(const GsArgs*)kp;
+        const int np = a.np;
+        const int nM = a.nM;
+        const long per_sweep = (long)nM * a.nTj * a.nTk;
+        const SkPre pre = sk_prefetch<TA, WY, WZ, BY>(a, tid); // in flight while the block takes its ticket and waits for its tile
         auto give_up = [&]() { __hip_atomic_fetch_max(a.ticket, (int)a.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         auto time_out = [&]() { // tell every slab, so that none of them spins on for a tile that will not come
-            for (int q = 0; q < a.nslab; ++q) st_flag_sys(a.all_ctl[q] + 2, 2), st_flag_sys(a.all_ctl[q] + 0, 1);
+            for (int q = 0; q < a.nslab; ++q) st_flag_sys(a.peers->all_ctl[q] + 2, 2), st_flag_sys(a.peers->all_ctl[q] + 0, 1);
         };
         if (tid == 0) {
             const long t = (long)__hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1047,16 +1069,17 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 auto m_lo = [&](int B_, int C_) { return (T::NYT * B_ + T::NZT * C_) / TA; };
                 auto m_hi = [&](int B_, int C_) { return (T::NYT * B_ + T::NYT - 1 + T::NZT * C_ + T::NZT - 1 + a.nx - 2) / TA; };
                 const int* td = a.tile_done + s * per_sweep; // the neighbour raises the flags of its tiles next to the cut here
-                w0 = m - 1 >= m_lo(B, C) ? td + (m - 1) + (long)nM * (B + (long)a.nTj * C) : nullptr;
-                w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : nullptr;
-                w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : nullptr;
+                const int* w0 = m - 1 >= m_lo(B, C) ? td + (m - 1) + (long)nM * (B + (long)a.nTj * C) : nullptr;
+                const int* w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : nullptr;
+                const int* w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : nullptr;
                 const int need1 = s == 0 ? 0 : min(P + a.sweep_tab[4 * s + 3], np);
                 const int* always = a.ctl + 4; // INT_MAX (host)
                 const int* p3 = s == 0 ? always : a.planes_done + s - 1;
                 const int* p3l = (s == 0 || !a.nb_pd[0]) ? always : a.pd_of_nb[0] + s - 1;
                 const int* p3h = (s == 0 || !a.nb_pd[1]) ? always : a.pd_of_nb[1] + s - 1;
                 const int* p4 = s < a.nbuf ? always : a.verdict + s - a.nbuf;
-                t0 = __builtin_amdgcn_s_memrealtime();
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                sh_wait[0] = (unsigned long long)w0, sh_wait[1] = (unsigned long long)w1, sh_wait[2] = (unsigned long long)w2, sh_wait[3] = t0;
                 go = 1;
                 for (;;) { // stage 1: conditions (b) and (c)
                     const int vstop = ld_flag_sys(a.ctl + 0);
@@ -1094,6 +1117,8 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
         auto wait_upstream = [&]() -> bool { // stage 2: condition (a)
             if (tid == 0) {
                 int go2 = 1;
+                const int *w0 = (const int*)sh_wait[0], *w1 = (const int*)sh_wait[1], *w2 = (const int*)sh_wait[2];
+                const unsigned long long t0 = sh_wait[3];
                 for (;;) {
                     const int vstop = ld_flag_sys(a.ctl + 0);
                     const int v0 = w0 ? ld_flag(w0) : 1, v1 = w1 ? ld_flag(w1) : 1, v2 = w2 ? ld_flag_sys(w2) : 1;
@@ -1145,6 +1170,9 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
             }
         }
         // thread 0 rewrites sh_task only after the barrier above, which every wave reaches after its last read of it
+#ifdef LSF_EXPERIMENTS
+        if (a.seg_g[0] == 1) return; // one tile per block, as in k_reinit_gs_persist (timing experiment, one slab only)
+#endif
     }
 }
 
