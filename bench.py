@@ -159,6 +159,9 @@ def main() -> None:
                     help="internal: measure the one-process driver with the RCCL transport on --gpus devices and write the "
                          "entries to this file (a child process of rank 0: a transport that has never run on more than one "
                          "device where it was written must not be able to take the job with it)")
+    ap.add_argument("--slab-worker", default=None,
+                    help="internal: measure the reference's ordering over z slabs (lsf_reinit_multi, LSF_ORDER_GS) on 1, 2, 4 ... "
+                         "--gpus devices and write the entries to this file (a child process, for the same reason)")
     ap.add_argument("--multi-grid", type=int, default=512)
     ap.add_argument("--cpu-slab", type=int, default=20)
     ap.add_argument("--cpu-sweeps", type=int, default=8)
@@ -171,6 +174,11 @@ def main() -> None:
 
         ent = _single_process_entries(_lib.load(), args.gpus, args.multi_grid, args.steps, args.warmup, args.arith, transports=("rccl",))
         with open(args.multi_worker, "w") as fh:
+            json.dump(ent, fh)
+        return
+    if args.slab_worker:
+        ent = _slab_entries(args.gpus, args.multi_grid, args.steps, args.warmup, args.arith)
+        with open(args.slab_worker, "w") as fh:
             json.dump(ent, fh)
         return
     f32 = args.dtype == "f32"
@@ -496,6 +504,8 @@ def main() -> None:
                         Gs = 64 if N < 128 else 512
                         _single_process_entries(lib, world, Gs, K, W, args.arith, transports=("peer",), sink=entries)
                         entries.extend(_rccl_entries_in_a_child(world, Gs, K, W, args.arith))
+                        # the ordering that IS reference-equal, sharded: z slabs of the exact Gauss-Seidel tile graph
+                        entries.extend(_slab_entries_in_a_child(world, Gs, K, W, args.arith))
                     except Exception as e:  # noqa: BLE001
                         entries.append({"path": "one process, lsf_multi", "value": None, "error": repr(e)[:300]})
                         failed = True
@@ -538,6 +548,74 @@ def _rccl_entries_in_a_child(world, G, K, W, arith, timeout=150.0):
         except Exception as e:  # noqa: BLE001
             return [{"path": "one process, lsf_multi (C ABI), halos by RCCL ncclSend / ncclRecv", "n_gpus": world, "transport": "rccl",
                      "value": None, "error": repr(e)[:300]}]
+
+
+def _slab_entries_in_a_child(world, G, K, W, arith, timeout=200.0):
+    """the reference's ordering over z slabs on 1, 2, 4 ... `world` devices, measured by a child process with a time limit (peer
+    stores and cross-device flags have never run between two devices where this code was written)"""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "slabs.json")
+        cmd = [sys.executable, os.path.abspath(__file__), "--slab-worker", out, "--gpus", str(world), "--multi-grid", str(G),
+               "--steps", str(K), "--warmup", str(W), "--arith", arith]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                 "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+        try:
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=timeout, env=env)
+            return json.load(open(out))
+        except Exception as e:  # noqa: BLE001
+            return [{"path": SLAB_PATH, "ordering": "gs", "n_gpus": world, "value": None, "error": repr(e)[:300]}]
+
+
+SLAB_PATH = "one process, lsf_reinit_multi with LSF_ORDER_GS (C ABI): one dataflow launch per z slab, cut planes by peer stores"
+
+
+def _slab_entries(world, G, K, W, arith, devices_of=None):
+    """the reference's in-place ordering over z slabs (include/lsf.h: lsf_reinit_multi, LSF_ORDER_GS) on 1, 2, 4 ... `world`
+    devices, fixed G^3 grid: `value` from the device time of the slabs' launches (lsf_slabs_info; the call also uploads, transposes
+    and downloads the field: `call_s`).  devices_of(nd) -> device list (default 0 .. nd - 1; a one-GPU test names device 0 nd times)."""
+    import numpy as np
+
+    import levelsetfortran_amd as lsf
+    from levelsetfortran_amd import _lib, fields
+
+    lib = _lib.load()
+    out = []
+    counts, nd = [], 1
+    while nd <= world:
+        counts.append(nd)
+        nd *= 2
+    if counts[-1] != world:
+        counts.append(world)
+    n = G - 1
+    phi0, dx = fields.two_sphere_phi0((G, G, G))
+    h = fields.reinit_step(dx)
+    first = None
+    for nd in counts:
+        devs = list(devices_of(nd)) if devices_of else list(range(nd))
+        try:
+            a = phi0.copy(order="F")
+            lsf.reinit_multi(a, n, n, n, max(min(W, 8), 1) - 1, dx, h, devs, tol=0.0, arith=arith, order="gs")  # warm-up: code, tables
+            a = phi0.copy(order="F")
+            t0 = time.perf_counter()
+            rep = lsf.reinit_multi(a, n, n, n, K - 1, dx, h, devs, tol=0.0, arith=arith, order="gs")
+            call_s = time.perf_counter() - t0
+            assert rep.count == K, (rep.count, K)
+            v = [ctypes.c_int(0) for _ in range(4)]
+            ks = ctypes.c_double(0)
+            _lib.check(lib.lsf_slabs_info(*[ctypes.byref(x) for x in v], ctypes.byref(ks)))
+            val = float(n - 1) ** 3 * K / ks.value
+            if first is None:
+                first = a
+            out.append({"path": SLAB_PATH, "ordering": "gs", "arith": arith, "dtype": "f64", "scaling": "strong", "global_grid": [G, G, G],
+                        "n_gpus": nd, "devices": devs, "value": val, "unit": "cell-updates/s", "ms_per_step": ks.value / K * 1e3,
+                        "roofline": _job_roofline(val, len(set(devs)), BYTES_PER_CELL_UPDATE), "call_s": call_s,
+                        "blocks_per_slab": v[1].value, "finegrained": bool(v[2].value),
+                        "equal_to_first_entry": bool(np.array_equal(a, first)),
+                        "note": "reference-equal ordering (bit-identical to lsf_reinit on one device); value = cell-updates of the K "
+                                "sweeps / the longest of the slabs' launches (device events)"})
+        except Exception as e:  # noqa: BLE001
+            out.append({"path": SLAB_PATH, "ordering": "gs", "n_gpus": nd, "value": None, "error": repr(e)[:300]})
+    return out
 
 
 def _rccl_ranks(dist):

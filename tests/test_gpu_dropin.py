@@ -114,7 +114,8 @@ def test_fortran_host_drives_the_block_decomposed_reinit(tmp_path):
     """order = 'jacobi' with a device list in &lsf_inputs: the reference's host runs both reinit calls block-decomposed
     (lsf_reinit_multi, one block per listed device; here four blocks sharing this box's GPU) between seams that keep
     their arrays on the device (resident = 2).  Both .vti payloads and the printed residuals equal the one-GPU Jacobi
-    run, and LSF_DEVICES overrides the namelist."""
+    run, and LSF_DEVICES overrides the namelist.  With order = 'gs' (the default) the same device list runs the reference's own
+    ordering over z slabs."""
     import stl_io
 
     s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
@@ -145,12 +146,27 @@ def test_fortran_host_drives_the_block_decomposed_reinit(tmp_path):
             assert np.array_equal(stl_io.vti_read_phi(tmp_path / name / f, shape), stl_io.vti_read_phi(tmp_path / "one" / f, shape)), (name, f)
         rms = [float(x) for x in re.findall(r"RMS Error:\s+(\S+)", outs[name])]
         assert np.allclose(rms, rms_one, rtol=1e-10, atol=0)  # block sums added in rank order vs one fixed-order sum
-    # the exact ordering does not shard: a device list is ignored there, with a note
-    d = tmp_path / "gs"
-    d.mkdir()
-    stl_io.stl_write(d / "cube40.stl", s["cube40_surfX"], s["cube40_surfElem"])
-    env = {k: v for k, v in os.environ.items() if not k.startswith("LSF_")}
-    env.update(LSF_DEVICES="0,0", LSF_REINIT_ITER="3", LSF_MINMAX_ITER="0", LSF_REINIT2_ITER="0")
-    p = subprocess.run(f"ulimit -s unlimited; cd {d}; {EXE} cube40.stl", shell=True, env=env, text=True,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    assert p.returncode == 0 and "devices ignored" in p.stdout
+    # the reference's own ordering shards too: z slabs of the exact Gauss-Seidel tile graph (lsf_reinit_multi with LSF_ORDER_GS),
+    # same payload as the one-device run of that ordering, bit for bit, in the reference's arithmetic (the shim's default)
+    got = {}
+    for name, devs in (("gs1", None), ("gs2", "0,0"), ("gs3", "0,0,0")):
+        d = tmp_path / name
+        d.mkdir()
+        stl_io.stl_write(d / "cube40.stl", s["cube40_surfX"], s["cube40_surfElem"])
+        env = {k: v for k, v in os.environ.items() if not k.startswith("LSF_")}
+        env.update(LSF_REINIT_ITER="70", LSF_MINMAX_ITER="4", LSF_REINIT2_ITER="5")
+        if devs:
+            env["LSF_DEVICES"] = devs
+        p = subprocess.run(f"ulimit -s unlimited; cd {d}; {EXE} cube40.stl", shell=True, env=env, text=True,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:]
+        got[name] = p.stdout
+    assert "z slabs" not in got["gs1"]
+    assert got["gs2"].count("Reinit in the reference's ordering over  2  z slabs") == 2
+    assert got["gs3"].count("Reinit in the reference's ordering over  3  z slabs") == 2
+    rms1 = re.findall(r"RMS Error:\s+(\S+)", got["gs1"])
+    assert len(rms1) == 71 + 4 + 6
+    for name in ("gs2", "gs3"):
+        for f in ("signedDistanceFunction.vti", "smoothedDistanceFunction.vti"):
+            assert np.array_equal(stl_io.vti_read_phi(tmp_path / name / f, shape), stl_io.vti_read_phi(tmp_path / "gs1" / f, shape)), (name, f)
+        assert re.findall(r"RMS Error:\s+(\S+)", got[name]) == rms1  # printed residuals: the same digits

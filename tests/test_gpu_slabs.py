@@ -146,3 +146,23 @@ def test_slabs_time_out_is_an_error_not_a_hang(lsf, env):
     del env["LSF_GS_TIMEOUT_TICKS"]
     want, r1, got, r = _both(lsf, (60, 50, 40), 2, 6, "fast")
     assert np.array_equal(got, want) and r.rms == r1.rms
+
+
+def test_bench_slab_entries_helper_and_child(lsf):
+    """bench.py's measurement of the sharded exact ordering (rank 0 of an N > 1 job runs it on 1, 2, 4 ... N devices, in a child
+    process): here with device 0 named once per slab, in process and through the child"""
+    import importlib.util
+
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ent = bench._slab_entries(2, 96, 5, 2, "fast", devices_of=lambda nd: [0] * nd)
+    assert [e["n_gpus"] for e in ent] == [1, 2]
+    for e in ent:
+        assert e.get("error") is None and e["value"] > 0 and e["ordering"] == "gs" and e["equal_to_first_entry"]
+        assert 0 < e["roofline"]["frac"] < 1 and e["roofline"]["peak"] == 8000.0  # one physical device
+        assert e["blocks_per_slab"] > 0 and e["call_s"] > e["ms_per_step"] * 5e-3
+    child = bench._slab_entries_in_a_child(1, 64, 3, 1, "strict")
+    assert len(child) == 1 and child[0].get("error") is None and child[0]["n_gpus"] == 1 and child[0]["arith"] == "strict"
