@@ -152,7 +152,7 @@ def main() -> None:
                     help="N > 1, mode gs: skip the block-decomposed Jacobi sweep (RCCL halo exchange) that is otherwise "
                          "timed after the headline measurement and attached as \"decomposed\"")
     ap.add_argument("--force-decomposed", action="store_true", help="run that measurement at N = 1 too (test aid)")
-    ap.add_argument("--decomposed-timeout", type=float, default=240.0,
+    ap.add_argument("--decomposed-timeout", type=float, default=480.0,
                     help="seconds the decomposed measurement may take before the headline line is printed without it")
     ap.add_argument("--cpu-worker", default=None)
     ap.add_argument("--multi-worker", default=None,
@@ -550,7 +550,7 @@ def _rccl_entries_in_a_child(world, G, K, W, arith, timeout=150.0):
                      "value": None, "error": repr(e)[:300]}]
 
 
-def _slab_entries_in_a_child(world, G, K, W, arith, timeout=200.0):
+def _slab_entries_in_a_child(world, G, K, W, arith, timeout=120.0):
     """the reference's ordering over z slabs on 1, 2, 4 ... `world` devices, measured by a child process with a time limit (peer
     stores and cross-device flags have never run between two devices where this code was written)"""
     with tempfile.TemporaryDirectory() as td:

@@ -266,7 +266,7 @@ int lsf_stl_get(double *surfX, int32_t *surfElem);
  * sweep's stop verdict are stored by the producing kernel straight into the neighbour's memory (peer stores over xGMI,
  * system scope, drained before the flag that announces them).  Field, sweep count and RMS trace are those of lsf_reinit
  * with the same mode, bit for bit -- with LSF_ARITH_STRICT the reference's.  Field memory per device is its slab plus three
- * planes per cut.  Needs peer access between neighbouring devices; slabs that share a device (the one-GPU rehearsal) need
+ * planes per cut.  Needs peer access between the devices; slabs that share a device (the one-GPU rehearsal) need
  * their launches resident together: at most three per device unless GPU_MAX_HW_QUEUES is raised.  A tile that waits longer
  * than 4 s for a predecessor ends the call with LSF_ERR_HIP on every slab (bounded spins, no hang).  lsf_slabs_info: the
  * last such call of this thread -- slabs, resident blocks per slab, whether the shared buffers were fine-grained

@@ -114,18 +114,19 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
     for (int d = 1; d < ndev; ++d) distinct = distinct || devices[d] != devices[0];
     bool fine = distinct;
     if (const char* e = getenv("LSF_SLAB_FINEGRAINED")) fine = atoi(e) != 0;
-    for (int a = 0; a + 1 < ndev; ++a)
-        if (devices[a] != devices[a + 1])
-            for (int dir = 0; dir < 2; ++dir) {
-                const int from = devices[a + dir], to = devices[a + 1 - dir];
-                int can = 0;
-                if (hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || !can)
-                    return fail(LSF_ERR_INVALID, "exact ordering across slabs: neighbouring devices cannot access each other's memory");
-                HIPCHK(hipSetDevice(from));
-                const hipError_t pe = hipDeviceEnablePeerAccess(to, 0);
-                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(LSF_ERR_HIP, "hipDeviceEnablePeerAccess failed");
-                (void)hipGetLastError();
-            }
+    // every pair: the cut planes go to the neighbours only, but the sweep epilogue stores its verdict on every slab
+    for (int a = 0; a < ndev; ++a)
+        for (int b = 0; b < ndev; ++b) {
+            const int from = devices[a], to = devices[b];
+            if (from == to) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || !can)
+                return fail(LSF_ERR_INVALID, "exact ordering across slabs: the devices cannot access each other's memory");
+            HIPCHK(hipSetDevice(from));
+            const hipError_t pe = hipDeviceEnablePeerAccess(to, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(LSF_ERR_HIP, "hipDeviceEnablePeerAccess failed");
+            (void)hipGetLastError();
+        }
 
     // ---- geometry, buffers, tile lists of every slab -----------------------------------------------------------------
     std::map<int, int> share; // slabs per device
