@@ -166,3 +166,32 @@ def test_bench_slab_entries_helper_and_child(lsf):
         assert e["blocks_per_slab"] > 0 and e["call_s"] > e["ms_per_step"] * 5e-3
     child = bench._slab_entries_in_a_child(1, 64, 3, 1, "strict")
     assert len(child) == 1 and child[0].get("error") is None and child[0]["n_gpus"] == 1 and child[0]["arith"] == "strict"
+
+
+@pytest.mark.parametrize("n,slabs", [(256, 3), (512, 2)])
+def test_slabs_at_baseline_sizes_equal_the_reference_itself(lsf, n, slabs):
+    """BASELINE sizes: the sharded exact ordering against the reference's OWN reinit (tests/golden/synth_big.npz, made by
+    tests/golden/make_golden_big.py from the amdflang build of subs.f90): SHA-256 of the whole field after 8 sweeps at 256^3
+    (three slabs) and 2 sweeps at 512^3 (two slabs; the one-lane-per-cell tile, selected by size)."""
+    import hashlib
+
+    from conftest import GOLDEN
+    from levelsetfortran_amd import fields
+
+    path = os.path.join(GOLDEN, "synth_big.npz")
+    if not os.path.exists(path):
+        pytest.skip("synth_big.npz not generated")
+    g = np.load(path)
+    sweeps = int(g[f"n{n}_sweeps"])
+    phi, dx = fields.two_sphere_phi0((n, n, n))
+    h = fields.reinit_step(dx)
+    rep = lsf.reinit_multi(phi, n - 1, n - 1, n - 1, sweeps - 1, dx, h, [0] * slabs, tol=0.0, arith="strict", order="gs")
+    assert rep.count == sweeps
+    assert hashlib.sha256(phi.reshape(-1, order="F").tobytes()).hexdigest() == str(g[f"n{n}_sha"])
+    assert np.allclose(rep.rms, g[f"n{n}_rms"], rtol=1e-7, atol=0)
+
+
+def test_slabs_single_sweep(lsf):
+    """iter = 0: one sweep, one batch of one"""
+    want, r1, got, r = _both(lsf, (40, 36, 26), 2, 0, "strict")
+    assert r.count == r1.count == 1 and np.array_equal(got, want) and r.rms == r1.rms
