@@ -130,6 +130,9 @@ int gs_nbuf()
     const char* e = getenv("LSF_GS_NBUF");
     return (e && atoi(e) == 3) ? 3 : 4;
 }
+#ifndef LSF_DF_PAD
+#define LSF_DF_PAD 1024 // ints between the control words of the dataflow launch (experiment: 0 = adjacent, as before)
+#endif
 constexpr int MM_TA = 32;      // tile length along i of the exact-GS min/max kernel
 constexpr int CHECK_EVERY = 8; // sweeps between host reads of the device stop flag
 // fp32 sweep: the pure x-face wall points are written by the sweep kernel instead of k_bc (kernel argument `xwall`):
@@ -857,12 +860,15 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         const int BATCH = (int)std::max<long>(8, std::min<long>(DF_BATCH, (512L << 20) / (ntiles * 8) / 8 * 8));
         const int nM = (knx - 2 + nyc * nTj - 1 + nzc * nTk - 1) / ta + 1; // m_max + 1 (get_skew_tiles)
         const size_t tile_flags = (size_t)BATCH * nM * nTj * nTk;
-        if ((rc = ws(c.slot[S_PLANECNT], ((size_t)BATCH * np + BATCH + 16) * sizeof(int)))) return rc;
+        // hyperplane counters | 4 KB | leading-hyperplane counters of the sweeps | 4 KB | ticket: the three are polled / updated at
+        // very different rates (see DF_PAD)
+        constexpr size_t DF_PAD = LSF_DF_PAD;
+        if ((rc = ws(c.slot[S_PLANECNT], ((size_t)BATCH * np + 2 * DF_PAD + BATCH + 16) * sizeof(int)))) return rc;
         if ((rc = ws(c.slot[S_BFLAG], tile_flags * sizeof(int)))) return rc;
         if ((rc = ws(c.slot[S_ORDER], (size_t)std::min(BATCH, max_sweeps) * ntiles * sizeof(uint2)))) return rc;
         int* d_cnt = (int*)c.slot[S_PLANECNT].p;
-        int* d_done = d_cnt + (size_t)BATCH * np;
-        int* d_ticket = d_done + BATCH;
+        int* d_done = d_cnt + (size_t)BATCH * np + DF_PAD;
+        int* d_ticket = d_done + BATCH + DF_PAD;
         unsigned long long* d_dbg = nullptr;
         // per-tile wait / work times of the dataflow launch: three contended atomics per tile (+70 % run time), so its own
         // switch and not part of LSF_TRACE, whose per-call times are meant to be read as measurements
@@ -926,7 +932,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             const int* m_psize = m_tab + 4 * DF_BATCH;
             const int* m_poff = m_psize + np;
             if (!marked) prof_mark(st), marked = true; // the timed region starts once the first plan exists
-            HIPCHK(hipMemsetAsync(d_cnt, 0, ((size_t)BATCH * np + BATCH + 16) * sizeof(int), st)); // counters, ticket
+            HIPCHK(hipMemsetAsync(d_cnt, 0, ((size_t)BATCH * np + 2 * DF_PAD + BATCH + 16) * sizeof(int), st)); // counters, ticket
             HIPCHK(hipMemsetAsync(c.slot[S_BFLAG].p, 0, (size_t)ns * nM * nTj * nTk * sizeof(int), st));
             if (d_dbg) HIPCHK(hipMemsetAsync(d_dbg, 0, 64, st));
             hipLaunchKernelGGL(k_build_order, dim3(bp.nslots), dim3(256), 0, st, (uint2*)c.slot[S_ORDER].p, (const uint32_t*)tl->d,

@@ -99,21 +99,30 @@ __device__ __forceinline__ void st_sys(double* p, double v)
 {
     __hip_atomic_store((long long*)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+#ifndef LSF_SYS_SCOPE
+#define LSF_SYS_SCOPE __HIP_MEMORY_SCOPE_SYSTEM // (experiment builds: agent)
+#endif
 __device__ __forceinline__ int ld_flag_sys(const int* p)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, LSF_SYS_SCOPE);
 }
 __device__ __forceinline__ void st_flag_sys(int* p, int v)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, LSF_SYS_SCOPE);
 }
+#ifndef LSF_FLAG_LD_SCOPE
+#define LSF_FLAG_LD_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+#ifndef LSF_FLAG_ST_SCOPE
+#define LSF_FLAG_ST_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
 __device__ __forceinline__ int ld_flag(const int* p)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, LSF_FLAG_LD_SCOPE);
 }
 __device__ __forceinline__ void st_flag(int* p, int v)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, LSF_FLAG_ST_SCOPE);
 }
 
 // Tile geometry: TA cells along i, NY x 4 cells in the (j,k) cross-section.

@@ -246,9 +246,6 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
         if ((rc = slab_alloc(b, (void**)&d_pe, sizeof pe, false))) return rc;
         HIPCHK(hipMemcpy(d_pe, &pe, sizeof pe, hipMemcpyHostToDevice));
         a.peers = d_pe;
-#ifdef LSF_EXPERIMENTS
-        if (getenv("LSF_SLAB_ONE_SHOT") && ndev == 1) a.seg_g[0] = 1; // one tile per block (see k_reinit_gs_slab)
-#endif
         a.timeout_ticks = FLOW_TIMEOUT_TICKS;
         if (const char* e = getenv("LSF_GS_TIMEOUT_TICKS")) a.timeout_ticks = strtoull(e, nullptr, 10);
     }
@@ -331,25 +328,58 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
             HIPCHK(hipSetDevice(b.device));
             GsArgs& a = fa[d];
             int grid = 0;
-            // every launch must be resident as a whole (its blocks wait for tiles of the other launches): the device's capacity
-            // for this kernel, divided by the slabs that share the device
-#define LSF_LAUNCH_SLAB(WY_, WZ_, BY_)                                                                                        \
+            // slabs that share a device: every launch must be resident as a whole (its blocks wait for tiles of the other
+            // launches): a loop over tickets, the device's capacity for the kernel divided by the slabs on it.  A slab that has
+            // its device to itself: one block per tile (k_reinit_gs_slab).  LSF_SLAB_LOOP = 0 / 1 overrides (0 only where no
+            // device is shared).
+            bool loop = share[b.device] > 1;
+            if (const char* e = getenv("LSF_SLAB_LOOP")) loop = loop || atoi(e) != 0;
+#define LSF_LAUNCH_SLAB_AS(WY_, WZ_, BY_, ST_, LP_)                                                                            \
     do {                                                                                                                      \
-        int per_cu = 0, cus = 0;                                                                                              \
-        const void* fn = strict ? (const void*)k_reinit_gs_slab<16, WY_, WZ_, BY_, true> : (const void*)k_reinit_gs_slab<16, WY_, WZ_, BY_, false>; \
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WY_ * WZ_, 0));                                 \
-        HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b.device));                                 \
-        grid = share[b.device] > 1 ? std::max(1, per_cu * cus * 9 / 10 / share[b.device]) : std::max(1, per_cu * cus);        \
-        if (const char* e = getenv("LSF_SLAB_GRID")) grid = std::max(1, atoi(e));                                             \
-        if (a.seg_g[0] == 1) grid = (int)a.total;                                                                                     \
-        grid = (int)std::min<long>(grid, std::max<long>(a.total, 1));                                                         \
-        HIPCHK(hipEventRecord(b.ev0, b.st));                                                                                  \
-        if (strict) hipLaunchKernelGGL((k_reinit_gs_slab<16, WY_, WZ_, BY_, true>), dim3(grid), dim3(64 * WY_ * WZ_), 0, b.st, a); \
-        else hipLaunchKernelGGL((k_reinit_gs_slab<16, WY_, WZ_, BY_, false>), dim3(grid), dim3(64 * WY_ * WZ_), 0, b.st, a);  \
-        HIPCHK(hipEventRecord(b.ev1, b.st));                                                                                  \
+        dim3 gd(1);                                                                                                            \
+        if (LP_) {                                                                                                             \
+            int per_cu = 0, cus = 0;                                                                                           \
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_reinit_gs_slab<16, WY_, WZ_, BY_, ST_, LP_>, 64 * WY_ * WZ_, 0)); \
+            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b.device));                              \
+            grid = share[b.device] > 1 ? std::max(1, per_cu * cus * 9 / 10 / share[b.device]) : std::max(1, per_cu * cus);     \
+            if (const char* e = getenv("LSF_SLAB_GRID")) grid = std::max(1, atoi(e));                                          \
+            grid = (int)std::min<long>(grid, std::max<long>(a.total, 1));                                                      \
+            gd = dim3((unsigned)grid);                                                                                         \
+        } else { /* one block per tile (2-D: gridDim.x * blockDim.x must stay below 2^32) */                                   \
+            grid = (int)std::min<long>(a.total, INT_MAX);                                                                      \
+            gd = dim3((unsigned)std::min<long>(std::max<long>(a.total, 1), 65536), (unsigned)((std::max<long>(a.total, 1) + 65535) / 65536)); \
+        }                                                                                                                      \
+        HIPCHK(hipEventRecord(b.ev0, b.st));                                                                                   \
+        hipLaunchKernelGGL((k_reinit_gs_slab<16, WY_, WZ_, BY_, ST_, LP_>), gd, dim3(64 * WY_ * WZ_), 0, b.st, a);             \
+        HIPCHK(hipEventRecord(b.ev1, b.st));                                                                                   \
     } while (0)
+#define LSF_LAUNCH_SLAB(WY_, WZ_, BY_)                                                       \
+    do {                                                                                     \
+        if (strict && loop) LSF_LAUNCH_SLAB_AS(WY_, WZ_, BY_, true, true);                   \
+        else if (strict) LSF_LAUNCH_SLAB_AS(WY_, WZ_, BY_, true, false);                     \
+        else if (loop) LSF_LAUNCH_SLAB_AS(WY_, WZ_, BY_, false, true);                       \
+        else LSF_LAUNCH_SLAB_AS(WY_, WZ_, BY_, false, false);                                \
+    } while (0)
+#ifdef LSF_EXPERIMENTS
+            if (ndev == 1 && getenv("LSF_TRACE_TILES")) { // per-tile phase times (skew_tile, LSF_PHASE)
+                unsigned long long* dd = nullptr;
+                if ((rc = slab_alloc(b, (void**)&dd, 64, false))) return rc;
+                HIPCHK(hipMemsetAsync(dd, 0, 64, b.st));
+                a.dbg = dd;
+            }
+#endif
+#ifdef LSF_EXPERIMENTS // which side makes the one-slab launch faster than lsf_reinit's at 256^3: the kernel or the buffers?
+            if (ndev == 1 && getenv("LSF_SLAB_USE_PERSIST") && !strict && wy == 2 && wz == 2 && by == 5) {
+                const dim3 gd((unsigned)std::min<long>(a.total, 65536), (unsigned)((a.total + 65535) / 65536));
+                HIPCHK(hipEventRecord(b.ev0, b.st));
+                if (atoi(getenv("LSF_SLAB_USE_PERSIST")) == 2) hipLaunchKernelGGL((k_reinit_gs_persist<16, 2, 2, 5, false, true>), gd, dim3(256), 0, b.st, a);
+                else hipLaunchKernelGGL((k_reinit_gs_persist<16, 2, 2, 5, false>), gd, dim3(256), 0, b.st, a);
+                HIPCHK(hipEventRecord(b.ev1, b.st));
+            } else
+#endif
             LSF_SK_SHAPES(LSF_LAUNCH_SLAB, wy, wz, by);
 #undef LSF_LAUNCH_SLAB
+#undef LSF_LAUNCH_SLAB_AS
             grid_used = grid;
             HIPCHK(hipGetLastError());
         }
@@ -360,6 +390,16 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
             float ms = 0;
             if (hipEventElapsedTime(&ms, b.ev0, b.ev1) == hipSuccess) kernel_ms[d] += ms;
         }
+#ifdef LSF_EXPERIMENTS
+        if (fa[0].dbg) {
+            unsigned long long hd[8];
+            HIPCHK(hipSetDevice(S.s[0].device));
+            HIPCHK(hipMemcpy(hd, fa[0].dbg, sizeof hd, hipMemcpyDeviceToHost));
+            if (hd[7])
+                fprintf(stderr, "[lsf] tile phases (us per tile, %llu tiles): row table %.2f, load %.2f, march %.2f, write back %.2f\n", hd[7],
+                        hd[3] / 100.0 / hd[7], hd[4] / 100.0 / hd[7], hd[5] / 100.0 / hd[7], hd[6] / 100.0 / hd[7]);
+        }
+#endif
         // slab 0's copy of the control words (every slab holds the same: the epilogues store them everywhere)
         HIPCHK(hipSetDevice(S.s[0].device));
         HIPCHK(hipMemcpy(host_ctl, S.s[0].ctlblk, sizeof host_ctl, hipMemcpyDeviceToHost));

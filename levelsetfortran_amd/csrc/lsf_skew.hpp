@@ -48,6 +48,10 @@
 #define LSF_CELL_UNROLL 8 // one lane per cell: marching steps per iteration of the march loop (code size vs. loop overhead)
 #endif
 
+#ifndef LSF_POLL_SLEEP
+#define LSF_POLL_SLEEP 16 // 64-cycle units between two looks of a waiting tile at its flags
+#endif
+
 namespace lsf {
 
 // A tile is WY x WZ adjacent 5 x 4 bundles (one wavefront each), marched in lock step: NYT = 5 WY by NZT = 4 WZ
@@ -231,7 +235,12 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     int tid_ = threadIdx.x;
     // called from a loop over tiles (k_reinit_gs_slab): what depends on the thread index only would be computed in front of the
     // loop and kept in vector registers across it (measured: 60 of them spilled to scratch) -- make it a value of this call
-    if constexpr (PUSH) asm volatile("" : "+v"(tid_));
+#ifndef LSF_GS_LAUNDER
+#define LSF_GS_LAUNDER 0 // experiment: the same in the single launch
+#endif
+#ifndef LSF_SLAB_NO_TLAUNDER
+    if constexpr (PUSH || LSF_GS_LAUNDER) asm volatile("" : "+v"(tid_));
+#endif
     const int tid = tid_, lane = tid & 63, wave = tid >> 6;
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1);
@@ -242,7 +251,10 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
 #ifndef LSF_SLAB_AGENT_SCOPE
 #define LSF_SLAB_AGENT_SCOPE 0
 #endif
-    constexpr bool SYS = PUSH && !LSF_SLAB_AGENT_SCOPE;
+#ifndef LSF_GS_SYS_SCOPE
+#define LSF_GS_SYS_SCOPE 0 // experiment: the single launch's loads / stores at system scope too
+#endif
+    constexpr bool SYS = (PUSH && !LSF_SLAB_AGENT_SCOPE) || (SC1 && LSF_GS_SYS_SCOPE);
     auto ldp = [](const double* p_) { return SYS ? ld_sys(p_) : (SC1 ? ld_sc1(p_) : *p_); };
     auto stp = [](double* p_, double v_) {
         if (SYS) st_sys(p_, v_);
@@ -657,28 +669,72 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
         nb_lo = a.peers->nb_buf[0][ob], nb_hi = a.peers->nb_buf[1][ob];
         k_push_lo = 1 + a.tk_lo * NZT + 3, k_push_hi = min(1 + a.tk_hi * NZT, nz) - 3;
     }
+    // Near the walls: the old values of the wall points (their change enters the RMS, subs.f90:902-914) are asked for BEFORE any
+    // result of the chunk is stored, all of them in flight together.  Taken one by one inside the store loop, each cost a round
+    // trip past the caches, and -- the counter of outstanding memory operations being one for loads and stores -- the wait for
+    // each also waited for the acknowledgement of the write-through stores in front of it: up to 35 such waits in a row for a
+    // wavefront of a corner tile, and the tiles along the walls are the first of every hyperplane.  At 256^3, where a sweep is
+    // bound by the latency of its dependency chains, 0.725 -> 0.65 ms per sweep.
+    constexpr int NUW = T::NCORE / (4 * W);        // row iterations of a lane
+#ifndef LSF_WB_CHUNK
+#define LSF_WB_CHUNK 3
+#endif
+    constexpr int GW = NUW < LSF_WB_CHUNK ? NUW : LSF_WB_CHUNK; // ... per chunk (7 old values each: registers)
+    struct WbRow {
+        int cq, t, gi, gj2, gk2, ai, aj, ak;
+        int2 e;
+        bool mine;
+    };
+    auto wb_row = [&](int u) {
+        WbRow w;
+        const int r = 4 * W * u + (tid >> 4);
+        w.cq = r / NYT;
+        const int bq = r - NYT * w.cq;
+        w.t = tid & 15;
+        w.e = rowtab[r];
+        w.gi = w.e.y + (si > 0 ? w.t : -w.t);
+        w.mine = bq < nj && w.cq < nk && (unsigned)(w.gi - 1) <= (unsigned)(nx - 2);
+        w.gj2 = j_lo + (sj > 0 ? bq : nj - 1 - bq), w.gk2 = k_lo + (sk > 0 ? w.cq : nk - 1 - w.cq);
+        // wall points that clamp to this cell: move outward along any non-empty subset of its wall-adjacent axes
+        w.ai = w.gi == 1 ? -1 : (w.gi == nx - 1 ? 1 : 0), w.aj = w.gj2 == 1 ? -1 : (w.gj2 == ny - 1 ? 1 : 0);
+        w.ak = w.gk2 == 1 ? -1 : (w.gk2 == nz - 1 ? 1 : 0);
+        return w;
+    };
+    auto sub_on = [](const WbRow& w, int sub) { return !(((sub & 1) && !w.ai) || ((sub & 2) && !w.aj) || ((sub & 4) && !w.ak)); };
 #pragma unroll
-    for (int u = 0; u < T::NCORE / (4 * W); ++u) {
-        const int r = 4 * W * u + (tid >> 4), cq = r / NYT, bq = r - NYT * cq, t = tid & 15;
-        const int2 e = rowtab[r];
-        const int gi = e.y + (si > 0 ? t : -t);
-        const bool mine = bq < nj && cq < nk && (unsigned)(gi - 1) <= (unsigned)(nx - 2);
-        const double val0 = lds[T::core_at(r) + 3 + t];
-        if (mine) stp(out_t + ((unsigned)(e.x >> 2) + (unsigned)gi), val0);
-        if constexpr (PUSH) {
-            const int gk2 = k_lo + (sk > 0 ? cq : nk - 1 - cq);
-            if (mine && nb_lo && gk2 < k_push_lo) st_sys(nb_lo + org + ((unsigned)(e.x >> 2) + (unsigned)gi), val0);
-            if (mine && nb_hi && gk2 >= k_push_hi) st_sys(nb_hi + org + ((unsigned)(e.x >> 2) + (unsigned)gi), val0);
-        }
-        if (near_wall && mine) {
-            const int gj2 = j_lo + (sj > 0 ? bq : nj - 1 - bq), gk2 = k_lo + (sk > 0 ? cq : nk - 1 - cq);
-            // wall points that clamp to this cell: move outward along any non-empty subset of its wall-adjacent axes
-            const int ai = gi == 1 ? -1 : (gi == nx - 1 ? 1 : 0), aj = gj2 == 1 ? -1 : (gj2 == ny - 1 ? 1 : 0),
-                      ak = gk2 == 1 ? -1 : (gk2 == nz - 1 ? 1 : 0);
-            if (ai | aj | ak) {
+    for (int u0 = 0; u0 < NUW; u0 += GW) {
+        double oldw[GW][7];
+        if (near_wall) {
+#pragma unroll
+            for (int g_ = 0; g_ < GW; ++g_) {
+                if (u0 + g_ >= NUW) break;
+                const WbRow w = wb_row(u0 + g_);
+#pragma unroll
                 for (int sub = 1; sub < 8; ++sub) {
-                    if (((sub & 1) && !ai) || ((sub & 2) && !aj) || ((sub & 4) && !ak)) continue;
-                    const int wi = gi + ((sub & 1) ? ai : 0), wj = gj2 + ((sub & 2) ? aj : 0), wk = gk2 + ((sub & 4) ? ak : 0);
+                    oldw[g_][sub - 1] = 0.0;
+                    if (!w.mine || !sub_on(w, sub)) continue;
+                    const int wi = w.gi + ((sub & 1) ? w.ai : 0), wj = w.gj2 + ((sub & 2) ? w.aj : 0), wk = w.gk2 + ((sub & 4) ? w.ak : 0);
+                    oldw[g_][sub - 1] = ldp(in + (wi + sx * wj + sxy * wk));
+                }
+            }
+        }
+#pragma unroll
+        for (int g_ = 0; g_ < GW; ++g_) {
+            const int u = u0 + g_;
+            if (u >= NUW) break;
+            const WbRow w = wb_row(u);
+            const int r = 4 * W * u + (tid >> 4);
+            const double val0 = lds[T::core_at(r) + 3 + w.t];
+            if (w.mine) stp(out_t + ((unsigned)(w.e.x >> 2) + (unsigned)w.gi), val0);
+            if constexpr (PUSH) {
+                if (w.mine && nb_lo && w.gk2 < k_push_lo) st_sys(nb_lo + org + ((unsigned)(w.e.x >> 2) + (unsigned)w.gi), val0);
+                if (w.mine && nb_hi && w.gk2 >= k_push_hi) st_sys(nb_hi + org + ((unsigned)(w.e.x >> 2) + (unsigned)w.gi), val0);
+            }
+            if (near_wall && w.mine && (w.ai | w.aj | w.ak)) {
+#pragma unroll
+                for (int sub = 1; sub < 8; ++sub) {
+                    if (!sub_on(w, sub)) continue;
+                    const int wi = w.gi + ((sub & 1) ? w.ai : 0), wj = w.gj2 + ((sub & 2) ? w.aj : 0), wk = w.gk2 + ((sub & 4) ? w.ak : 0);
                     const int nb = __builtin_popcount(sub);
                     const int nh = (int)(wi == nx) + (int)(wj == ny) + (int)(wk == nz);
                     const int mrep = min(nb, 1 + nh);
@@ -688,7 +744,7 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
                         for (int rr = 0; rr < mrep; ++rr) val = val + dx;
                     }
                     const long p = wi + sx * wj + sxy * wk;
-                    const double dlt = val - ldp(in + p);
+                    const double dlt = val - oldw[g_][sub - 1];
                     stp(out + p, val);
                     if constexpr (PUSH) {
                         if (nb_lo && wk < k_push_lo) st_sys(nb_lo + p, val);
@@ -842,17 +898,21 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
 // is no deadlock whatever the dispatch order or the number of resident blocks; every spin is bounded (ctl[2] = 2 on
 // time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
 // plane_cnt[s][P]; the last tile of a hyperplane publishes planes_done[s] = P + 1.
-template <int TA, int WY, int WZ, int BY, bool STRICT>
+template <int TA, int WY, int WZ, int BY, bool STRICT, bool PUSHX = false>
 __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_persist(GsArgs a)
 {
     using T = SkTile<TA, WY, WZ, BY>;
     __shared__ int sh_task[8]; // packed tile, s | P << DF_SWEEP_BITS, go flag, raster signs of the sweep, go flag of stage 2
-    const int tid = threadIdx.x;
+    int tid_k = threadIdx.x;
+    if (LSF_GS_LAUNDER) asm volatile("" : "+v"(tid_k));
+    const int tid = tid_k;
     const int np = a.np;
     const int nM = a.nM;                       // tile_done[s] is indexed m + nM * (B + nTj * C)
     const long per_sweep = (long)nM * a.nTj * a.nTk;
     {
-        const unsigned long long tsA = __builtin_amdgcn_s_memrealtime();
+        // (time stamps of LSF_TRACE_TILES only where asked for: s_memrealtime is a scalar memory read, and the first
+        // s_waitcnt lgkmcnt(0) behind it -- the one in front of the tile's first LDS access -- waits for it)
+        const unsigned long long tsA = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
         const SkPre pre = sk_prefetch<TA, WY, WZ, BY>(a); // in flight while the block takes its ticket and waits for its tile
         // thread 0 only: the flags of the up to three upstream tiles (condition (a), awaited between the two load stages)
         const int *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
@@ -910,7 +970,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                         go = 2;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(16); // ~0.5 us between looks; 8..64 measured within 2 % of each other
+                    __builtin_amdgcn_s_sleep(LSF_POLL_SLEEP); // ~0.5 us between looks; 8..64 measured within 2 % of each other
                 }
                 sh_task[3] = a.sweep_tab[4 * s], sh_task[4] = a.sweep_tab[4 * s + 1], sh_task[5] = a.sweep_tab[4 * s + 2];
             }
@@ -924,7 +984,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
         int go = uni(sh_task[2]);
         const int s = sP & (DF_BATCH - 1), P = (int)((unsigned)sP >> DF_SWEEP_BITS);
         if (go == 0) return;
-        const unsigned long long tsB = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long tsB = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
         // stage 2, called by skew_tile with its stage-1 loads in flight: condition (a) -- the upstream tiles of this sweep
         auto wait_upstream = [&]() -> bool {
             if (tid == 0) {
@@ -944,7 +1004,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                         go2 = 2;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(16);
+                    __builtin_amdgcn_s_sleep(LSF_POLL_SLEEP);
                 }
                 sh_task[6] = go2;
             }
@@ -953,7 +1013,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
             return uni(sh_task[6]) == 1;
         };
         if (go == 1) {
-            if (!skew_tile<TA, WY, WZ, BY, STRICT, true>(a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream))
+            if (!skew_tile<TA, WY, WZ, BY, STRICT, true, PUSHX>(a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream))
                 go = 2;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1026,14 +1086,19 @@ __global__ __launch_bounds__(256) void k_build_order_slab(uint2* __restrict__ or
     }
 }
 
-template <int TA, int WY, int WZ, int BY, bool STRICT>
-// 2 x 2 wavefronts, three lanes per cell: four tiles per CU (128 registers), not the five of k_reinit_gs_persist -- inside the
-// ticket loop the compiler needs ~106 registers, at five per CU (96) it spills ten to scratch: 3.09 against 2.95 ms per
-// 512^3 sweep on one box (k_reinit_gs_persist: 2.75)
+// LOOP = true: a loop over tickets, for slabs that SHARE a device (the rehearsal): the launches wait for each other, so each must
+// be resident as a whole.  2 x 2 wavefronts, three lanes per cell: four tiles per CU (128 registers), not the five of
+// k_reinit_gs_persist -- inside the ticket loop the compiler needs ~106 registers, at five per CU (96) it spills ten to scratch:
+// 3.09 against 2.95 ms per 512^3 sweep on one box (k_reinit_gs_persist: 2.75).
+// LOOP = false: one block per tile like k_reinit_gs_persist, for a slab that has its device to itself (what a node runs): the
+// blocks of a launch take their tickets in list order as they become resident, so the earliest unfinished tile of a device is
+// always held by a resident block, and what it waits for on OTHER devices is held by resident blocks there -- no deadlock
+// without the loop, no loop-carried registers, five tiles per CU.
 #ifndef LSF_SLAB_WAVES
 #define LSF_SLAB_WAVES 4
 #endif
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? LSF_SLAB_WAVES : 1)))) void k_reinit_gs_slab(GsArgs args_)
+template <int TA, int WY, int WZ, int BY, bool STRICT, bool LOOP>
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? (LOOP ? LSF_SLAB_WAVES : 5) : 1)))) void k_reinit_gs_slab(GsArgs args_)
 {
     using T = SkTile<TA, WY, WZ, BY>;
     __shared__ int sh_task[8]; // as in k_reinit_gs_persist
@@ -1041,14 +1106,18 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     for (;;) {
         int tid = threadIdx.x;
+#ifndef LSF_SLAB_NO_TLAUNDER
         asm volatile("" : "+v"(tid)); // (and nothing that depends on the thread index only either: see skew_tile)
+#endif
         // The arguments are read afresh in every iteration, through a pointer the compiler cannot see through: left to itself it
         // loads all of them in front of the loop and keeps them in registers across it -- 73 scalar registers spilled to vector
         // lanes, those to 272 bytes of scratch per lane, 38 % more time per tile than k_reinit_gs_persist.  (GsArgs is the
         // kernel's only argument: it starts the kernarg segment.)
         typedef const __attribute__((address_space(4))) GsArgs* KArg;
         KArg kp = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+#ifndef LSF_SLAB_NO_KLAUNDER
         asm volatile("" : "+s"(kp));
+#endif
         const GsArgs& a = *(const GsArgs*)kp;
         const int np = a.np;
         const int nM = a.nM;
@@ -1101,7 +1170,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                         go = 2;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(16);
+                    __builtin_amdgcn_s_sleep(LSF_POLL_SLEEP);
                 }
                 sh_task[3] = a.sweep_tab[4 * s], sh_task[4] = a.sweep_tab[4 * s + 1], sh_task[5] = a.sweep_tab[4 * s + 2];
             }
@@ -1133,7 +1202,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                         go2 = 2;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(16);
+                    __builtin_amdgcn_s_sleep(LSF_POLL_SLEEP);
                 }
                 sh_task[6] = go2;
             }
@@ -1170,9 +1239,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
             }
         }
         // thread 0 rewrites sh_task only after the barrier above, which every wave reaches after its last read of it
-#ifdef LSF_EXPERIMENTS
-        if (a.seg_g[0] == 1) return; // one tile per block, as in k_reinit_gs_persist (timing experiment, one slab only)
-#endif
+        if constexpr (!LOOP) return;
     }
 }
 

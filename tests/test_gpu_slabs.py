@@ -191,6 +191,24 @@ def test_slabs_at_baseline_sizes_equal_the_reference_itself(lsf, n, slabs):
     assert np.allclose(rep.rms, g[f"n{n}_rms"], rtol=1e-7, atol=0)
 
 
+def test_one_slab_both_launch_forms(lsf, env):
+    """a slab that has its device to itself runs one block per tile (what a node runs), slabs that share a device a loop over
+    tickets: with one slab both forms can be asked for"""
+    import ctypes
+
+    from levelsetfortran_amd import _lib
+
+    grids = {}
+    for loop in ("0", "1"):
+        env["LSF_SLAB_LOOP"] = loop
+        want, r1, got, r = _both(lsf, (70, 66, 90), 1, 13, "fast")
+        assert np.array_equal(got, want) and r.rms == r1.rms
+        g = ctypes.c_int(0)
+        _lib.check(_lib.load().lsf_slabs_info(None, ctypes.byref(g), None, None, None))
+        grids[loop] = g.value
+    assert grids["0"] > grids["1"] > 0  # every tile of the batch against the blocks the device holds at once
+
+
 def test_slabs_single_sweep(lsf):
     """iter = 0: one sweep, one batch of one"""
     want, r1, got, r = _both(lsf, (40, 36, 26), 2, 0, "strict")
