@@ -669,12 +669,13 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
         nb_lo = a.peers->nb_buf[0][ob], nb_hi = a.peers->nb_buf[1][ob];
         k_push_lo = 1 + a.tk_lo * NZT + 3, k_push_hi = min(1 + a.tk_hi * NZT, nz) - 3;
     }
-    // Near the walls: the old values of the wall points (their change enters the RMS, subs.f90:902-914) are asked for BEFORE any
-    // result of the chunk is stored, all of them in flight together.  Taken one by one inside the store loop, each cost a round
-    // trip past the caches, and -- the counter of outstanding memory operations being one for loads and stores -- the wait for
-    // each also waited for the acknowledgement of the write-through stores in front of it: up to 35 such waits in a row for a
-    // wavefront of a corner tile, and the tiles along the walls are the first of every hyperplane.  At 256^3, where a sweep is
-    // bound by the latency of its dependency chains, 0.725 -> 0.65 ms per sweep.
+    // Near the walls the old values of the wall points are needed (their change enters the RMS, subs.f90:902-914).  Taken one by
+    // one inside the store loop, as this was written first, each cost a round trip past the caches, and -- the counter of
+    // outstanding memory operations being one for loads and stores -- the wait for each also waited for the acknowledgement of
+    // the write-through stores in front of it, at EVERY row of a tile near a wall whether the lane had wall points or not; the
+    // tiles along the walls are the first of every hyperplane.  Now: wall points first (chunks of rows, all old values of a chunk
+    // in flight together, wavefronts without wall points skip), then the cells.  At 256^3, where a sweep is bound by the latency
+    // of its dependency chains: 0.725 -> 0.65 ms per sweep; the summation order of the RMS is unchanged.
     constexpr int NUW = T::NCORE / (4 * W);        // row iterations of a lane
 #ifndef LSF_WB_CHUNK
 #define LSF_WB_CHUNK 3
@@ -701,14 +702,18 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
         return w;
     };
     auto sub_on = [](const WbRow& w, int sub) { return !(((sub & 1) && !w.ai) || ((sub & 2) && !w.aj) || ((sub & 4) && !w.ak)); };
+    // 1. the wall points, chunk by chunk -- only loads are outstanding when a chunk waits for its old values, and a wavefront
+    //    without wall points (most wavefronts of a tile at a wall) passes without waiting at all
+    if (near_wall) {
 #pragma unroll
-    for (int u0 = 0; u0 < NUW; u0 += GW) {
-        double oldw[GW][7];
-        if (near_wall) {
+        for (int u0 = 0; u0 < NUW; u0 += GW) {
+            double oldw[GW][7];
+            bool any = false;
 #pragma unroll
             for (int g_ = 0; g_ < GW; ++g_) {
                 if (u0 + g_ >= NUW) break;
                 const WbRow w = wb_row(u0 + g_);
+                any = any || (w.mine && (w.ai | w.aj | w.ak));
 #pragma unroll
                 for (int sub = 1; sub < 8; ++sub) {
                     oldw[g_][sub - 1] = 0.0;
@@ -717,20 +722,14 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
                     oldw[g_][sub - 1] = ldp(in + (wi + sx * wj + sxy * wk));
                 }
             }
-        }
+            if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
 #pragma unroll
-        for (int g_ = 0; g_ < GW; ++g_) {
-            const int u = u0 + g_;
-            if (u >= NUW) break;
-            const WbRow w = wb_row(u);
-            const int r = 4 * W * u + (tid >> 4);
-            const double val0 = lds[T::core_at(r) + 3 + w.t];
-            if (w.mine) stp(out_t + ((unsigned)(w.e.x >> 2) + (unsigned)w.gi), val0);
-            if constexpr (PUSH) {
-                if (w.mine && nb_lo && w.gk2 < k_push_lo) st_sys(nb_lo + org + ((unsigned)(w.e.x >> 2) + (unsigned)w.gi), val0);
-                if (w.mine && nb_hi && w.gk2 >= k_push_hi) st_sys(nb_hi + org + ((unsigned)(w.e.x >> 2) + (unsigned)w.gi), val0);
-            }
-            if (near_wall && w.mine && (w.ai | w.aj | w.ak)) {
+            for (int g_ = 0; g_ < GW; ++g_) {
+                const int u = u0 + g_;
+                if (u >= NUW) break;
+                const WbRow w = wb_row(u);
+                if (!(w.mine && (w.ai | w.aj | w.ak))) continue;
+                const double val0 = lds[T::core_at(4 * W * u + (tid >> 4)) + 3 + w.t];
 #pragma unroll
                 for (int sub = 1; sub < 8; ++sub) {
                     if (!sub_on(w, sub)) continue;
@@ -753,6 +752,17 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
                     acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
                 }
             }
+        }
+    }
+    // 2. the cells: nothing waits between these stores
+#pragma unroll
+    for (int u = 0; u < NUW; ++u) {
+        const WbRow w = wb_row(u);
+        const double val0 = lds[T::core_at(4 * W * u + (tid >> 4)) + 3 + w.t];
+        if (w.mine) stp(out_t + ((unsigned)(w.e.x >> 2) + (unsigned)w.gi), val0);
+        if constexpr (PUSH) {
+            if (w.mine && nb_lo && w.gk2 < k_push_lo) st_sys(nb_lo + org + ((unsigned)(w.e.x >> 2) + (unsigned)w.gi), val0);
+            if (w.mine && nb_hi && w.gk2 >= k_push_hi) st_sys(nb_hi + org + ((unsigned)(w.e.x >> 2) + (unsigned)w.gi), val0);
         }
     }
     }
