@@ -680,7 +680,11 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
 #ifndef LSF_WB_CHUNK
 #define LSF_WB_CHUNK 3
 #endif
-    constexpr int GW = NUW < LSF_WB_CHUNK ? NUW : LSF_WB_CHUNK; // ... per chunk (7 old values each: registers)
+#ifndef LSF_WB_CHUNK16
+#define LSF_WB_CHUNK16 3
+#endif
+    constexpr int GWC = BY == 16 ? LSF_WB_CHUNK16 : LSF_WB_CHUNK;
+    constexpr int GW = NUW < GWC ? NUW : GWC; // ... per chunk (7 old values each: registers)
     struct WbRow {
         int cq, t, gi, gj2, gk2, ai, aj, ak;
         int2 e;
