@@ -278,6 +278,13 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     const int gb = a.nbuf == 4 ? (g & 3) : g % 3; // nbuf is 3 or 4: no division by a run-time value
     const double* in = a.buf[gb];
     double* out = a.buf[gb + 1 == a.nbuf ? 0 : gb + 1];
+    // slabs: the planes [k_own_lo, k_own_lo + 3) also live in the lower neighbour's buffer, [k_own_hi - 3, k_own_hi) in the upper
+    // one's (their addresses come from device memory: asked for here, used by the write back)
+    [[maybe_unused]] double *nb_lo = nullptr, *nb_hi = nullptr;
+    if constexpr (PUSH) {
+        const int ob = gb + 1 == a.nbuf ? 0 : gb + 1;
+        nb_lo = a.peers->nb_buf[0][ob], nb_hi = a.peers->nb_buf[1][ob];
+    }
 
     // ---- row table ------------------------------------------------------------------------------------------
     // rowtab[r].x = (element offset of the row's i = 0 point from the tile origin) * 4 + flags
@@ -661,14 +668,7 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
             }
         }
     } else {
-    // slabs: the planes [k_own_lo, k_own_lo + 3) also live in the lower neighbour's buffer, [k_own_hi - 3, k_own_hi) in the upper one's
-    [[maybe_unused]] double *nb_lo = nullptr, *nb_hi = nullptr;
-    [[maybe_unused]] int k_push_lo = 0, k_push_hi = 0;
-    if constexpr (PUSH) {
-        const int ob = gb + 1 == a.nbuf ? 0 : gb + 1;
-        nb_lo = a.peers->nb_buf[0][ob], nb_hi = a.peers->nb_buf[1][ob];
-        k_push_lo = 1 + a.tk_lo * NZT + 3, k_push_hi = min(1 + a.tk_hi * NZT, nz) - 3;
-    }
+    [[maybe_unused]] const int k_push_lo = PUSH ? 1 + a.tk_lo * NZT + 3 : 0, k_push_hi = PUSH ? min(1 + a.tk_hi * NZT, nz) - 3 : 0;
     // Near the walls the old values of the wall points are needed (their change enters the RMS, subs.f90:902-914).  Taken one by
     // one inside the store loop, as this was written first, each cost a round trip past the caches, and -- the counter of
     // outstanding memory operations being one for loads and stores -- the wait for each also waited for the acknowledgement of
