@@ -800,6 +800,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     if ((rc = ws(c.slot[S_COLSUM], (size_t)4 * nTj * nTk * sizeof(double)))) return rc;
     int* ctl = (int*)c.slot[S_CTL].p;
     HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(ctl + 4), 0x7fffffff, 1, st)); // ctl[4]: never 0 (k_reinit_gs_persist: the flag of an absent upstream tile)
 
     // nbuf field buffers in rotation: sweep g overwrites the result of sweep g - nbuf, so it has to wait for the
     // stop verdict of that sweep only, and consecutive sweeps are spaced by the raster-flip rule alone.

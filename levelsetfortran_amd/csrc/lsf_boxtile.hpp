@@ -42,7 +42,7 @@ struct GsArgs {
     double* trace;
     int trace_cap;
     double den, tol;
-    int* ctl;           // [0] done, [1] sweeps completed, [2] status (1 NaN, 2 timeout), [3] unused
+    int* ctl;           // [0] done, [1] sweeps completed, [2] status (1 NaN, 2 timeout), [3] unused, [4] INT_MAX (dataflow launches)
     long nTiles;
     // slot launches (dependencies resolved by launch order): up to 4 tile-plane segments, one per sweep in
     // flight; seg_end[] = running block count (segment q holds the blocks seg_end[q-1] <= blockIdx.x < seg_end[q])

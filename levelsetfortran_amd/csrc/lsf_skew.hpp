@@ -929,7 +929,8 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
         const unsigned long long tsA = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
         const SkPre pre = sk_prefetch<TA, WY, WZ, BY>(a); // in flight while the block takes its ticket and waits for its tile
         // thread 0 only: the flags of the up to three upstream tiles (condition (a), awaited between the two load stages)
-        const int *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
+        const int* const set_word = a.ctl + 4; // a word that is never 0 (host): stands in for an upstream tile that does not exist
+        const int *w0 = set_word, *w1 = set_word, *w2 = set_word;
         unsigned long long t0 = 0;
         auto give_up = [&]() { // converged, NaN or time-out elsewhere: skip, and let the blocks still to come leave at once
             __hip_atomic_fetch_max(a.ticket, (int)a.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -945,9 +946,9 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 auto m_lo = [&](int B_, int C_) { return (T::NYT * B_ + T::NZT * C_) / TA; };
                 auto m_hi = [&](int B_, int C_) { return (T::NYT * B_ + T::NYT - 1 + T::NZT * C_ + T::NZT - 1 + a.nx - 2) / TA; };
                 const int* td = a.tile_done + s * per_sweep;
-                w0 = m - 1 >= m_lo(B, C) ? td + (m - 1) + (long)nM * (B + (long)a.nTj * C) : nullptr;
-                w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : nullptr;
-                w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : nullptr;
+                w0 = m - 1 >= m_lo(B, C) ? td + (m - 1) + (long)nM * (B + (long)a.nTj * C) : set_word;
+                w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : set_word;
+                w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : set_word;
                 const int* pd = a.planes_done;
                 const int need1 = s == 0 ? 0 : min(P + a.sweep_tab[4 * s + 3], np);
                 const int need3 = s < a.nbuf ? 0 : np + 1;
@@ -1005,7 +1006,9 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 int go2 = 1;
                 for (;;) {
                     const int vstop = ld_flag(a.ctl + 0);
-                    const int v0 = w0 ? ld_flag(w0) : 1, v1 = w1 ? ld_flag(w1) : 1, v2 = w2 ? ld_flag(w2) : 1;
+                    // (three unconditional loads in flight together: `w ? load : 1` compiled to a branch, a load and a wait per
+                    // flag -- three round trips past the caches one after the other between two looks)
+                    const int v0 = ld_flag(w0), v1 = ld_flag(w1), v2 = ld_flag(w2);
                     if (vstop != 0) {
                         go2 = 2;
                         give_up();
@@ -1152,9 +1155,10 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 auto m_lo = [&](int B_, int C_) { return (T::NYT * B_ + T::NZT * C_) / TA; };
                 auto m_hi = [&](int B_, int C_) { return (T::NYT * B_ + T::NYT - 1 + T::NZT * C_ + T::NZT - 1 + a.nx - 2) / TA; };
                 const int* td = a.tile_done + s * per_sweep; // the neighbour raises the flags of its tiles next to the cut here
-                const int* w0 = m - 1 >= m_lo(B, C) ? td + (m - 1) + (long)nM * (B + (long)a.nTj * C) : nullptr;
-                const int* w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : nullptr;
-                const int* w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : nullptr;
+                const int* const set_word = a.ctl + 4; // INT_MAX (host): stands in for an upstream tile that does not exist
+                const int* w0 = m - 1 >= m_lo(B, C) ? td + (m - 1) + (long)nM * (B + (long)a.nTj * C) : set_word;
+                const int* w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : set_word;
+                const int* w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : set_word;
                 const int need1 = s == 0 ? 0 : min(P + a.sweep_tab[4 * s + 3], np);
                 const int* always = a.ctl + 4; // INT_MAX (host)
                 const int* p3 = s == 0 ? always : a.planes_done + s - 1;
@@ -1204,7 +1208,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 const unsigned long long t0 = sh_wait[3];
                 for (;;) {
                     const int vstop = ld_flag_sys(a.ctl + 0);
-                    const int v0 = w0 ? ld_flag(w0) : 1, v1 = w1 ? ld_flag(w1) : 1, v2 = w2 ? ld_flag_sys(w2) : 1;
+                    const int v0 = ld_flag(w0), v1 = ld_flag(w1), v2 = ld_flag_sys(w2); // (unconditional: see k_reinit_gs_persist)
                     if (vstop != 0) {
                         go2 = 2;
                         give_up();
