@@ -950,7 +950,8 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : set_word;
                 w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : set_word;
                 const int* pd = a.planes_done;
-                const int need1 = s == 0 ? 0 : min(P + a.sweep_tab[4 * s + 3], np);
+                const int4 swp = *(const int4*)(a.sweep_tab + 4 * s); // signs and spacing of the sweep: one request
+                const int need1 = s == 0 ? 0 : min(P + swp.w, np);
                 const int need3 = s < a.nbuf ? 0 : np + 1;
                 // absent conditions point at a word that always passes (the stop flag's neighbour ctl[1] >= 0)
                 const int* always = a.ctl + 1;
@@ -987,7 +988,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                     }
                     __builtin_amdgcn_s_sleep(LSF_POLL_SLEEP); // ~0.5 us between looks; 8..64 measured within 2 % of each other
                 }
-                sh_task[3] = a.sweep_tab[4 * s], sh_task[4] = a.sweep_tab[4 * s + 1], sh_task[5] = a.sweep_tab[4 * s + 2];
+                sh_task[3] = swp.x, sh_task[4] = swp.y, sh_task[5] = swp.z;
             }
             sh_task[0] = (int)e.x, sh_task[1] = (int)e.y, sh_task[2] = go;
         }
@@ -1159,7 +1160,8 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 const int* w0 = m - 1 >= m_lo(B, C) ? td + (m - 1) + (long)nM * (B + (long)a.nTj * C) : set_word;
                 const int* w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : set_word;
                 const int* w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : set_word;
-                const int need1 = s == 0 ? 0 : min(P + a.sweep_tab[4 * s + 3], np);
+                const int4 swp = *(const int4*)(a.sweep_tab + 4 * s); // signs and spacing of the sweep: one request
+                const int need1 = s == 0 ? 0 : min(P + swp.w, np);
                 const int* always = a.ctl + 4; // INT_MAX (host)
                 const int* p3 = s == 0 ? always : a.planes_done + s - 1;
                 const int* p3l = (s == 0 || !a.nb_pd[0]) ? always : a.pd_of_nb[0] + s - 1;
@@ -1190,7 +1192,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                     }
                     __builtin_amdgcn_s_sleep(LSF_POLL_SLEEP);
                 }
-                sh_task[3] = a.sweep_tab[4 * s], sh_task[4] = a.sweep_tab[4 * s + 1], sh_task[5] = a.sweep_tab[4 * s + 2];
+                sh_task[3] = swp.x, sh_task[4] = swp.y, sh_task[5] = swp.z;
             }
             sh_task[0] = (int)e.x, sh_task[1] = (int)e.y, sh_task[2] = go;
         }
