@@ -850,15 +850,18 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     long launches = 0;
     bool marked = false;
     if (persist) {
-        // Dataflow schedule (k_reinit_gs_persist): one launch per batch of up to DF_BATCH = 64 sweeps, one block per tile,
+        // Dataflow schedule (k_reinit_gs_persist): one launch per batch of up to DF_BATCH = 256 sweeps, one block per tile,
         // dependencies resolved in the kernel.  What depends on the grid, the raster phase of the batch's first sweep and the
         // number of sweeps (start slots, entries per slot, spacing table) is small and cached on the device; the task list
         // itself is rebuilt by k_build_order in front of every launch.
         const long ntiles = tl->off[np];
-        // sweeps per launch: 64 (a batch costs about one sweep time of fill and drain, measured 26.6 / 50.0 / 73.9 /
-        // 97.4 ms for 8 / 16 / 24 / 32 sweeps at 512^3), fewer on very large grids so that the task list stays below
-        // 512 MB; a multiple of 8 keeps the raster phase, hence the cached plan, the same
-        const int BATCH = (int)std::max<long>(8, std::min<long>(DF_BATCH, (512L << 20) / (ntiles * 8) / 8 * 8));
+        // sweeps per launch: up to 256 (a batch costs about one sweep time of fill and drain, measured 26.6 / 50.0 / 73.9 /
+        // 97.4 ms for 8 / 16 / 24 / 32 sweeps at 512^3; 256^3 to convergence: 0.645 -> 0.628 ms per sweep against 64 per
+        // launch), fewer on very large grids so that the task list stays below 512 MB; a multiple of 8 keeps the raster
+        // phase, hence the cached plan, the same
+        // (calls of up to 64 sweeps keep the 64-sweep layout of their control arrays: what bench.py times)
+        int BATCH = (int)std::max<long>(8, std::min<long>(max_sweeps <= 64 ? 64 : DF_BATCH, (512L << 20) / (ntiles * 8) / 8 * 8));
+        if (const char* e = getenv("LSF_DF_BATCH")) BATCH = std::max(8, std::min(BATCH, atoi(e) / 8 * 8)); // test hook: batch boundaries
         const int nM = (knx - 2 + nyc * nTj - 1 + nzc * nTk - 1) / ta + 1; // m_max + 1 (get_skew_tiles)
         const size_t tile_flags = (size_t)BATCH * nM * nTj * nTk;
         // hyperplane counters | 4 KB | leading-hyperplane counters of the sweeps | 4 KB | ticket: the three are polled / updated at

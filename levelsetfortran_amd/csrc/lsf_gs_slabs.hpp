@@ -253,7 +253,8 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
     // ---- batches of up to DF_BATCH sweeps: one launch per slab and batch -------------------------------------------------
     long max_tiles = 0;
     for (Slab& b : S.s) max_tiles = std::max<long>(max_tiles, std::max(b.off[0][np], b.off[1][np]));
-    const int BATCH = (int)std::max<long>(8, std::min<long>(DF_BATCH, (512L << 20) / (std::max<long>(max_tiles, 1) * 8) / 8 * 8));
+    int BATCH = (int)std::max<long>(8, std::min<long>(max_sweeps <= 64 ? 64 : DF_BATCH, (512L << 20) / (std::max<long>(max_tiles, 1) * 8) / 8 * 8));
+    if (const char* e = getenv("LSF_DF_BATCH")) BATCH = std::max(8, std::min(BATCH, atoi(e) / 8 * 8)); // test hook: batch boundaries
     int host_ctl[4] = {0, 0, 0, 0};
     std::vector<double> kernel_ms(ndev, 0.0);
     int grid_used = 0;

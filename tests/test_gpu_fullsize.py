@@ -142,9 +142,10 @@ def test_full_size_field_equals_the_reference_itself(n):
 
 @pytest.mark.parametrize("arith", ["strict", "fast"])
 def test_dataflow_launch_equals_slot_launches_over_many_sweeps(arith, monkeypatch):
-    """70 sweeps on a 300 x 250 x 200 grid (partial tiles on every axis, three batches' worth of raster phases, up to
-    four sweeps in flight): the dataflow launch (in-kernel dependencies, tiles marching along y) and the slot launches
-    (dependencies = launch boundaries, tiles marching along x) must produce the same bits and the same sweep count."""
+    """70 sweeps on a 300 x 250 x 200 grid (partial tiles on every axis, up to four sweeps in flight; batches of 24 sweeps:
+    three launches with all their raster phases, LSF_DF_BATCH): the dataflow launch (in-kernel dependencies, tiles marching
+    along y) and the slot launches (dependencies = launch boundaries, tiles marching along x) must produce the same bits and
+    the same sweep count."""
     import torch
 
     import levelsetfortran_amd as lsf
@@ -155,6 +156,7 @@ def test_dataflow_launch_equals_slot_launches_over_many_sweeps(arith, monkeypatc
     phi0, dx = fields.two_sphere_phi0_device(npts, "cuda")
     h = fields.reinit_step(dx)
     res = {}
+    monkeypatch.setenv("LSF_DF_BATCH", "24")
     for schedule in ("dataflow", "skew"):
         monkeypatch.setenv("LSF_GS_SCHEDULE", schedule)
         phi, ps = phi0.clone(), phi0.clone()

@@ -53,9 +53,9 @@ def _both(lsf, npts, slabs, iters, arith, tol=0.0):
 @pytest.mark.parametrize("npts,slabs,iters", [((60, 50, 40), 1, 5), ((60, 50, 40), 2, 9), ((96, 80, 72), 3, 20), ((71, 83, 97), 2, 12),
                                               ((33, 47, 98), 3, 10), ((40, 36, 26), 3, 17), ((128, 128, 128), 2, 70)])
 @pytest.mark.parametrize("arith", ["strict", "fast"])
-def test_slabs_equal_the_single_device_field_bitwise(lsf, npts, slabs, iters, arith):
-    if npts == (128, 128, 128) and arith == "strict":
-        iters = 66  # two batches of the dataflow launch (64 + 3 sweeps): control words are reset in between
+def test_slabs_equal_the_single_device_field_bitwise(lsf, npts, slabs, iters, arith, env):
+    if npts == (128, 128, 128):
+        env["LSF_DF_BATCH"] = "32" if arith == "strict" else "64"  # three resp. two batches: control words are reset in between
     want, r1, got, r = _both(lsf, npts, slabs, iters, arith)
     assert r.count == r1.count == iters + 1
     assert np.array_equal(got, want), float(np.abs(got - want).max())
@@ -77,13 +77,14 @@ def test_slabs_strict_is_the_oracle_bitwise(lsf, oracle):
 
 
 @pytest.mark.parametrize("lo,hi,cap,hf", [(3, 30, 40, 1.0), (66, 100, 110, 0.1)])
-def test_slabs_stop_at_the_reference_stop_sweep(lsf, lo, hi, cap, hf):
+def test_slabs_stop_at_the_reference_stop_sweep(lsf, env, lo, hi, cap, hf):
     """tol > 0: the sweep whose RMS falls below it is the last one on every slab, later sweeps already in flight are abandoned
     and the field returned is that sweep's -- in the first batch of the launch and (a tenth of the time step: the trace still
     falls after 64 sweeps) in the second"""
     npts = (64, 60, 56)
     phi0, n, dx, h = _field(npts)
     h *= hf
+    env["LSF_DF_BATCH"] = "64"  # (calls of more than 64 sweeps would otherwise run 256 per launch)
     probe = phi0.copy(order="F")
     ref = lsf.reinit(probe, None, None, *n, cap, dx, h, tol=0.0, order="gs", arith="fast")
     tr = np.array(ref.rms)
