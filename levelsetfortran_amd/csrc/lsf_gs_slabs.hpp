@@ -369,15 +369,6 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
                 a.dbg = dd;
             }
 #endif
-#ifdef LSF_EXPERIMENTS // which side makes the one-slab launch faster than lsf_reinit's at 256^3: the kernel or the buffers?
-            if (ndev == 1 && getenv("LSF_SLAB_USE_PERSIST") && !strict && wy == 2 && wz == 2 && by == 5) {
-                const dim3 gd((unsigned)std::min<long>(a.total, 65536), (unsigned)((a.total + 65535) / 65536));
-                HIPCHK(hipEventRecord(b.ev0, b.st));
-                if (atoi(getenv("LSF_SLAB_USE_PERSIST")) == 2) hipLaunchKernelGGL((k_reinit_gs_persist<16, 2, 2, 5, false, true>), gd, dim3(256), 0, b.st, a);
-                else hipLaunchKernelGGL((k_reinit_gs_persist<16, 2, 2, 5, false>), gd, dim3(256), 0, b.st, a);
-                HIPCHK(hipEventRecord(b.ev1, b.st));
-            } else
-#endif
             LSF_SK_SHAPES(LSF_LAUNCH_SLAB, wy, wz, by);
 #undef LSF_LAUNCH_SLAB
 #undef LSF_LAUNCH_SLAB_AS

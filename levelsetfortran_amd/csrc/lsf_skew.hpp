@@ -237,12 +237,7 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     int tid_ = threadIdx.x;
     // called from a loop over tiles (k_reinit_gs_slab): what depends on the thread index only would be computed in front of the
     // loop and kept in vector registers across it (measured: 60 of them spilled to scratch) -- make it a value of this call
-#ifndef LSF_GS_LAUNDER
-#define LSF_GS_LAUNDER 0 // experiment: the same in the single launch
-#endif
-#ifndef LSF_SLAB_NO_TLAUNDER
-    if constexpr (PUSH || LSF_GS_LAUNDER) asm volatile("" : "+v"(tid_));
-#endif
+    if constexpr (PUSH) asm volatile("" : "+v"(tid_)); // (in the single launch it costs 0.4-1 %: measured)
     const int tid = tid_, lane = tid & 63, wave = tid >> 6;
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const long sx = nx + 1, sxy = (long)(nx + 1) * (ny + 1);
@@ -918,14 +913,12 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
 // is no deadlock whatever the dispatch order or the number of resident blocks; every spin is bounded (ctl[2] = 2 on
 // time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
 // plane_cnt[s][P]; the last tile of a hyperplane publishes planes_done[s] = P + 1.
-template <int TA, int WY, int WZ, int BY, bool STRICT, bool PUSHX = false>
+template <int TA, int WY, int WZ, int BY, bool STRICT>
 __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_persist(GsArgs a)
 {
     using T = SkTile<TA, WY, WZ, BY>;
     __shared__ int sh_task[8]; // packed tile, s | P << DF_SWEEP_BITS, go flag, raster signs of the sweep, go flag of stage 2
-    int tid_k = threadIdx.x;
-    if (LSF_GS_LAUNDER) asm volatile("" : "+v"(tid_k));
-    const int tid = tid_k;
+    const int tid = threadIdx.x;
     const int np = a.np;
     const int nM = a.nM;                       // tile_done[s] is indexed m + nM * (B + nTj * C)
     const long per_sweep = (long)nM * a.nTj * a.nTk;
@@ -1037,7 +1030,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
             return uni(sh_task[6]) == 1;
         };
         if (go == 1) {
-            if (!skew_tile<TA, WY, WZ, BY, STRICT, true, PUSHX>(a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream))
+            if (!skew_tile<TA, WY, WZ, BY, STRICT, true>(a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream))
                 go = 2;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1130,18 +1123,14 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     for (;;) {
         int tid = threadIdx.x;
-#ifndef LSF_SLAB_NO_TLAUNDER
         asm volatile("" : "+v"(tid)); // (and nothing that depends on the thread index only either: see skew_tile)
-#endif
         // The arguments are read afresh in every iteration, through a pointer the compiler cannot see through: left to itself it
         // loads all of them in front of the loop and keeps them in registers across it -- 73 scalar registers spilled to vector
         // lanes, those to 272 bytes of scratch per lane, 38 % more time per tile than k_reinit_gs_persist.  (GsArgs is the
         // kernel's only argument: it starts the kernarg segment.)
         typedef const __attribute__((address_space(4))) GsArgs* KArg;
         KArg kp = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
-#ifndef LSF_SLAB_NO_KLAUNDER
         asm volatile("" : "+s"(kp));
-#endif
         const GsArgs& a = *(const GsArgs*)kp;
         const int np = a.np;
         const int nM = a.nM;
