@@ -1,7 +1,10 @@
 #!/bin/bash
-# one box, experiment builds: k_reinit_gs_persist around skew_tile<PUSH> (LSF_SLAB_USE_PERSIST=2) at 256^3 with one part of the
-# PUSH write back switched off per library (xWB2: the copies of the cell results, xWB3: the copies of the wall points)
-for L in exp xWB2 xWB3 exp xWB2 xWB3; do
+# one box: the slab launch (profiles/micro/slab_bench.py) with experiment builds build/exp/liblsf_<name>.so against the product
+# library.  How the write back of the wall tiles was found: with -DLSF_EXPERIMENTS builds that
+# launched k_reinit_gs_persist around skew_tile<PUSH> on the one-slab launch's buffers and switched the parts of PUSH off one at
+# a time (commits 6d97f0c..fadb6da carry those switches; they are gone from the sources now).
+for L in ${LIBS:-prod}; do
+  P=$PWD/levelsetfortran_amd/liblsf_hip.so; [ $L != prod ] && P=$PWD/build/exp/liblsf_$L.so
   echo "== $L"
-  env LSF_LIB_PATH=$PWD/build/exp/liblsf_$L.so LSF_SLAB_USE_PERSIST=2 python3 profiles/micro/slab_bench.py ${N:-256} 64 2>&1 | grep -E "fast: (1 slab)"
+  LSF_LIB_PATH=$P python3 profiles/micro/slab_bench.py ${N:-256} 64 2>&1 | grep -E "fast: (single|1 slab|2 slab\(s\) fine=0)"
 done
