@@ -277,6 +277,7 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     double* out = a.buf[gb + 1 == a.nbuf ? 0 : gb + 1];
     // slabs: the planes [k_own_lo, k_own_lo + 3) also live in the lower neighbour's buffer, [k_own_hi - 3, k_own_hi) in the upper
     // one's (their addresses come from device memory: asked for here, used by the write back)
+    [[maybe_unused]] const int k_push_lo = PUSH ? 1 + a.tk_lo * NZT + 3 : 0, k_push_hi = PUSH ? min(1 + a.tk_hi * NZT, nz) - 3 : 0;
     [[maybe_unused]] double *nb_lo = nullptr, *nb_hi = nullptr;
     if constexpr (PUSH) {
         const int ob = gb + 1 == a.nbuf ? 0 : gb + 1;
@@ -345,8 +346,8 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     // request per 16 bytes instead of one per 8 (an 8-byte write-through store is a fabric write of its own), and the six
     // odd entries per bundle row no longer cost separate scattered requests.
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-    constexpr int AUX_SC1 = SC1 ? 16 : 0; // cache policy of the buffer instructions: sc1 = bit 4
-    const bool widex = !PUSH && (LSF_SKEW_WIDE == 2 || (LSF_SKEW_WIDE == 1 && BY == 16)) && deep && X0 - (NYT + NZT + 4) >= 0 && X0 + 22 <= nxi - 1 &&
+    constexpr int AUX_SC1 = SYS ? 17 : (SC1 ? 16 : 0); // cache policy of the buffer instructions: sc1 = bit 4, sc0 = bit 0 (system scope: both)
+    const bool widex = (LSF_SKEW_WIDE == 2 || (LSF_SKEW_WIDE == 1 && BY == 16)) && deep && X0 - (NYT + NZT + 4) >= 0 && X0 + 22 <= nxi - 1 &&
                        (double)(NZT + 7) * (double)sxy * 8.0 < 4.0e9;
     if (widex) {
         const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(in_t), 0, 0x7fffffff, 0x00020000);
@@ -666,10 +667,16 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
                 pk.z = (unsigned)__double2loint(hi), pk.w = (unsigned)__double2hiint(hi);
                 const unsigned el = (unsigned)(e.x >> 2) + (unsigned)(e.y + (si > 0 ? t : -t - 1));
                 __builtin_amdgcn_raw_buffer_store_b128(pk, r_out, 8u * el, 0, AUX_SC1);
+                if constexpr (PUSH) { // the copies for the neighbour slabs (the three planes next to a cut)
+                    const int cq = r / NYT, gk2 = k_lo + (sk > 0 ? cq : nk - 1 - cq);
+                    if (nb_lo && gk2 < k_push_lo)
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, __builtin_amdgcn_make_buffer_rsrc(nb_lo + org, 0, 0x7fffffff, 0x00020000), 8u * el, 0, AUX_SC1);
+                    if (nb_hi && gk2 >= k_push_hi)
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, __builtin_amdgcn_make_buffer_rsrc(nb_hi + org, 0, 0x7fffffff, 0x00020000), 8u * el, 0, AUX_SC1);
+                }
             }
         }
     } else {
-    [[maybe_unused]] const int k_push_lo = PUSH ? 1 + a.tk_lo * NZT + 3 : 0, k_push_hi = PUSH ? min(1 + a.tk_hi * NZT, nz) - 3 : 0;
     // Near the walls the old values of the wall points are needed (their change enters the RMS, subs.f90:902-914).  Taken one by
     // one inside the store loop, as this was written first, each cost a round trip past the caches, and -- the counter of
     // outstanding memory operations being one for loads and stores -- the wait for each also waited for the acknowledgement of
