@@ -1,5 +1,5 @@
 """randomised soak of the exact ordering: odd grids, 1-3 slabs on one device, tile shapes, both arithmetics, against lsf_reinit;
-and lsf_reinit (dataflow) against the slot launches.  python3 profiles/micro/slab_soak.py [cases=40] [seed=1]"""
+and lsf_reinit (dataflow) against the slot launches.  python3 profiles/micro/slab_soak.py [cases=40] [seed=1] [min points] [max points]"""
 import os, sys, random
 sys.path.insert(0, '.')
 import numpy as np
@@ -7,10 +7,11 @@ import levelsetfortran_amd as L
 from levelsetfortran_amd import fields
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+lo_n, hi_n = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (18, 110)  # points per axis
 shapes = [None, "1x1", "2x1", "4x1", "1x2", "4x2", "2x4", "c1x1", "c1x2", "c1x3", "c1x4"]
 bad = 0
 for case in range(n_cases):
-    npts = tuple(rng.randint(18, 110) for _ in range(3))
+    npts = tuple(rng.randint(lo_n, hi_n) for _ in range(3))
     arith = rng.choice(["fast", "strict"])
     shape = rng.choice(shapes)
     sweeps = rng.randint(1, 19)
