@@ -125,6 +125,20 @@ int gs_march()
     const char* e = getenv("LSF_GS_MARCH");
     return (e && (e[0] == 'x' || e[0] == 'X')) ? 0 : 1;
 }
+// dataflow launch: resident blocks that carry on down a tile column (k_reinit_gs_stream, default) or one block per tile
+// (k_reinit_gs_persist, LSF_GS_STREAM=0); LSF_GS_CONT=0 keeps the loop but never continues a column
+int gs_stream()
+{
+    const char* e = getenv("LSF_GS_STREAM");
+    return !(e && atoi(e) == 0);
+}
+// 0 = never; 1 = when the two cross upstream tiles of the next tile are claimed (the block then waits for them); 2 (default) = only
+// when they are done already (the block never waits while it holds a column)
+int gs_cont()
+{
+    const char* e = getenv("LSF_GS_CONT");
+    return e ? std::max(0, std::min(2, atoi(e))) : 2;
+}
 int gs_nbuf()
 {
     const char* e = getenv("LSF_GS_NBUF");
@@ -739,7 +753,8 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     // launches on the box tiles of lsf_boxtile.hpp (`slots`): 256^3 0.97 / 1.24 / 1.75 ms, 512^3 3.25 / 4.61 / 6.83 ms,
     // 1024^3 24.7 / 25.2 / 38.0 ms.
     if (sched < 0) sched = 5;
-    bool persist = sched == 5; // k_reinit_gs_persist
+    bool persist = sched == 5; // k_reinit_gs_stream / k_reinit_gs_persist
+    const bool stream = gs_stream();
     if (persist) sched = 3;
     // skewed tiles need TA = 16, NY = 5 and at least two interior cells per axis
     const bool skew = sched == 3 && ta == 16 && nyc == 5 && nx >= 3 && ny >= 3 && nz >= 3;
@@ -877,7 +892,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         // per-tile wait / work times of the dataflow launch: three contended atomics per tile (+70 % run time), so its own
         // switch and not part of LSF_TRACE, whose per-call times are meant to be read as measurements
         if (getenv("LSF_TRACE_TILES")) {
-            if ((rc = ws(c.slot[S_DBG], 64))) return rc;
+            if ((rc = ws(c.slot[S_DBG], 128))) return rc;
             d_dbg = (unsigned long long*)c.slot[S_DBG].p;
         }
         if (c.plans.size() > 64) { // bounded: every earlier call has synchronised its stream before returning
@@ -938,7 +953,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             if (!marked) prof_mark(st), marked = true; // the timed region starts once the first plan exists
             HIPCHK(hipMemsetAsync(d_cnt, 0, ((size_t)BATCH * np + 2 * DF_PAD + BATCH + 16) * sizeof(int), st)); // counters, ticket
             HIPCHK(hipMemsetAsync(c.slot[S_BFLAG].p, 0, (size_t)ns * nM * nTj * nTk * sizeof(int), st));
-            if (d_dbg) HIPCHK(hipMemsetAsync(d_dbg, 0, 64, st));
+            if (d_dbg) HIPCHK(hipMemsetAsync(d_dbg, 0, 128, st));
             hipLaunchKernelGGL(k_build_order, dim3(bp.nslots), dim3(256), 0, st, (uint2*)c.slot[S_ORDER].p, (const uint32_t*)tl->d,
                                m_poff, m_start, m_base, ns, np);
             fa.sweep_tab = m_tab, fa.plane_size = m_psize;
@@ -957,15 +972,29 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         if (strict) hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, BY_, true>), grid, dim3(64 * WY_ * WZ_), 0, st, fa); \
         else hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, BY_, false>), grid, dim3(64 * WY_ * WZ_), 0, st, fa);       \
     } while (0)
-            LSF_SK_SHAPES(LSF_LAUNCH_DF, wy, wz, by);
+            // Default: the launch with column continuation (k_reinit_gs_stream: resident blocks that loop over tiles and carry on
+            // down a tile column; lsf_stream.hip).  LSF_GS_STREAM=0: one block per tile, no continuation (k_reinit_gs_persist);
+            // LSF_GS_CONT=0: the loop without continuation (every tile acquired from the list).
+            if (stream) {
+                fa.cont_on = gs_cont();
+                int cus = 0;
+                HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device));
+                const hipError_t le = (hipError_t)launch_gs_stream(wy, wz, by, strict, st, fa, cus, nullptr);
+                if (le != hipSuccess) return fail(LSF_ERR_HIP, std::string("k_reinit_gs_stream: ") + hipGetErrorString(le));
+            } else {
+                LSF_SK_SHAPES(LSF_LAUNCH_DF, wy, wz, by);
+            }
 #undef LSF_LAUNCH_DF
             ++launches;
             if (g0 + BATCH < max_sweeps || d_dbg) { // stop flag between batches (later batches would exit at once anyway)
                 HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
                 if (d_dbg) {
-                    unsigned long long hd[8];
+                    unsigned long long hd[16];
                     HIPCHK(hipMemcpy(hd, d_dbg, sizeof hd, hipMemcpyDeviceToHost));
+                    if (stream)
+                        fprintf(stderr, "[lsf] column continuation: %llu of %llu tiles continued; not continued: end of column %llu, previous sweep not past %llu, "
+                                "cross tiles unclaimed %llu, claim lost %llu\n", hd[8], hd[2], hd[9], hd[10], hd[11], hd[12]);
 #ifdef LSF_EXPERIMENTS
                     if (hd[7])
                         fprintf(stderr, "[lsf] tile phases (us per tile): row table %.2f, load %.2f, march %.2f, write back %.2f\n",
@@ -1077,7 +1106,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         g_prof.bc_ms = g_prof.finish_ms = 0;
         g_prof.sweeps = nsw;
         g_prof.sweep_launches = launches;
-        g_prof.kernel = !slots_loop ? "k_reinit_gs_persist" : (skew ? "k_reinit_gs_skew" : "k_reinit_gs_box");
+        g_prof.kernel = !slots_loop ? (stream ? "k_reinit_gs_stream" : "k_reinit_gs_persist") : (skew ? "k_reinit_gs_skew" : "k_reinit_gs_box");
     }
     if (host_ctl[2] == 2) {
         // A block of the dataflow launch waited 4 s for a predecessor: never observed, but the launch relies on

@@ -377,7 +377,7 @@ __device__ __forceinline__ double block_sum(const double* __restrict__ partials,
     return red[0];
 }
 
-__global__ __launch_bounds__(RED_T) void k_finish(const double* __restrict__ partials, long nPart, double den,
+static __global__ __launch_bounds__(RED_T) void k_finish(const double* __restrict__ partials, long nPart, double den,
                                                   double tol, double* __restrict__ trace, int trace_cap,
                                                   int* __restrict__ ctl)
 {
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(RED_T) void k_finish(const double* __restrict__ par
 }
 
 // adds the fixed-order sum of the partials to *acc (building block for the decomposed path)
-__global__ __launch_bounds__(RED_T) void k_accumulate(const double* __restrict__ partials, long nPart,
+static __global__ __launch_bounds__(RED_T) void k_accumulate(const double* __restrict__ partials, long nPart,
                                                       double* __restrict__ accum)
 {
     __shared__ double red[RED_T];
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(RED_T) void k_accumulate(const double* __restrict__
 // =============================================================================================
 // narrowBand, subs.f90:178-207
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_narrowband(const double* __restrict__ phi, int32_t* __restrict__ nb,
+static __global__ __launch_bounds__(256) void k_narrowband(const double* __restrict__ phi, int32_t* __restrict__ nb,
                                                     int32_t* __restrict__ sb, long n, double dx)
 {
     const double tn = 4.1 * dx, ts = 8.1 * dx;
@@ -456,7 +456,7 @@ __device__ __forceinline__ bool in_band(const int32_t* nbmask, long g, double a,
 }
 
 // Jacobi ordering: pAve from A as well.
-__global__ __launch_bounds__(256) void k_minmax_jacobi(const double* __restrict__ A, double* __restrict__ Bout,
+static __global__ __launch_bounds__(256) void k_minmax_jacobi(const double* __restrict__ A, double* __restrict__ Bout,
                                                        const int32_t* __restrict__ nbmask, int nx, int ny,
                                                        int nz, double dx, double h1,
                                                        double* __restrict__ partials,
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void k_minmax_fp(const double* __restrict__ A,
 }
 
 // deterministic two-stage reduction of many partials: block b sums its contiguous slice
-__global__ __launch_bounds__(256) void k_reduce_slices(const double* __restrict__ in, long n, double* __restrict__ out)
+static __global__ __launch_bounds__(256) void k_reduce_slices(const double* __restrict__ in, long n, double* __restrict__ out)
 {
     __shared__ double red[256];
     const long per = (n + gridDim.x - 1) / gridDim.x;
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(64) void k_minmax_gs_plane(const double* __restrict
 // =============================================================================================
 constexpr int PHI0_CHUNK = 1024;
 
-__global__ __launch_bounds__(256) void k_phi0(double* __restrict__ phi, int nx, int ny, int im, int ip, int jm,
+static __global__ __launch_bounds__(256) void k_phi0(double* __restrict__ phi, int nx, int ny, int im, int ip, int jm,
                                               int jp, int km, int kp, double dx, double xlo0, double xlo1,
                                               double xlo2, const double* __restrict__ cen,
                                               const double* __restrict__ vtx, int nElem)
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256) void k_phi0(double* __restrict__ phi, int nx, 
     phi[i + (long)(nx + 1) * (j + (long)(ny + 1) * k)] = pS / __builtin_sqrt(pS * pS + dx * dx * gM); // subs.f90:169
 }
 
-__global__ __launch_bounds__(256) void k_fill(double* __restrict__ p, long n, double v)
+static __global__ __launch_bounds__(256) void k_fill(double* __restrict__ p, long n, double v)
 {
     for (long q = blockIdx.x * 256L + threadIdx.x; q < n; q += 256L * gridDim.x) p[q] = v;
 }
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void k_fill(double* __restrict__ p, long n, do
 // nodes after every single move (O(iter n^2)); a node's value depends on its own position only.
 // Contraction off, IEEE division / sqrt: bit-identical.
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_firstderiv8(const double* __restrict__ phi, const int32_t* __restrict__ sb,
+static __global__ __launch_bounds__(256) void k_firstderiv8(const double* __restrict__ phi, const int32_t* __restrict__ sb,
                                                      double* __restrict__ grad, int nx, int ny, int nz, double dx)
 {
 #pragma clang fp contract(off)
@@ -897,7 +897,7 @@ __device__ __forceinline__ double interp_node(const double* __restrict__ phi, co
     return out[0];
 }
 
-__global__ __launch_bounds__(64) void k_advect_nodes(const double* __restrict__ phi, const double* __restrict__ grad,
+static __global__ __launch_bounds__(64) void k_advect_nodes(const double* __restrict__ phi, const double* __restrict__ grad,
                                                      int nx, int ny, int nz, double dx, double lo0, double lo1,
                                                      double lo2, double* __restrict__ nodes, int nnode, int iters)
 {

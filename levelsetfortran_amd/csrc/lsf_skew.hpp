@@ -50,6 +50,16 @@
                            // ms, STRICT 512^3 equal -- once its refill was taken out from behind a run-time branch, see the march)
 #endif
 
+// k_reinit_gs_stream: the blocks of a CU live as long as the launch, and between wavefronts of equal priority the OLDER one
+// is served first -- one block of every CU would win every contest for the vector unit, the other would always lose.  With
+// this switch a wavefront raises its priority as its march proceeds (0..3) and drops it with the tile: the tile that is further
+// along wins, which is what the one-block-per-tile launch does by itself (its blocks age).
+#ifndef LSF_STREAM_PRIO
+#define LSF_STREAM_PRIO 1
+#endif
+#ifndef LSF_PERSIST_PRIO
+#define LSF_PERSIST_PRIO 0 // k_reinit_gs_persist: priority by the age of the tile's sweep (sk_sweep_prio): measured SLOWER (2.57 -> 2.71 ms, STRICT 4.48 -> 5.11 at 512^3)
+#endif
 #ifndef LSF_POLL_SLEEP
 #define LSF_POLL_SLEEP 16 // 64-cycle units between two looks of a waiting tile at its flags
 #endif
@@ -207,6 +217,35 @@ __device__ __forceinline__ SkPre sk_prefetch(const GsArgs& a, int tid = threadId
     return p;
 }
 
+// (LSF_STREAM_PRIO) priority of a wavefront at step u of its march
+__device__ __forceinline__ void sk_march_prio(int u)
+{
+    if (u == 0) __builtin_amdgcn_s_setprio(0);
+    else if (u == 4) __builtin_amdgcn_s_setprio(1);
+    else if (u == 8) __builtin_amdgcn_s_setprio(2);
+    else if (u == 12) __builtin_amdgcn_s_setprio(3);
+}
+
+// Priority by the age of the tile's sweep: the sweeps of a batch follow each other at the spacing their raster flips dictate, so
+// the time per sweep is (spacing in hyperplanes) x (time the OLDEST sweep in flight needs per hyperplane) whenever the chip is not
+// saturated -- the tiles of that sweep are the critical path, everything behind them fills gaps.  lag = sweeps between this
+// tile's sweep and the oldest unfinished one.
+__device__ __forceinline__ void sk_sweep_prio(int lag)
+{
+    if (lag <= 0) __builtin_amdgcn_s_setprio(3);
+    else if (lag == 1) __builtin_amdgcn_s_setprio(2);
+    else if (lag == 2) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
+// LDS of one tile: declared by the kernel (a kernel that runs several tiles one after the other, or two tile functions, has one)
+template <class T>
+struct SkShared {
+    double lds[T::TOTAL];
+    int2 rowtab[T::NR];
+    double wsum[T::W];
+};
+
 // One tile.  SC1 = false: every value this tile reads was written by an earlier launch (slot schedule).
 // SC1 = true: producers may have run in this launch on another XCD (persistent schedule): results are stored
 // write-through and drained before the caller publishes the tile, phi is loaded past the non-coherent caches
@@ -224,16 +263,17 @@ __device__ __forceinline__ SkPre sk_prefetch(const GsArgs& a, int tid = threadId
 // each with field buffers of its own.  Results within three planes of a cut are stored into the neighbour's buffer as well
 // (same address map), the column's running RMS sum into the colsum of the slab that runs this sweep's epilogue, and the
 // epilogue's verdict into every slab's control words; all of that and every load at system scope.
-template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, bool PUSH = false, class WaitUp>
-__device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int g, int si, int sj, int sk, const SkPre& pre,
-                                          WaitUp&& wait_upstream)
+template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, bool PUSH = false, bool STREAM = false, class WaitUp>
+__device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, const GsArgs& a, uint32_t packed, int g, int si, int sj,
+                                          int sk, const SkPre& pre, WaitUp&& wait_upstream, int cont_ = 0)
 {
     static_assert(TA == 16, "row-per-16-lanes loader");
+    const int cont = STREAM ? cont_ : 0; // continued column (k_reinit_gs_stream only)
     using T = SkTile<TA, WY, WZ, BY>;
     constexpr int NYT = T::NYT, NZT = T::NZT, W = T::W, NT = 64 * W;
-    __shared__ double lds[T::TOTAL];
-    __shared__ int2 rowtab[T::NR];
-    __shared__ double wsum[W];
+    double* const lds = sm.lds;
+    int2* const rowtab = sm.rowtab;
+    double* const wsum = sm.wsum;
     int tid_ = threadIdx.x;
     // called from a loop over tiles (k_reinit_gs_slab): what depends on the thread index only would be computed in front of the
     // loop and kept in vector registers across it (measured: 60 of them spilled to scratch) -- make it a value of this call
@@ -299,7 +339,26 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     // deep tile: full, and every row of its LDS image (3 halo rows on each side included) is an interior row
     const bool deep = a.tables && nj == NYT && nk == NZT && j_lo >= 4 && j_lo + NYT + 2 <= ny - 1 && k_lo >= 4 && k_lo + NZT + 2 <= nz - 1;
     const int dir = (sj > 0 ? 2 : 0) + (sk > 0 ? 1 : 0);
-    for (int r = tid; r < T::NR; r += NT) {
+    // Continued column (cont != 0, k_reinit_gs_stream): the LDS image still holds tile m - 1 of this column, marched and written
+    // back by this block.  Entries 16..21 of its bundle rows are entries 0..5 of this tile's (0..2 this sweep's values, computed
+    // here; 3..5 old ones), 16, 17 of its upstream and 20, 21 of its downstream halo rows are entries 0, 1 resp. 4, 5: they move
+    // inside LDS, the rows' table entries advance by one tile length, and the loader fetches 16 instead of 22 (18) entries per row.
+    constexpr int NSHC = (6 * T::NCORE + NT - 1) / NT, NSHH = (2 * (T::NR - T::NCORE) + NT - 1) / NT;
+    double shc[NSHC], shh[NSHH];
+    if (cont) {
+        for (int r = tid; r < T::NR; r += NT) rowtab[r].y += si > 0 ? TA : -TA;
+#pragma unroll
+        for (int u = 0; u < NSHC; ++u) {
+            const int idx = min(tid + NT * u, 6 * T::NCORE - 1), r = idx / 6, k = idx - 6 * r;
+            shc[u] = lds[T::core_at(r) + TA + k];
+        }
+#pragma unroll
+        for (int u = 0; u < NSHH; ++u) {
+            const int idx = min(tid + NT * u, 2 * (T::NR - T::NCORE) - 1), r = T::NCORE + (idx >> 1), k = idx & 1;
+            shh[u] = lds[T::at(r, (r < T::YD0 ? TA : TA + 4) + k)];
+        }
+    }
+    for (int r = tid; r < T::NR && !cont; r += NT) {
         if (deep) {
             const uint32_t w = r == tid ? (dir == 0 ? pre.rel.x : (dir == 1 ? pre.rel.y : (dir == 2 ? pre.rel.z : pre.rel.w)))
                                         : a.tables[4 * r + dir];
@@ -316,6 +375,18 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
         rowtab[r] = make_int2(o * 4 + (rin & up) + 2 * (rin & (up | core)), si > 0 ? gi0 - (bq + cq) : gi0 + (bq + cq));
     }
     __syncthreads();
+    if (cont) {
+#pragma unroll
+        for (int u = 0; u < NSHC; ++u) {
+            const int idx = min(tid + NT * u, 6 * T::NCORE - 1), r = idx / 6, k = idx - 6 * r;
+            lds[T::core_at(r) + k] = shc[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NSHH; ++u) {
+            const int idx = min(tid + NT * u, 2 * (T::NR - T::NCORE) - 1), r = T::NCORE + (idx >> 1), k = idx & 1;
+            lds[T::at(r, (r < T::YD0 ? 0 : 4) + k)] = shh[u];
+        }
+    }
     LSF_PHASE(1);
 
     // ---- load: all global loads in flight before the first LDS write ------------------------------------
@@ -348,17 +419,20 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));
     constexpr int AUX_SC1 = SYS ? 17 : (SC1 ? 16 : 0); // cache policy of the buffer instructions: sc1 = bit 4, sc0 = bit 0 (system scope: both)
     const bool widex = (LSF_SKEW_WIDE == 2 || (LSF_SKEW_WIDE == 1 && BY == 16)) && deep && X0 - (NYT + NZT + 4) >= 0 && X0 + 22 <= nxi - 1 &&
-                       (double)(NZT + 7) * (double)sxy * 8.0 < 4.0e9;
-    if (widex) {
+                       (double)(NZT + 7) * (double)sxy * 8.0 <= (double)(0x7fffffff - 16); // the image lies inside the buffer descriptor (num_records below)
+    // both loaders come in two instances: CT = false loads the whole image, CT = true what a continued column still needs
+    bool loaded = true;
+    auto load_wide = [&](auto ct_tag) {
+        constexpr bool CT = decltype(ct_tag)::value;
         const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(in_t), 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out_t, 0, 0x7fffffff, 0x00020000);
         constexpr int RPI = 4 * W;
         constexpr int NB = T::NCORE / RPI, NU = (T::YD0 - T::YU0 + RPI - 1) / RPI, ND = (T::NR - T::YD0 + RPI - 1) / RPI;
-        constexpr int XC = 3 * T::NCORE, NXC = (XC + NT - 1) / NT;
+        constexpr int XC = 3 * T::NCORE, NXC = CT ? 0 : (XC + NT - 1) / NT;
         u4_t w[NB + ND + NU];
         int dw[NB + ND + NU];
-        double v3[NXC];
-        int d3[NXC];
+        double v3[NXC + 1];
+        int d3[NXC + 1];
         const int xx = tid & 15, rsub = tid >> 4;
         int n_ = 0;
         // entries k, k + 1 of a row: one 16-byte load at the lower of their two addresses
@@ -366,27 +440,32 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
             const unsigned el = (unsigned)(e.x >> 2) + (unsigned)(e.y + (si > 0 ? k - 3 : 2 - k));
             return __builtin_amdgcn_raw_buffer_load_b128(rs, 8u * el, 0, AUX_SC1);
         };
-        // ---- stage 1: what the previous sweep left (bundle rows entries 3 .. 21 (+ 22, dropped), downstream halo 4 .. 21)
+        // ---- stage 1: what the previous sweep left (bundle rows entries 3 .. 21 (+ 22, dropped), downstream halo 4 .. 21;
+        //      continued: 6 .. 21 of both)
 #pragma unroll
         for (int u = 0; u < NB; ++u, ++n_) {
-            const int r = RPI * u + rsub, k = 3 + 2 * min(xx, 9);
+            const int r = RPI * u + rsub, k = CT ? 6 + 2 * min(xx, 7) : 3 + 2 * min(xx, 9);
             dw[n_] = T::core_at(r) + k;
             w[n_] = pair_at(r_in, rowtab[r], k);
         }
 #pragma unroll
         for (int u = 0; u < ND; ++u, ++n_) {
-            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = 4 + 2 * min(xx, 8);
+            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = CT ? 6 + 2 * min(xx, 7) : 4 + 2 * min(xx, 8);
             dw[n_] = T::HB + (r - T::NCORE) * T::RH + k - 4;
             w[n_] = pair_at(r_in, rowtab[r], k);
         }
 #pragma unroll
         for (int t = 0; t < NPS; ++t) ps[t] = ps_load(t);
-        if (!wait_upstream()) return false;
+        if (!wait_upstream()) {
+            loaded = false;
+            return;
+        }
         if (tid == 0 && m != (NYT * fB + NZT * fC) / TA) colsum_prev = ldp(a.colsum + (long)gb * ncol + (tj + (long)a.nTj * tk));
-        // ---- stage 2: what the upstream tiles of this sweep wrote (upstream halo 0 .. 17, bundle rows entries 0 .. 2)
+        // ---- stage 2: what the upstream tiles of this sweep wrote (upstream halo 0 .. 17, bundle rows entries 0 .. 2;
+        //      continued: upstream halo 2 .. 17)
 #pragma unroll
         for (int u = 0; u < NU; ++u, ++n_) {
-            const int r = min(T::YU0 + RPI * u + rsub, T::YD0 - 1), k = 2 * min(xx, 8);
+            const int r = min(T::YU0 + RPI * u + rsub, T::YD0 - 1), k = CT ? 2 + 2 * min(xx, 7) : 2 * min(xx, 8);
             dw[n_] = T::HB + (r - T::NCORE) * T::RH + k;
             w[n_] = pair_at(r_out, rowtab[r], k);
         }
@@ -401,25 +480,27 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
 #pragma unroll
         for (int u = 0; u < NB + ND + NU; ++u) {
             const double lo = __hiloint2double((int)w[u].y, (int)w[u].x), hi = __hiloint2double((int)w[u].w, (int)w[u].z);
-            lds[dw[u]] = si > 0 ? lo : hi;                              // entry k
-            if (u >= NB || xx < 9) lds[dw[u] + 1] = si > 0 ? hi : lo;   // entry k + 1 (a bundle row has no entry 22)
+            lds[dw[u]] = si > 0 ? lo : hi;                                    // entry k
+            if (CT || u >= NB || xx < 9) lds[dw[u] + 1] = si > 0 ? hi : lo;   // entry k + 1 (a bundle row has no entry 22)
         }
 #pragma unroll
         for (int u = 0; u < NXC; ++u) lds[d3[u]] = v3[u];
-    } else {
+    };
+    auto load_rows = [&](auto ct_tag) {
+        constexpr bool CT = decltype(ct_tag)::value;
         // 16 entries of one row per 16 lanes, 4 W rows per load instruction.  Rows are taken CLASS BY CLASS (bundle /
         // upstream halo / downstream halo) so that everything that depends on the class -- first entry, where the row
         // lives in the LDS image, whether a value of this sweep has to be fetched from `out` -- is a compile-time
         // property of the instruction (the class boundaries are not multiples of 4 W rows: the last instruction of a
         // class re-loads its last row in the lanes that would overshoot, which rewrites the same LDS value).
         constexpr int RPI = 4 * W;                                        // rows per load instruction
-        constexpr int NB = T::NCORE / RPI;                                // bundle rows: entries 3..18, old values
+        constexpr int NB = T::NCORE / RPI;                                // bundle rows: entries 3..18 (continued: 6..21), old values
         constexpr int NU = (T::YD0 - T::YU0 + RPI - 1) / RPI;             // upstream halo: 2..17, this sweep's inside the interior
-        constexpr int ND = (T::NR - T::YD0 + RPI - 1) / RPI;              // downstream halo: 4..19, old values
-        // the remaining entries: 0..2 (this sweep's) and 19..21 (old) of the bundle rows, 0..1 of the upstream and 20..21 of
-        // the downstream halo rows
+        constexpr int ND = (T::NR - T::YD0 + RPI - 1) / RPI;              // downstream halo: 4..19 (continued: 6..21), old values
+        // the remaining entries (none in a continued column): 0..2 (this sweep's) and 19..21 (old) of the bundle rows, 0..1 of
+        // the upstream and 20..21 of the downstream halo rows
         constexpr int XC = 3 * T::NCORE, XHU = 2 * (T::YD0 - T::NCORE), XHD = 2 * (T::NR - T::YD0);
-        constexpr int NXC = (XC + NT - 1) / NT, NXHU = (XHU + NT - 1) / NT, NXHD = (XHD + NT - 1) / NT;
+        constexpr int NXC = CT ? 0 : (XC + NT - 1) / NT, NXHU = CT ? 0 : (XHU + NT - 1) / NT, NXHD = CT ? 0 : (XHD + NT - 1) / NT;
         constexpr int NV = NB + NU + ND + 2 * NXC + NXHU + NXHD;
         double v[NV];
         int dst[NV];
@@ -430,14 +511,14 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
         // ---- stage 1: what the previous sweep left
 #pragma unroll
         for (int u = 0; u < NB; ++u, ++n_) {
-            const int r = RPI * u + rsub, k = 3 + xx;
+            const int r = RPI * u + rsub, k = (CT ? 6 : 3) + xx;
             const int2 e = rowtab[r];
             dst[n_] = T::core_at(r) + k;
             v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
         }
 #pragma unroll
         for (int u = 0; u < ND; ++u, ++n_) {
-            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = 4 + xx;
+            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = (CT ? 6 : 4) + xx;
             const int2 e = rowtab[r];
             dst[n_] = T::HB + (r - T::NCORE) * T::RH + k - 4;
             v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
@@ -460,7 +541,10 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
         }
 #pragma unroll
         for (int t = 0; t < NPS; ++t) ps[t] = ps_load(t);
-        if (!wait_upstream()) return false;
+        if (!wait_upstream()) {
+            loaded = false;
+            return;
+        }
         // the running RMS sum of this tile column, left by the previous tile of the column (one of the upstream tiles):
         // requested now, used by thread 0 after the march (the dependent load used to sit between the tile's stores and its flag)
         if (tid == 0 && m != (NYT * fB + NZT * fC) / TA) colsum_prev = ldp(a.colsum + (long)gb * ncol + (tj + (long)a.nTj * tk));
@@ -496,7 +580,20 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
         }
 #pragma unroll
         for (int u = 0; u < NV; ++u) lds[dst[u]] = v[u]; // duplicates (clamped indices) rewrite the same value
+    };
+    if constexpr (STREAM) {
+        if (widex) {
+            if (cont) load_wide(std::true_type{});
+            else load_wide(std::false_type{});
+        } else {
+            if (cont) load_rows(std::true_type{});
+            else load_rows(std::false_type{});
+        }
+    } else {
+        if (widex) load_wide(std::false_type{});
+        else load_rows(std::false_type{});
     }
+    if (!loaded) return false;
     __syncthreads();
     LSF_PHASE(2);
 
@@ -546,6 +643,8 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
 #pragma unroll
             for (int u_ = 0; u_ < SU; ++u_) {
                 const int t = t0 + u_;
+                if constexpr (STREAM && LSF_STREAM_PRIO == 1)
+                    sk_march_prio(u_);
                 const bool active = ALLW ? x_lane : (bool)((act_bits >> t) & 1u) && axis == 0;
                 double q[7];
 #pragma unroll
@@ -617,6 +716,8 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
                 const int t = t0 + u;
                 const bool active = (act_bits >> t) & 1u;
                 const bool weno_ok = (weno_bits >> t) & 1u;
+                if constexpr (STREAM && LSF_STREAM_PRIO == 1) // the tile that is further along wins the vector unit (see stream_tile)
+                    sk_march_prio(u);
                 double qx[7], qy[7], qz[7];
 #pragma unroll
                 for (int mm = 0; mm < 7; ++mm) qx[mm] = lds[ox[mm] + t];
@@ -846,7 +947,7 @@ __device__ __forceinline__ bool skew_tile(const GsArgs& a, uint32_t packed, int 
 // only n / TA time slots of spacing between two sweeps whereas a flip of a cross-section axis costs n / TA + its number of
 // tiles; the kernel marches along its unit-stride axis, so the library runs it on the transposed field (reinit_slot_core).
 // dst2 (optional): a second copy of the result (phiS = phi on entry, subs.f90:731: one read of phi serves both).
-__global__ __launch_bounds__(256) void k_transpose_xy(const double* __restrict__ src, double* __restrict__ dst, int ex, int ey,
+static __global__ __launch_bounds__(256) void k_transpose_xy(const double* __restrict__ src, double* __restrict__ dst, int ex, int ey,
                                                       long planes, double* __restrict__ dst2)
 {
     __shared__ double t[32][33];
@@ -880,7 +981,7 @@ __global__ __launch_bounds__(256) void k_transpose_xy(const double* __restrict__
 // per time slot; slot_base[slot] = index of the slot's first entry; the slot holds hyperplane P = slot - start[q] of
 // every sweep q of the batch with 0 <= P < np, in increasing q (exactly what the slot schedule launches, launch after
 // launch).
-__global__ __launch_bounds__(256) void k_build_order(uint2* __restrict__ order, const uint32_t* __restrict__ tiles,
+static __global__ __launch_bounds__(256) void k_build_order(uint2* __restrict__ order, const uint32_t* __restrict__ tiles,
                                                      const int* __restrict__ plane_off, const int* __restrict__ start,
                                                      const unsigned* __restrict__ slot_base, int ns, int np)
 {
@@ -906,7 +1007,8 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
     const uint32_t packed = a.seg_tiles[seg][bx - (seg ? a.seg_end[seg - 1] : 0)];
     if (ld_flag(a.ctl + 0) != 0) return; // converged or failed in an earlier launch
     const SkPre pre = sk_prefetch<TA, WY, WZ, BY>(a);
-    skew_tile<TA, WY, WZ, BY, STRICT, false>(a, packed, a.seg_g[seg], a.seg_sign[seg][0], a.seg_sign[seg][1], a.seg_sign[seg][2], pre,
+    __shared__ SkShared<SkTile<TA, WY, WZ, BY>> sm;
+    skew_tile<TA, WY, WZ, BY, STRICT, false>(sm, a, packed, a.seg_g[seg], a.seg_sign[seg][0], a.seg_sign[seg][1], a.seg_sign[seg][2], pre,
                                              [] { return true; }); // every predecessor ran in an earlier launch
 }
 
@@ -924,6 +1026,7 @@ template <int TA, int WY, int WZ, int BY, bool STRICT>
 __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_persist(GsArgs a)
 {
     using T = SkTile<TA, WY, WZ, BY>;
+    __shared__ SkShared<T> sm;
     __shared__ int sh_task[8]; // packed tile, s | P << DF_SWEEP_BITS, go flag, raster signs of the sweep, go flag of stage 2
     const int tid = threadIdx.x;
     const int np = a.np;
@@ -995,6 +1098,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                     __builtin_amdgcn_s_sleep(LSF_POLL_SLEEP); // ~0.5 us between looks; 8..64 measured within 2 % of each other
                 }
                 sh_task[3] = swp.x, sh_task[4] = swp.y, sh_task[5] = swp.z;
+                sh_task[7] = a.g0 + s - ld_flag(a.ctl + 1); // sweeps between this tile's and the oldest unfinished one
             }
             sh_task[0] = (int)e.x, sh_task[1] = (int)e.y, sh_task[2] = go;
         }
@@ -1004,6 +1108,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
         const uint32_t packed = (uint32_t)uni(sh_task[0]);
         const int sP = uni(sh_task[1]);
         int go = uni(sh_task[2]);
+        if (LSF_PERSIST_PRIO && go) sk_sweep_prio(uni(sh_task[7]));
         const int s = sP & (DF_BATCH - 1), P = (int)((unsigned)sP >> DF_SWEEP_BITS);
         if (go == 0) return;
         const unsigned long long tsB = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1037,7 +1142,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
             return uni(sh_task[6]) == 1;
         };
         if (go == 1) {
-            if (!skew_tile<TA, WY, WZ, BY, STRICT, true>(a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream))
+            if (!skew_tile<TA, WY, WZ, BY, STRICT, true>(sm, a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream))
                 go = 2;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1073,6 +1178,9 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
     }
 }
 
+// host side (lsf_stream.hip): launches the instance of the tile shape with as many blocks as the device keeps resident
+int launch_gs_stream(int wy, int wz, int by, bool strict, hipStream_t st, const GsArgs& fa, int cus, int* blocks_out);
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Exact ordering across z slabs: the dataflow schedule above, one launch PER SLAB (one device each; several on one device
 // for the rehearsal), all working on the same tile graph.  A slab owns the tile columns tk_lo <= tk < tk_hi; its task list
@@ -1089,7 +1197,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
 // Every cross-slab word and value is stored and loaded at system scope (write-through to the fabric, loads past the caches);
 // stores are drained (s_waitcnt vmcnt(0)) before the flag that announces them is raised.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_build_order_slab(uint2* __restrict__ order, const uint32_t* __restrict__ tiles_pos,
+static __global__ __launch_bounds__(256) void k_build_order_slab(uint2* __restrict__ order, const uint32_t* __restrict__ tiles_pos,
                                                           const uint32_t* __restrict__ tiles_neg, const int* __restrict__ off_pos,
                                                           const int* __restrict__ off_neg, const int* __restrict__ sweep_tab,
                                                           const int* __restrict__ start, const unsigned* __restrict__ slot_base, int ns, int np)
@@ -1125,6 +1233,7 @@ template <int TA, int WY, int WZ, int BY, bool STRICT, bool LOOP>
 __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? (LOOP ? LSF_SLAB_WAVES : 5) : 1)))) void k_reinit_gs_slab(GsArgs args_)
 {
     using T = SkTile<TA, WY, WZ, BY>;
+    __shared__ SkShared<T> sm;
     __shared__ int sh_task[8]; // as in k_reinit_gs_persist
     __shared__ unsigned long long sh_wait[4]; // thread 0's upstream flags and start time: parked here while the tile loads (registers)
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
@@ -1232,7 +1341,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
             return uni(sh_task[6]) == 1;
         };
         if (go == 1) {
-            if (!skew_tile<TA, WY, WZ, BY, STRICT, true, true>(a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), sk, pre, wait_upstream))
+            if (!skew_tile<TA, WY, WZ, BY, STRICT, true, true>(sm, a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), sk, pre, wait_upstream))
                 go = 2;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
