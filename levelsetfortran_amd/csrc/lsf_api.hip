@@ -125,12 +125,12 @@ int gs_march()
     const char* e = getenv("LSF_GS_MARCH");
     return (e && (e[0] == 'x' || e[0] == 'X')) ? 0 : 1;
 }
-// dataflow launch: resident blocks that carry on down a tile column (k_reinit_gs_stream, default) or one block per tile
-// (k_reinit_gs_persist, LSF_GS_STREAM=0); LSF_GS_CONT=0 keeps the loop but never continues a column
+// dataflow launch: one block per tile (k_reinit_gs_persist, default) or resident blocks that carry on down a tile column
+// (k_reinit_gs_stream, LSF_GS_STREAM=1); LSF_GS_CONT selects when such a block continues
 int gs_stream()
 {
     const char* e = getenv("LSF_GS_STREAM");
-    return !(e && atoi(e) == 0);
+    return e && atoi(e) != 0; // opt-in: measured slower than the one-block-per-tile launch
 }
 // 0 = never; 1 = when the two cross upstream tiles of the next tile are claimed (the block then waits for them); 2 (default) = only
 // when they are done already (the block never waits while it holds a column)
@@ -972,9 +972,9 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         if (strict) hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, BY_, true>), grid, dim3(64 * WY_ * WZ_), 0, st, fa); \
         else hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, BY_, false>), grid, dim3(64 * WY_ * WZ_), 0, st, fa);       \
     } while (0)
-            // Default: the launch with column continuation (k_reinit_gs_stream: resident blocks that loop over tiles and carry on
-            // down a tile column; lsf_stream.hip).  LSF_GS_STREAM=0: one block per tile, no continuation (k_reinit_gs_persist);
-            // LSF_GS_CONT=0: the loop without continuation (every tile acquired from the list).
+            // Default: one block per tile (k_reinit_gs_persist).  LSF_GS_STREAM=1: the launch with column continuation
+            // (k_reinit_gs_stream: resident blocks that loop over tiles and carry on down a tile column; lsf_stream.hip);
+            // LSF_GS_CONT=0: that loop without continuation (every tile acquired from the list).
             if (stream) {
                 fa.cont_on = gs_cont();
                 int cus = 0;

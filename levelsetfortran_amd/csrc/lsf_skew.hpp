@@ -427,7 +427,8 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(in_t), 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out_t, 0, 0x7fffffff, 0x00020000);
         constexpr int RPI = 4 * W;
-        constexpr int NB = T::NCORE / RPI, NU = (T::YD0 - T::YU0 + RPI - 1) / RPI, ND = (T::NR - T::YD0 + RPI - 1) / RPI;
+        // (continued: the 16 entries a bundle row still needs are 8 requests: 8 lanes per row, 8 W rows per instruction)
+        constexpr int NB = CT ? T::NCORE / (2 * RPI) : T::NCORE / RPI, NU = (T::YD0 - T::YU0 + RPI - 1) / RPI, ND = (T::NR - T::YD0 + RPI - 1) / RPI;
         constexpr int XC = 3 * T::NCORE, NXC = CT ? 0 : (XC + NT - 1) / NT;
         u4_t w[NB + ND + NU];
         int dw[NB + ND + NU];
@@ -444,7 +445,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         //      continued: 6 .. 21 of both)
 #pragma unroll
         for (int u = 0; u < NB; ++u, ++n_) {
-            const int r = RPI * u + rsub, k = CT ? 6 + 2 * min(xx, 7) : 3 + 2 * min(xx, 9);
+            const int r = CT ? 2 * RPI * u + (tid >> 3) : RPI * u + rsub, k = CT ? 6 + 2 * (tid & 7) : 3 + 2 * min(xx, 9);
             dw[n_] = T::core_at(r) + k;
             w[n_] = pair_at(r_in, rowtab[r], k);
         }

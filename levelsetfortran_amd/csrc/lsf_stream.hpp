@@ -31,12 +31,15 @@ namespace lsf {
 // list waits for nothing: its holder finishes it (a block holds at most the tile it runs).  Every spin is bounded as before.
 // The RMS sums, the hyperplane counters, the stop verdict and the epilogue are those of k_reinit_gs_persist: same bits.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef LSF_STREAM_FINE
+#define LSF_STREAM_FINE 1 // a block that runs down a column asks the tiles of the previous sweep themselves (stream_prev_sweep_past)
+#endif
 #ifndef LSF_STREAM_WAVES
-#define LSF_STREAM_WAVES 4 // three lanes per cell, 2 x 2 wavefronts: tiles per CU
+#define LSF_STREAM_WAVES 5 // three lanes per cell, 2 x 2 wavefronts: tiles per CU (94 registers + 104 bytes of scratch; 4: 120 registers)
 #endif
 // LDS of the launch, at namespace scope: the tile runs in a function of its own (below), which shares it with the kernel
 struct StreamCtl {
-    int task[12];               // packed tile, s | P << DF_SWEEP_BITS, go flag, raster signs, go flag of stage 2, continue flag, spacing
+    int task[12];               // packed tile, s | P << DF_SWEEP_BITS, go flag, raster signs (3), go flag of stage 2, continue flag, spacing
     unsigned long long wait[6]; // thread 0's upstream flags and start time, time stamps of LSF_TRACE_TILES
 };
 template <class T>
@@ -44,12 +47,48 @@ __shared__ SkShared<T> g_stream_sm;
 template <class T>
 __shared__ StreamCtl g_stream_ctl;
 
+// Has sweep s - 1 left the neighbourhood of tile (m, fB, fC) of sweep s for good?  The launch's condition (b) asks the count of
+// leading complete hyperplanes of that sweep -- right for the order of the list, but far more than a tile needs once a block
+// runs ahead of the list down a column: after a flip of the march axis the previous sweep passed the column's far tiles long
+// before its hyperplane count says so.  Exact form: every tile of sweep s - 1 that holds a cell of this tile's LDS image must be
+// done.  The image is five boxes in the frame (bundle rows, four halo groups), each inside one tile column; the skew coordinate
+// of sweep s - 1 is linear in the frame coordinates (b, c, entry k), so its maximum over a box is at a corner, and in a column
+// the tiles of a sweep finish in the order of their m: one flag per box.  Only for tiles whose image holds interior cells only
+// (deep, wide path).  Thread 0 only.
+template <class T, int TA>
+__device__ __forceinline__ bool stream_prev_sweep_past(const GsArgs& a, int s, int m, int fB, int fC, long per_sweep)
+{
+    if (s == 0) return true; // the sweeps of earlier launches are complete
+    const int4 cur = *(const int4*)(a.sweep_tab + 4 * s), prv = *(const int4*)(a.sweep_tab + 4 * (s - 1));
+    const int X0 = TA * m - T::NYT * fB - T::NZT * fC;
+    // frame coordinates of a cell of the image: Fx = X0 - b - c + k - 3, Fy = NYT fB + b, Fz = NZT fC + c;  in the frame of the
+    // previous sweep an axis whose direction flipped counts from the other wall: F' = (n - 2) - F
+    const int ex = cur.x == prv.x ? 1 : -1, ey = cur.y == prv.y ? 1 : -1, ez = cur.z == prv.z ? 1 : -1;
+    const int c0 = (ex > 0 ? X0 - 3 : a.nx - 2 - X0 + 3) + (ey > 0 ? T::NYT * fB : a.ny - 2 - T::NYT * fB) + (ez > 0 ? T::NZT * fC : a.nz - 2 - T::NZT * fC);
+    const int cb = -ex + ey, cc = -ex + ez, ck = ex; // d S' / d b, d c, d k
+    const int tj = cur.y > 0 ? fB : a.nTj - 1 - fB, tk = cur.z > 0 ? fC : a.nTk - 1 - fC;
+    const int dj = cur.y > 0 ? 1 : -1, dk = cur.z > 0 ? 1 : -1; // absolute column step of one frame column
+    auto box_done = [&](int b0, int b1, int c0_, int c1, int k0, int k1, int tj2, int tk2) {
+        const int smax = c0 + (cb > 0 ? cb * b1 : cb * b0) + (cc > 0 ? cc * c1 : cc * c0_) + (ck > 0 ? ck * k1 : ck * k0);
+        const int mp = smax / TA; // smax >= 0: the cells are interior cells
+        const int fBp = prv.y > 0 ? tj2 : a.nTj - 1 - tj2, fCp = prv.z > 0 ? tk2 : a.nTk - 1 - tk2;
+        return ld_flag(a.tile_done + (s - 1) * per_sweep + mp + (long)a.nM * (fBp + (long)a.nTj * fCp));
+    };
+    const int v0 = box_done(0, T::NYT - 1, 0, T::NZT - 1, 0, T::RA - 1, tj, tk);
+    const int v1 = box_done(-3, -1, 0, T::NZT - 1, 0, T::RH - 1, tj - dj, tk);
+    const int v2 = box_done(T::NYT, T::NYT + 2, 0, T::NZT - 1, 4, T::RA - 1, tj + dj, tk);
+    const int v3 = box_done(0, T::NYT - 1, -3, -1, 0, T::RH - 1, tj, tk - dk);
+    const int v4 = box_done(0, T::NYT - 1, T::NZT, T::NZT + 2, 4, T::RA - 1, tj, tk + dk);
+    return (v0 >= 2) & (v1 >= 2) & (v2 >= 2) & (v3 >= 2) & (v4 >= 2);
+}
+
 // One tile of the launch: waits, the tile itself (skew_tile), its flag, and the decision about the next tile of the column.
 // NOT inlined: as the body of the kernel's loop over tiles the compiler moved everything that depends only on the kernel's
 // arguments or the thread index in front of the loop and kept it in registers across the tile (230 vector registers, scalar
-// registers spilled to vector lanes, 25 % more time per tile than k_reinit_gs_persist); as a function it is compiled like the
-// single tile of that kernel.  Returns 0 (stop, NaN, time-out: leave), 1 (done: acquire the next tile from the list) or 2 (done,
-// and task[0], task[1] hold the next tile of this column, claimed: call again with cont = 1).
+// registers spilled to vector lanes in the wall code); a function that runs a whole chain of tiles in a loop of its own does
+// the same (256 registers, 832 bytes of scratch per lane).  One call per tile is compiled like the single tile of
+// k_reinit_gs_persist.  Returns 0 (stop, NaN, time-out: leave), 1 (done: acquire the next tile from the list) or 2 (done, and
+// task[0], task[1] hold the next tile of this column, claimed: call again with cont = 1).
 template <int TA, int WY, int WZ, int BY, bool STRICT>
 __device__ __noinline__ int stream_tile(int cont_, unsigned karg_lo, unsigned karg_hi)
 {
@@ -74,10 +113,17 @@ __device__ __noinline__ int stream_tile(int cont_, unsigned karg_lo, unsigned ka
     auto m_hi = [&](int B_, int C_) { return (T::NYT * B_ + T::NYT - 1 + T::NZT * C_ + T::NZT - 1 + a.nx - 2) / TA; };
     auto tile_word = [&](int s, int m, int B, int C) { return a.tile_done + s * per_sweep + m + (long)nM * (B + (long)a.nTj * C); };
     auto give_up = [&]() { __hip_atomic_fetch_max(a.ticket, (int)a.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // the tile's LDS image holds interior cells only (full tile, three rows and 22 entries of interior around every bundle row)?
+    auto interior_image = [&](int m, int B, int C, int sj, int sk) {
+        const int tj = sj > 0 ? B : a.nTj - 1 - B, tk = sk > 0 ? C : a.nTk - 1 - C;
+        const int j_lo = 1 + tj * T::NYT, k_lo = 1 + tk * T::NZT, X0 = TA * m - T::NYT * B - T::NZT * C;
+        return j_lo >= 4 && j_lo + T::NYT + 2 <= a.ny - 1 && k_lo >= 4 && k_lo + T::NZT + 2 <= a.nz - 1 && X0 - (T::NYT + T::NZT + 4) >= 0 &&
+               X0 + 22 <= a.nx - 2;
+    };
     const uint32_t packed = (uint32_t)uni(sh_task[0]);
     const int sP = uni(sh_task[1]);
     const int s = sP & (DF_BATCH - 1), P = (int)((unsigned)sP >> DF_SWEEP_BITS);
-    if (LSF_STREAM_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    if (LSF_STREAM_PRIO) __builtin_amdgcn_s_setprio(0);
     if (tid == 0) {
         const int m = packed & 0x3ff, B = (packed >> 10) & 0x3ff, C = (packed >> 20) & 0x3ff;
         const int4 swp = *(const int4*)(a.sweep_tab + 4 * s); // signs and spacing of the sweep: one request
@@ -119,7 +165,6 @@ __device__ __noinline__ int stream_tile(int cont_, unsigned karg_lo, unsigned ka
             }
         }
         sh_task[2] = go, sh_task[3] = swp.x, sh_task[4] = swp.y, sh_task[5] = swp.z, sh_task[8] = swp.w;
-        sh_task[9] = a.g0 + s - ld_flag(a.ctl + 1); // sweeps between this tile's and the oldest unfinished one
         // (parked as offsets from tile_done, not as pointers: a pointer that has been through LDS is a flat pointer to the compiler)
         sh_wait[0] = (unsigned long long)(w0 - a.tile_done), sh_wait[1] = (unsigned long long)(w1 - a.tile_done);
         sh_wait[2] = (unsigned long long)(w2 - a.tile_done), sh_wait[3] = t0;
@@ -127,7 +172,6 @@ __device__ __noinline__ int stream_tile(int cont_, unsigned karg_lo, unsigned ka
     }
     __syncthreads();
     int go = uni(sh_task[2]);
-    if (LSF_STREAM_PRIO == 2) sk_sweep_prio(uni(sh_task[9]));
     auto wait_upstream = [&]() -> bool { // stage 2: condition (a), the upstream tiles DONE
         if (tid == 0) {
             int go2 = 1;
@@ -179,7 +223,7 @@ __device__ __noinline__ int stream_tile(int cont_, unsigned karg_lo, unsigned ka
                 }
             }
             // ---- CONTINUE with (m + 1, B, C)? ----
-            int why = 9; // (LSF_TRACE_TILES) 9 end of column, 10 previous sweep not past, 11 cross tiles unclaimed, 12 claim lost
+            int why = 9; // (LSF_TRACE_TILES) 9 end of column, 10 previous sweep not past, 11 cross tiles not ready, 12 claim lost
             if (m + 1 <= m_hi(B, C) && a.cont_on) {
                 const int* c1 = (B >= 1 && m + 1 >= m_lo(B - 1, C) && m + 1 <= m_hi(B - 1, C)) ? tile_word(s, m + 1, B - 1, C) : set_word;
                 const int* c2 = (C >= 1 && m + 1 >= m_lo(B, C - 1) && m + 1 <= m_hi(B, C - 1)) ? tile_word(s, m + 1, B, C - 1) : set_word;
@@ -187,8 +231,11 @@ __device__ __noinline__ int stream_tile(int cont_, unsigned karg_lo, unsigned ka
                 const int vstop = ld_flag(a.ctl + 0);
                 const int v3 = ld_flag(s == 0 ? always : a.planes_done + s - 1), v1 = ld_flag(c1), v2 = ld_flag(c2);
                 const int need1 = s == 0 ? 0 : min(P + 1 + sh_task[8], np);
-                why = !(v3 >= need1 && v3 <= np + 1) ? 10 : 11;
-                if (vstop == 0 && v3 >= need1 && (s == 0 || v3 <= np + 1) && v1 >= a.cont_on && v2 >= a.cont_on) {
+                bool past = s == 0 || (v3 >= need1 && v3 <= np + 1);
+                if (!past && v3 <= np + 1 && LSF_STREAM_FINE && interior_image(m + 1, B, C, sh_task[4], sh_task[5]))
+                    past = stream_prev_sweep_past<T, TA>(a, s, m + 1, B, C, per_sweep);
+                why = !past ? 10 : 11;
+                if (vstop == 0 && past && v1 >= a.cont_on && v2 >= a.cont_on) {
                     int expect = 0;
                     why = 12;
                     if (__hip_atomic_compare_exchange_strong(tile_word(s, m + 1, B, C), &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import levelsetfortran_amd as lsf  # noqa: E402
 from levelsetfortran_amd import _lib, fields  # noqa: E402
 
-VARIANTS = {"persist": {"LSF_GS_STREAM": "0"}, "stream": {}, "nocont": {"LSF_GS_CONT": "0"}}
+VARIANTS = {"persist": {"LSF_GS_STREAM": "0"}, "stream": {"LSF_GS_STREAM": "1"}, "nocont": {"LSF_GS_STREAM": "1", "LSF_GS_CONT": "0"}}
 
 
 def setenv(d):
