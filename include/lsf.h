@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSF_VERSION 104 /* 0.1.4: lsf_reinit_multi takes LSF_ORDER_GS (the reference's ordering over z slabs), lsf_slabs_info */
+#define LSF_VERSION 105 /* 0.1.5: lsf_peer_selftest; LSF_GS_STREAM (the dataflow launch with column continuation, opt-in) */
 
 /* ---- return codes ---------------------------------------------------------------------- */
 #define LSF_OK 0
@@ -79,6 +79,9 @@ int lsf_release_workspace(void);
  * the sweep kernel(s), the boundary-condition kernel and the RMS/stop kernel with HIP events on the
  * stream they are launched on.  lsf_profile_get returns the sums over the sweeps of that call (ms),
  * the number of sweep-kernel launches and the number of sweeps timed. */
+/* diagnostic: 1 when the 16-byte loads / stores of the exact-ordering tiles (one raw buffer descriptor of 2^31 - 1 bytes per
+ * tile image of rows_z + 6 planes) can address every point of a tile on an (nx, ny) grid; the kernels test the same expression. */
+int lsf_skew_wide_fits(int nx, int ny, int rows_z);
 int lsf_profile(int enable);
 int lsf_profile_get(double *sweep_kernel_ms, double *bc_ms, double *finish_ms,
                     long long *sweep_kernel_launches, int *sweeps);
@@ -259,6 +262,10 @@ int lsf_stl_get(double *surfX, int32_t *surfElem);
  * share it): that is how the path is tested on a one-GPU machine.  `phi` is a HOST array; a device twin of it left by
  * an earlier seam call (lsf_mirror) is brought home first and dropped afterwards.  The lsf_multi_* calls are the same
  * thing in pieces, for callers that keep the blocks resident (bench.py).
+ * The RMS is judged a window of sweeps late; a run that can stop (tol > 0) keeps the field at the start of the last two
+ * windows (two more field copies per block) and goes back to the stop sweep, a NaN sweep included.  With tol <= 0 nothing is
+ * kept: when such a run returns LSF_ERR_NAN the sweep count and the trace are exact, the FIELD is that of the last sweep
+ * enqueued (up to two windows later) -- undefined for the caller, as after the reference's STOP (subs.f90:926).
  *
  * LSF_ORDER_GS (fp64; dims NULL or {1, 1, ndev}): the reference's in-place ordering (subs.f90:743-852) itself, over ndev
  * slabs of tile layers in z, devices[0] at k = 0.  Every slab runs the dataflow launch of lsf_reinit on its own tile columns
@@ -274,6 +281,15 @@ int lsf_stl_get(double *surfX, int32_t *surfElem);
  * slabs' launches took (device events; uploads, transpositions and downloads excluded). */
 typedef struct lsf_multi lsf_multi;
 int lsf_slabs_info(int *slabs, int *blocks_per_slab, int *finegrained, int *sweeps, double *kernel_s);
+/* First-contact self-test of what those slab launches assume of memory shared between two devices (nothing in the reference
+ * corresponds: it is serial, README.md:17): two kernels, one per device, that wait for each other -- 200 rounds of a
+ * message-passing litmus in both directions at once (8 KB stored into the peer's memory at system scope, s_waitcnt vmcnt(0),
+ * a flag; the peer polls the flag and checks every word) and an atomic-max contest on one word.  Returns LSF_OK, or
+ * LSF_ERR_HIP with *violated = the assumption of DESIGN.md section 6.1 that failed: 1 / 2 a payload announced by its flag
+ * was not there (the drain does not cover stores to the peer, or the peer's loads were stale), 3 the atomic lost an update,
+ * 4 the kernels did not run at the same time (bounded spins: no hang).  devA == devB runs both kernels on one device.
+ * lsf_reinit_multi(LSF_ORDER_GS) runs it once per process for every pair of distinct neighbouring devices. */
+int lsf_peer_selftest(int devA, int devB, int *violated);
 int lsf_reinit_multi(double *phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,
                      const int *devices, int ndev, const int dims[3], int *sweeps_done, double *rms_trace, int trace_cap);
 int lsf_reinit_multi_f32(float *phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode,
@@ -302,7 +318,7 @@ int lsf_multi_gather(lsf_multi *m, void *host_phi);                     /* owned
  *                                    list; librccl.so is loaded on first use); needs a distinct device per block
  *                LSF_TRANSPORT_MOCK  test aid: the RCCL schedule with a stand-in for the library (pull copies) that runs
  *                                    with several blocks on one device
- * lsf_multi_defaults sets what lsf_multi_create / lsf_reinit_multi start from (the environment variables
+ * lsf_multi_defaults sets what lsf_multi_create / lsf_reinit_multi of the calling thread start from (the environment variables
  * LSF_MULTI_CHECK_EVERY and LSF_MULTI_TRANSPORT = peer | rccl | mock override it).  lsf_multi_info: NULL for what is not
  * wanted; rccl_ranks = communicators held (0 unless the RCCL transport is on); host_enqueue_s = the longest any block's
  * thread spent enqueuing during the last lsf_multi_run (waits for its neighbours' threads and, when blocks share a device,
@@ -311,7 +327,8 @@ int lsf_multi_gather(lsf_multi *m, void *host_phi);                     /* owned
 #define LSF_TRANSPORT_PEER 0
 #define LSF_TRANSPORT_RCCL 1
 #define LSF_TRANSPORT_MOCK 2
-int lsf_multi_defaults(int check_every, int transport);
+int lsf_multi_defaults(int check_every, int transport);   /* per calling thread */
+int lsf_multi_defaults_get(int *check_every, int *transport);
 int lsf_multi_configure(lsf_multi *m, int check_every, int transport);
 int lsf_multi_info(const lsf_multi *m, int *check_every, int *transport, int *rccl_ranks, int *rccl_version,
                    double *host_enqueue_s, double *host_calls_s, double *wall_s, int *sweeps_enqueued);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "lsf_device_count": (c_int, []),
     "lsf_set_device": (c_int, [c_int]),
     "lsf_release_workspace": (c_int, []),
+    "lsf_skew_wide_fits": (c_int, [c_int, c_int, c_int]),
     "lsf_profile": (c_int, [c_int]),
     "lsf_profile_kernel": (ctypes.c_char_p, []),
     "lsf_profile_get": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_double),
@@ -90,6 +91,8 @@ SIGNATURES = {
     "lsf_multi_run": (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_int, POINTER(c_int), c_void_p, c_int]),
     "lsf_multi_gather": (c_int, [c_void_p, c_void_p]),
     "lsf_slabs_info": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_double)]),
+    "lsf_peer_selftest": (c_int, [c_int, c_int, POINTER(c_int)]),
+    "lsf_multi_defaults_get": (c_int, [POINTER(c_int), POINTER(c_int)]),
     "lsf_multi_defaults": (c_int, [c_int, c_int]),
     "lsf_multi_configure": (c_int, [c_void_p, c_int, c_int]),
     "lsf_multi_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_double),

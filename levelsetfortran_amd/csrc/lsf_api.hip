@@ -9,6 +9,7 @@
 #include <array>
 #include <chrono>
 #include <map>
+#include <set>
 #include <unordered_map>
 #include <mutex>
 #include <string>
@@ -937,6 +938,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
                 std::vector<int> meta;
                 meta.insert(meta.end(), st0.begin(), st0.end());
                 for (unsigned v : base) meta.push_back((int)v);
+                while (meta.size() % 4) meta.push_back(0); // the kernels read a sweep's four table entries as one 16-byte load
                 meta.insert(meta.end(), tab.begin(), tab.end());
                 for (int P = 0; P < np; ++P) meta.push_back(tl->off[P + 1] - tl->off[P]);
                 meta.insert(meta.end(), tl->off.begin(), tl->off.end());
@@ -947,7 +949,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             const BatchPlan& bp = it->second;
             const int* m_start = bp.d_meta;
             const unsigned* m_base = (const unsigned*)(bp.d_meta + ns);
-            const int* m_tab = bp.d_meta + ns + bp.nslots + 1;
+            const int* m_tab = bp.d_meta + (ns + bp.nslots + 1 + 3) / 4 * 4; // 16-byte aligned (hipMalloc aligns the block)
             const int* m_psize = m_tab + 4 * DF_BATCH;
             const int* m_poff = m_psize + np;
             if (!marked) prof_mark(st), marked = true; // the timed region starts once the first plan exists
@@ -1555,6 +1557,10 @@ int lsf_set_device(int device)
     g_device = device;
     return ensure_device();
 }
+
+// diagnostic: does the 16-byte path of the exact-ordering tiles apply to tiles of rows_z rows in z on an (nx, ny) grid?  (the guard
+// of skew_tile's buffer descriptor, evaluated on the host: tests/test_host_logic.py)
+int lsf_skew_wide_fits(int nx, int ny, int rows_z) { return sk_wide_image_fits((long)(nx + 1) * (ny + 1), rows_z) ? 1 : 0; }
 
 int lsf_profile(int enable)
 {
@@ -2305,7 +2311,8 @@ Rccl::~Rccl()
 
 // process-wide defaults of lsf_multi_create (lsf_multi_defaults; LSF_MULTI_TRANSPORT = peer | rccl | mock and
 // LSF_MULTI_CHECK_EVERY in the environment override them: the Fortran host has no other way in)
-static int g_multi_check_every = 8, g_multi_transport = LSF_TRANSPORT_PEER;
+// (per thread: a caller that sets them around a call of its own does not race with other threads' calls)
+static thread_local int g_multi_check_every = 8, g_multi_transport = LSF_TRANSPORT_PEER;
 
 // the lsf_multi_* calls visit other devices: the calling thread gets its own device back (HIP's and the library's)
 struct DeviceRestore {
@@ -2318,6 +2325,9 @@ struct DeviceRestore {
     }
 };
 
+// ---- first-contact self-test of the device-to-device hand-offs the slab launches rely on (lsf_peer_selftest) ------------
+#include "lsf_peer.hpp"
+
 // ---- the exact ordering across z slabs, one launch per device (lsf_reinit_multi with LSF_ORDER_GS) --------------------
 #include "lsf_gs_slabs.hpp"
 
@@ -2329,6 +2339,13 @@ int lsf_multi_defaults(int check_every, int transport)
     if (transport != LSF_TRANSPORT_PEER && transport != LSF_TRANSPORT_RCCL && transport != LSF_TRANSPORT_MOCK)
         return fail(LSF_ERR_INVALID, "unknown transport");
     g_multi_check_every = check_every, g_multi_transport = transport;
+    return LSF_OK;
+}
+
+int lsf_multi_defaults_get(int* check_every, int* transport)
+{
+    if (check_every) *check_every = g_multi_check_every;
+    if (transport) *transport = g_multi_transport;
     return LSF_OK;
 }
 

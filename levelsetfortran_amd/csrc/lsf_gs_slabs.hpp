@@ -128,6 +128,22 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
             (void)hipGetLastError();
         }
 
+    // First contact: the hand-offs below rely on four properties of peer memory that a one-GPU machine cannot show (DESIGN.md
+    // section 6.1).  Every pair of distinct devices runs the litmus test once per process before the first launch that needs it;
+    // a violated assumption ends the call with an error that names it -- not with a 4 s time-out or a field that differs.
+    {
+        static std::mutex mu;
+        static std::set<std::pair<int, int>> passed;
+        std::lock_guard<std::mutex> lk(mu);
+        for (int a = 0; a + 1 < ndev; ++a) {
+            const int da = std::min(devices[a], devices[a + 1]), db = std::max(devices[a], devices[a + 1]);
+            if (da == db || passed.count({da, db}) || getenv("LSF_SLAB_NO_SELFTEST")) continue;
+            int violated = 0;
+            if ((rc = lsf_peer_selftest(da, db, &violated))) return rc;
+            passed.insert({da, db});
+        }
+    }
+
     // ---- geometry, buffers, tile lists of every slab -----------------------------------------------------------------
     std::map<int, int> share; // slabs per device
     for (int d = 0; d < ndev; ++d) ++share[devices[d]];
@@ -294,6 +310,7 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
                 std::vector<int> meta;
                 meta.insert(meta.end(), st0.begin(), st0.end());
                 for (unsigned v : basev) meta.push_back((int)v);
+                while (meta.size() % 4) meta.push_back(0); // the kernels read a sweep's four table entries as one 16-byte load
                 meta.insert(meta.end(), tab.begin(), tab.end());
                 for (int v = 0; v < 2; ++v)
                     for (int P = 0; P < np; ++P) meta.push_back(b.off[v][P + 1] - b.off[v][P]);
@@ -306,7 +323,7 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
             const int* dm = it->second.first;
             const int* m_start = dm;
             const unsigned* m_base = (const unsigned*)(dm + ns);
-            const int* m_tab = dm + ns + nslots + 1;
+            const int* m_tab = dm + (ns + nslots + 1 + 3) / 4 * 4; // 16-byte aligned (hipMalloc aligns the block)
             const int* m_psize = m_tab + 4 * DF_BATCH;
             const int* m_poff = m_psize + 2 * np;
             GsArgs& a = fa[d];

@@ -217,6 +217,11 @@ __device__ __forceinline__ SkPre sk_prefetch(const GsArgs& a, int tid = threadId
     return p;
 }
 
+// Wide path of skew_tile: the tile's image -- NZT + 6 planes and a few rows of the field, from the tile origin -- is addressed
+// through ONE raw buffer descriptor of 0x7fffffff bytes with 32-bit byte offsets; out-of-range loads would return 0 and stores
+// would be dropped without a trace.  (Planes of 3 500^2 ... 4 650^2 points passed the old test, 4.0e9 bytes, and lay outside.)
+__host__ __device__ inline bool sk_wide_image_fits(long sxy, int nzt) { return (double)(nzt + 7) * (double)sxy * 8.0 <= (double)(0x7fffffff - 16); }
+
 // (LSF_STREAM_PRIO) priority of a wavefront at step u of its march
 __device__ __forceinline__ void sk_march_prio(int u)
 {
@@ -419,7 +424,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));
     constexpr int AUX_SC1 = SYS ? 17 : (SC1 ? 16 : 0); // cache policy of the buffer instructions: sc1 = bit 4, sc0 = bit 0 (system scope: both)
     const bool widex = (LSF_SKEW_WIDE == 2 || (LSF_SKEW_WIDE == 1 && BY == 16)) && deep && X0 - (NYT + NZT + 4) >= 0 && X0 + 22 <= nxi - 1 &&
-                       (double)(NZT + 7) * (double)sxy * 8.0 <= (double)(0x7fffffff - 16); // the image lies inside the buffer descriptor (num_records below)
+                       sk_wide_image_fits(sxy, NZT);
     // both loaders come in two instances: CT = false loads the whole image, CT = true what a continued column still needs
     bool loaded = true;
     auto load_wide = [&](auto ct_tag) {

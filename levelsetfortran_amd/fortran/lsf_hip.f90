@@ -42,8 +42,12 @@
 !                               ! 'fast' (same mathematics restructured for the GPU, 2 x faster, ~1e-16 per sweep away;
 !                               !   see DESIGN.md section 2 for what that becomes over thousands of sweeps)
 !     devices = 0, 1, 2, 3      ! reinit runs on these GPUs (lsf_reinit_multi; a device may be listed more than once):
-!                               !   order = 'jacobi': block-decomposed, one block each; order = 'gs': the reference's
-!                               !   ordering over one z slab each, same field as one GPU bit for bit; unset: one GPU
+!                               !   order = 'jacobi': block-decomposed, one block each; order = 'gs': ONE GPU (the first
+!                               !   listed) unless `slabs = 1`; unset: one GPU
+!     slabs = 0                 ! 1: with order = 'gs', the reference's ordering over one z slab per listed device, the
+!                               !   field of one GPU bit for bit (lsf_reinit_multi with LSF_ORDER_GS).  Opt-in: the path
+!                               !   has not run on two real devices yet; on first use every pair of neighbouring devices
+!                               !   runs lsf_peer_selftest, and a violated assumption ends the run with its name
 !     transport = 'peer'        ! how the blocks exchange their 3-cell halos: 'peer' (peer copies, default) | 'rccl'
 !                               !   (ncclSend / ncclRecv over xGMI; needs a distinct device per block)
 !     check_every = 8           ! sweeps between two looks of the host at the RMS of a block-decomposed run (1..64;
@@ -56,7 +60,7 @@
 !
 ! Every entry is optional; environment variables of the same meaning (LSF_DX, LSF_DD,
 ! LSF_DD_{X,Y,Z}_{LO,HI}, LSF_REINIT_ITER, LSF_MINMAX_ITER, LSF_REINIT2_ITER, LSF_ORDER,
-! LSF_ARITH, LSF_RESIDENT, LSF_DEVICES="0,1,2,3", LSF_MULTI_TRANSPORT, LSF_MULTI_CHECK_EVERY) override the namelist.
+! LSF_ARITH, LSF_RESIDENT, LSF_DEVICES="0,1,2,3", LSF_SLABS, LSF_MULTI_TRANSPORT, LSF_MULTI_CHECK_EVERY) override the namelist.
 !*************************************************************************************!
 MODULE lsf_hip
 
@@ -76,7 +80,7 @@ INTEGER, SAVE :: nml_dd = -1, nml_dd_lo(3) = -1, nml_dd_hi(3) = -1
 INTEGER, SAVE :: nml_reinit_iter = -1, nml_minmax_iter = -1, nml_reinit2_iter = -1
 CHARACTER(LEN=16), SAVE :: nml_order = ' ', nml_arith = ' ', nml_transport = ' '
 INTEGER, SAVE :: nml_check_every = 8
-INTEGER, SAVE :: nml_resident = -1
+INTEGER, SAVE :: nml_resident = -1, nml_slabs = 0
 INTEGER(c_int), SAVE :: nml_devices(16) = -1
 LOGICAL, SAVE :: mirror_set = .FALSE.
 
@@ -245,11 +249,11 @@ END FUNCTION lsf_mode
 !*************************************************************************************!
 SUBROUTINE lsf_load_inputs()
 REAL :: dx
-INTEGER :: dd,dd_lo(3),dd_hi(3),reinit_iter,minmax_iter,reinit2_iter,ios,u,resident,devices(16),check_every
+INTEGER :: dd,dd_lo(3),dd_hi(3),reinit_iter,minmax_iter,reinit2_iter,ios,u,resident,devices(16),check_every,slabs
 CHARACTER(LEN=16) :: order,arith,transport
 CHARACTER(LEN=1024) :: path
 LOGICAL :: there
-NAMELIST /lsf_inputs/ dx,dd,dd_lo,dd_hi,reinit_iter,minmax_iter,reinit2_iter,order,arith,resident,devices,transport,check_every
+NAMELIST /lsf_inputs/ dx,dd,dd_lo,dd_hi,reinit_iter,minmax_iter,reinit2_iter,order,arith,resident,devices,transport,check_every,slabs
 IF (nml_loaded) RETURN
 nml_loaded = .TRUE.
 path = ' '
@@ -266,7 +270,7 @@ END IF
 dx = nml_dx; dd = nml_dd; dd_lo = nml_dd_lo; dd_hi = nml_dd_hi
 reinit_iter = nml_reinit_iter; minmax_iter = nml_minmax_iter; reinit2_iter = nml_reinit2_iter
 order = nml_order; arith = nml_arith; resident = nml_resident; devices = nml_devices
-transport = nml_transport; check_every = nml_check_every
+transport = nml_transport; check_every = nml_check_every; slabs = nml_slabs
 u = 47
 OPEN(UNIT=u,FILE=TRIM(path),STATUS='old',ACTION='read',IOSTAT=ios)
 IF (ios == 0) READ(u,NML=lsf_inputs,IOSTAT=ios)
@@ -278,7 +282,7 @@ CLOSE(u)
 nml_dx = dx; nml_dd = dd; nml_dd_lo = dd_lo; nml_dd_hi = dd_hi
 nml_reinit_iter = reinit_iter; nml_minmax_iter = minmax_iter; nml_reinit2_iter = reinit2_iter
 nml_order = order; nml_arith = arith; nml_resident = resident; nml_devices = devices
-nml_transport = transport; nml_check_every = check_every
+nml_transport = transport; nml_check_every = check_every; nml_slabs = slabs
 PRINT*, " Run parameters read from ",TRIM(path)
 END SUBROUTINE lsf_load_inputs
 
@@ -337,7 +341,7 @@ REAL,DIMENSION(0:nx,0:ny,0:nz),INTENT(INOUT) :: phi,gradPhiMag
 REAL,DIMENSION(0:nx,0:ny,0:nz,3),INTENT(INOUT) :: gradPhi
 REAL,ALLOCATABLE :: trace(:)
 INTEGER(c_int) :: rc,done,mode,devs(16),nd
-INTEGER :: n
+INTEGER :: n,use_slabs
 
 ! gradPhi and gradPhiMag are dead outputs of the reference's reinit: the host zeroes them
 ! right after the first call (set3d.f90:372-375) and never reads them after the second.
@@ -346,6 +350,8 @@ INTEGER :: n
 ALLOCATE(trace(iter+1))
 mode = lsf_mode()
 CALL lsf_device_list(devs,nd)
+use_slabs = nml_slabs
+CALL lsf_env_int('LSF_SLABS',use_slabs)
 IF (nd >= 2 .AND. IAND(mode,LSF_ORDER_JACOBI) /= 0) THEN
    ! one block per listed GPU, halos peer to peer, same result as one GPU (include/lsf.h: lsf_reinit_multi)
    PRINT*, " Reinit block-decomposed over ",nd," devices "
@@ -357,12 +363,14 @@ IF (nd >= 2 .AND. IAND(mode,LSF_ORDER_JACOBI) /= 0) THEN
    IF (rc /= LSF_OK) CALL lsf_fail('lsf_multi_defaults',rc)
    rc = lsf_reinit_multi(phi,nx,ny,nz,iter,dx,h,1.E-5,mode,devs,nd,C_NULL_PTR,done,trace,iter+1)
    IF (rc /= LSF_OK .AND. rc /= LSF_ERR_NAN) CALL lsf_fail('lsf_reinit_multi',rc)
-ELSE IF (nd >= 2) THEN
-   ! the reference's own ordering, one slab of z per listed GPU: the field of one GPU, bit for bit (include/lsf.h)
+ELSE IF (nd >= 2 .AND. use_slabs /= 0) THEN
+   ! the reference's own ordering, one slab of z per listed GPU: the field of one GPU, bit for bit (include/lsf.h).
+   ! Opt-in (slabs = 1 / LSF_SLABS=1): without it a device list with order = 'gs' runs on one GPU, as it always did.
    PRINT*, " Reinit in the reference's ordering over ",nd," z slabs "
    rc = lsf_reinit_multi(phi,nx,ny,nz,iter,dx,h,1.E-5,mode,devs,nd,C_NULL_PTR,done,trace,iter+1)
    IF (rc /= LSF_OK .AND. rc /= LSF_ERR_NAN) CALL lsf_fail('lsf_reinit_multi',rc)
 ELSE
+   IF (nd >= 2) PRINT*, " Reinit in the reference's ordering on one device (slabs = 1 shards it over the listed devices) "
    rc = lsf_reinit(phi,nx,ny,nz,iter,dx,h,1.E-5,mode,done,trace,iter+1)
    IF (rc /= LSF_OK .AND. rc /= LSF_ERR_NAN) CALL lsf_fail('lsf_reinit',rc)
 END IF

@@ -28,7 +28,7 @@ import numpy as np
 from . import _lib
 from ._lib import LSF_ARITH_FAST, LSF_ARITH_STRICT, LSF_ORDER_GS, LSF_ORDER_JACOBI, LsfError, LsfNaNError
 
-__all__ = ["reinit", "narrowBand", "minmaxFlow", "phi0Init", "advectNodes", "SweepReport", "mode_word", "LsfError", "LsfNaNError"]
+__all__ = ["reinit", "narrowBand", "minmaxFlow", "phi0Init", "advectNodes", "SweepReport", "mode_word", "LsfError", "LsfNaNError", "peer_selftest"]
 
 REINIT_TOL = 1.0e-5  # subs.f90:915
 MINMAX_TOL = 1.0e-7  # set3d.f90:448
@@ -278,6 +278,14 @@ def reinit_multi(phi, nx: int, ny: int, nz: int, iter: int, dx: float, h: float,
     check_every: sweeps between two looks at the RMS (the stop sweep, the field and the trace do not depend on it);
     transport: "peer" (peer copies), "rccl" (ncclSend / ncclRecv, a distinct device per block) or "mock" (test aid)."""
     lib = _lib.load()
+    if transport not in TRANSPORTS:
+        raise ValueError(f"transport must be one of {sorted(TRANSPORTS)}, not {transport!r}")
+    if order not in ("jacobi", "gs"):
+        raise ValueError(f"order must be 'jacobi' or 'gs', not {order!r}")
+    if order == "gs" and (dims is not None or check_every != 8 or transport != "peer"):
+        raise ValueError("order='gs' (the reference's ordering over z slabs) takes no dims, check_every or transport")
+    old_ce, old_tr = ctypes.c_int(8), ctypes.c_int(_lib.LSF_TRANSPORT_PEER)
+    lib.lsf_multi_defaults_get(ctypes.byref(old_ce), ctypes.byref(old_tr))  # this thread's: put back afterwards
     _lib.check(lib.lsf_multi_defaults(int(check_every), TRANSPORTS[transport]))
     cap = int(iter) + 1
     trace = np.zeros(max(cap, 1), dtype=np.float64)
@@ -292,8 +300,17 @@ def reinit_multi(phi, nx: int, ny: int, nz: int, iter: int, dx: float, h: float,
         rc = fn(p, nx, ny, nz, int(iter), float(dx), float(h), float(tol), mode, devs, len(devices), dm, ctypes.byref(done),
                 trace.ctypes.data, cap)
     finally:
-        lib.lsf_multi_defaults(8, _lib.LSF_TRANSPORT_PEER)
+        lib.lsf_multi_defaults(old_ce.value, old_tr.value)
     n = done.value
     rep = SweepReport(n, [float(v) for v in trace[:n]], bool(n and trace[n - 1] < tol))
     _lib.check(rc)
     return rep
+
+
+def peer_selftest(dev_a: int, dev_b: int) -> int:
+    """include/lsf.h: lsf_peer_selftest -- the litmus test of the device-to-device hand-offs the exact ordering across z slabs
+    relies on.  Returns 0, or raises LsfError whose message names the violated assumption."""
+    lib = _lib.load()
+    bad = ctypes.c_int(0)
+    _lib.check(lib.lsf_peer_selftest(int(dev_a), int(dev_b), ctypes.byref(bad)))
+    return bad.value

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names  # the Python binding covers the whole header, nothing more
-    assert lib.lsf_version() == 104
+    assert lib.lsf_version() == 105
 
 
 def test_no_cpu_fallback_without_device():

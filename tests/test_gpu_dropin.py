@@ -91,6 +91,30 @@ def test_baseline_config2_cube40_256(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(EXE), reason="drop-in executable not built")
+def test_baseline_config1_cube40_64_literal(tmp_path):
+    """BASELINE config 1 at its LITERAL size: cube40.stl with dx = 2/42 -> nx = ny = nz = 63, a 64^3 grid (SURVEY.md 8b:
+    ceiling(2 / (2/42)) + 21 = 63 sits on a rounding knife-edge, so the host's own line is asserted).  The whole program
+    through the reference's Fortran host with the run-time dx override: reinit to the reference's
+    1e-5 stop (2 066 sweeps by the reference's own `reinit`, tests/golden/make_golden_c1.py), min/max flow to its 1e-7
+    stop (384 iterations, pinned oracle), both .vti payloads bit for bit."""
+    g = np.load(os.path.join(GOLDEN, "cube40_64.npz"))
+    out = _run_dropin(tmp_path, "cube40.stl", "cube40", dict(LSF_DX=repr(float(g["dx"])), LSF_REINIT2_ITER="0"))
+    assert "Grid Size: nx = 63 , ny = 63 ,nz = 63" in out
+    assert "Distance function time integration has reached steady state" in out
+    assert "Min/max time integration has reached steady state" in out
+    sweeps, mm = int(g["sweeps"]), int(g["mm_iters"])
+    its = [int(x) for x in re.findall(r"Iteration:\s+(\d+)", out)]
+    # the stop sweep prints the steady-state line instead of its RMS: reinit prints 0 .. sweeps-2, min/max 1 .. mm-1
+    assert its[:sweeps - 1] == list(range(sweeps - 1)) and its[sweeps - 1:sweeps - 1 + mm - 1] == list(range(1, mm))
+    rms = [float(x) for x in re.findall(r"RMS Error:\s+(\S+)", out)]
+    assert np.allclose(rms[:sweeps - 1], g["rms"], rtol=1e-9, atol=0)
+    sha1, a1 = _sha_file_payload(tmp_path / "signedDistanceFunction.vti", (64, 64, 64))
+    assert np.array_equal(a1, g["phi_re"]) and sha1 == str(g["phi_re_sha"])
+    sha2, a2 = _sha_file_payload(tmp_path / "smoothedDistanceFunction.vti", (64, 64, 64))
+    assert np.array_equal(a2[::3, ::3, ::3], g["phi_mm_sample"]) and sha2 == str(g["phi_mm_sha"])
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="drop-in executable not built")
 def test_baseline_config3_twocube10_512(tmp_path):
     """BASELINE config 3: twoCube10.stl at the 512-point resolution (512 x 63 x 63 with the host's uniform padding),
     128 reinit sweeps (the surface diverges later in the reference itself) + 200 min/max-flow iterations."""
@@ -149,7 +173,7 @@ def test_fortran_host_drives_the_block_decomposed_reinit(tmp_path):
     # the reference's own ordering shards too: z slabs of the exact Gauss-Seidel tile graph (lsf_reinit_multi with LSF_ORDER_GS),
     # same payload as the one-device run of that ordering, bit for bit, in the reference's arithmetic (the shim's default)
     got = {}
-    for name, devs in (("gs1", None), ("gs2", "0,0"), ("gs3", "0,0,0")):
+    for name, devs in (("gs1", None), ("gs2", "0,0"), ("gs3", "0,0,0"), ("gs2off", "0,0")):
         d = tmp_path / name
         d.mkdir()
         stl_io.stl_write(d / "cube40.stl", s["cube40_surfX"], s["cube40_surfElem"])
@@ -157,16 +181,19 @@ def test_fortran_host_drives_the_block_decomposed_reinit(tmp_path):
         env.update(LSF_REINIT_ITER="70", LSF_MINMAX_ITER="4", LSF_REINIT2_ITER="5")
         if devs:
             env["LSF_DEVICES"] = devs
+            if name != "gs2off":
+                env["LSF_SLABS"] = "1"  # opt-in (namelist `slabs = 1`): a device list alone keeps this ordering on one GPU
         p = subprocess.run(f"ulimit -s unlimited; cd {d}; {EXE} cube40.stl", shell=True, env=env, text=True,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         assert p.returncode == 0, p.stdout[-2000:]
         got[name] = p.stdout
-    assert "z slabs" not in got["gs1"]
+    assert "z slabs" not in got["gs1"] and "z slabs" not in got["gs2off"]
+    assert got["gs2off"].count("Reinit in the reference's ordering on one device") == 2
     assert got["gs2"].count("Reinit in the reference's ordering over  2  z slabs") == 2
     assert got["gs3"].count("Reinit in the reference's ordering over  3  z slabs") == 2
     rms1 = re.findall(r"RMS Error:\s+(\S+)", got["gs1"])
     assert len(rms1) == 71 + 4 + 6
-    for name in ("gs2", "gs3"):
+    for name in ("gs2", "gs3", "gs2off"):
         for f in ("signedDistanceFunction.vti", "smoothedDistanceFunction.vti"):
             assert np.array_equal(stl_io.vti_read_phi(tmp_path / name / f, shape), stl_io.vti_read_phi(tmp_path / "gs1" / f, shape)), (name, f)
         assert re.findall(r"RMS Error:\s+(\S+)", got[name]) == rms1  # printed residuals: the same digits

@@ -483,6 +483,50 @@ def test_reinit_alternative_schedules(lsf, synth, cube40, monkeypatch, schedule)
     assert rep.count == rep2.count and 1 < rep.count < 200 and rep.converged and np.array_equal(phi, phi2)
 
 
+def test_baseline_config1_literal_64_cubed_device_seam(lsf):
+    """BASELINE config 1 at its literal size (cube40.stl, dx = 2/42: nx = ny = nz = 63), stage by stage through the device
+    seam in the reference's arithmetic: phi0 (lsf_phi0) == the fixture's, reinit to the 1e-5 stop == the reference's own
+    `reinit` (2 066 sweeps, field, every printed RMS), narrowBand counts, the min/max flow to its 1e-7 stop (384 iterations)
+    == the pinned oracle (tests/golden/make_golden_c1.py)."""
+    import hashlib
+    import os
+
+    from conftest import GOLDEN
+
+    g = np.load(os.path.join(GOLDEN, "cube40_64.npz"))
+    s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    nx = int(g["nx"])
+    assert nx == 63
+    dx, h, h1 = float(g["dx"]), float(g["h"]), float(g["h1"])
+    phi = np.ones((nx + 1,) * 3, order="F")
+    lsf.phi0Init(phi, nx, nx, nx, dx, g["xLo"], g["xMin"], g["xMax"], s["cube40_surfX"].astype(np.float64), s["cube40_surfElem"])
+    assert np.array_equal(phi, g["phi0"])
+    rep = lsf.reinit(phi, None, None, nx, nx, nx, 10000, dx, h, arith="strict")
+    assert rep.count == int(g["sweeps"]) and rep.converged
+    assert np.array_equal(phi, g["phi_re"])
+    assert np.allclose(rep.rms[:-1], g["rms"], rtol=1e-9, atol=0) and np.isclose(rep.rms[-1], float(g["rms_stop"]), rtol=1e-9)
+    nb = np.zeros(phi.shape, dtype=np.int32, order="F")
+    sb = np.zeros(phi.shape, dtype=np.int32, order="F")
+    lsf.narrowBand(nx, nx, nx, dx, phi, nb, sb)
+    assert int(nb.sum()) == int(g["nb_count"]) and int(sb.sum()) == int(g["sb_count"])
+    rep = lsf.minmaxFlow(phi, nb, sb, nx, nx, nx, 10000, dx, h1)
+    assert rep.count == int(g["mm_iters"]) and rep.converged
+    assert np.array_equal(phi[::3, ::3, ::3], g["phi_mm_sample"])
+    sha_ = lambda a: hashlib.sha256(np.ascontiguousarray(a.ravel(order="F")).tobytes()).hexdigest()
+    assert sha_(phi) == str(g["phi_mm_sha"]) and sha_(nb) == str(g["nb_sha"]) and sha_(sb) == str(g["sb_sha"])
+
+
+def test_peer_selftest_on_one_device(lsf):
+    """lsf_peer_selftest: the message-passing and atomic-max litmus of the slab launches' device-to-device hand-offs
+    (DESIGN.md section 6.1), here with both kernels on device 0 -- the form a one-GPU box can run.  A pair of kernels that
+    cannot see each other ends with LSF_ERR_HIP naming assumption (4), not with a hang (time-out hook)."""
+    import levelsetfortran_amd as pkg
+
+    assert pkg.peer_selftest(0, 0) == 0
+    with pytest.raises(pkg.LsfError, match="out of range"):
+        pkg.peer_selftest(0, 99)
+
+
 @pytest.mark.parametrize("cont,waves", [("2", None), ("1", None), ("0", None), ("2", "c1x4"), ("1", "c1x4"), ("2", "c1x2"), ("1", "4x2"), ("2", "1"),
                                         ("2", "c1x1"), ("1", "2x4")])
 def test_reinit_dataflow_launch_with_column_continuation(lsf, oracle, synth, cube40, monkeypatch, cont, waves):

@@ -237,3 +237,21 @@ def test_native_stl_reader_reproduces_the_reference_merge(tmp_path):
     X, E = _read_native(tmp_path / "syn.stl")
     assert np.array_equal(E, El) and np.array_equal(X, Xl)
     assert E[0, 0] == E[0, 1] and E[1, 0] != E[1, 1]  # the two quirks are in the data
+
+
+def test_wide_path_guard_follows_the_buffer_descriptor():
+    """the 16-byte path of the exact-ordering tiles addresses a tile image of NZT + 6 planes through one raw
+    buffer descriptor of 2^31 - 1 bytes.  The guard must refuse every plane size whose image does not fit -- the old test
+    (4.0e9 bytes) let planes of about 3 500^2 to 4 650^2 points through, whose upper rows would have read zeros and dropped
+    their stores.  No GPU needed: the library evaluates the kernels' expression on the host."""
+    from levelsetfortran_amd import _lib
+
+    lib = _lib.load()
+    nzt = 16  # the one-lane-per-cell tile
+    for n, want in ((511, 1), (1023, 1), (3000, 1), (3399, 1), (3500, 0), (4095, 0), (4650, 0), (8000, 0)):
+        image_bytes = (nzt + 7) * (n + 1) ** 2 * 8
+        assert (image_bytes <= 0x7FFFFFFF - 16) == bool(want), n
+        assert lib.lsf_skew_wide_fits(n, n, nzt) == want, n
+    # the boundary itself
+    n = int(((0x7FFFFFFF - 16) / (8 * (nzt + 7))) ** 0.5) - 1
+    assert lib.lsf_skew_wide_fits(n, n, nzt) == 1 and lib.lsf_skew_wide_fits(n + 2, n + 2, nzt) == 0

@@ -179,3 +179,21 @@ def test_threaded_hyperplane_sweep_is_the_same_sweep(synth, tmp_path):
     env = dict(os.environ, LSF_ORACLE_OMP="1", OMP_NUM_THREADS="4")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
+
+
+def test_config1_literal_grid_is_64_cubed_and_the_oracle_follows_the_reference(oracle):
+    """BASELINE config 1 at its literal size: dx = 2/42 gives nx = ny = nz = 63 for the extents cube40.stl really has
+    (SURVEY.md 8b's knife-edge), and the oracle reproduces the first 64 residuals the reference's own `reinit` printed at
+    that size (the whole run, 2 066 sweeps, is compared when the fixture is made: tests/golden/make_golden_c1.py)."""
+    import os
+
+    import stl_io
+    from conftest import GOLDEN
+
+    g = np.load(os.path.join(GOLDEN, "cube40_64.npz"))
+    s = np.load(os.path.join(GOLDEN, "surfaces.npz"))
+    n, xLo, mn, mx = stl_io.grid_from_surface(s["cube40_surfX"].astype(np.float64), dx=float(g["dx"]), dd=10)
+    assert tuple(n) == (63, 63, 63) and np.array_equal(xLo, g["xLo"])
+    phi = np.asfortranarray(g["phi0"]).copy(order="F")
+    _, done, tr = oracle.reinit(phi, 63, 63, 63, 63, float(g["dx"]), float(g["h"]), tol=0.0)
+    assert done == 64 and np.array_equal(np.asarray(tr), g["rms"][:64])
