@@ -282,8 +282,8 @@ def reinit_multi(phi, nx: int, ny: int, nz: int, iter: int, dx: float, h: float,
         raise ValueError(f"transport must be one of {sorted(TRANSPORTS)}, not {transport!r}")
     if order not in ("jacobi", "gs"):
         raise ValueError(f"order must be 'jacobi' or 'gs', not {order!r}")
-    if order == "gs" and (dims is not None or check_every != 8 or transport != "peer"):
-        raise ValueError("order='gs' (the reference's ordering over z slabs) takes no dims, check_every or transport")
+    if order == "gs" and (check_every != 8 or transport != "peer"):
+        raise ValueError("order='gs' (the reference's ordering over z slabs) takes no check_every or transport")
     old_ce, old_tr = ctypes.c_int(8), ctypes.c_int(_lib.LSF_TRANSPORT_PEER)
     lib.lsf_multi_defaults_get(ctypes.byref(old_ce), ctypes.byref(old_tr))  # this thread's: put back afterwards
     _lib.check(lib.lsf_multi_defaults(int(check_every), TRANSPORTS[transport]))
