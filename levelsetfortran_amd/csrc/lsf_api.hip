@@ -215,7 +215,8 @@ struct Profile {
     double sweep_ms = 0, bc_ms = 0, finish_ms = 0;
     long sweep_launches = 0;
     int sweeps = 0;
-    const char* kernel = ""; // name of the sweep kernel of the last profiled call
+    const char* kernel = ""; // sweep kernel of the last profiled call, with its template arguments (the instance rocprofv3 lists)
+    char kernel_buf[96] = "";
     std::vector<hipEvent_t> ev; // 4 per timed sweep
 };
 thread_local Profile g_prof;
@@ -644,7 +645,10 @@ int jacobi_loop(T* d_phi, const T* d_phiS_in, int nx, int ny, int nz, int iter, 
     const int nsw = host_ctl[1];
     prof_end(nsw);
     g_prof.sweep_launches = g_prof.sweeps;
-    g_prof.kernel = F32 ? (jp.kind == 2 ? "k_reinit_jacobi_f32_sh" : "k_reinit_jacobi_f32") : (jp.kind == 2 ? "k_reinit_jacobi_sh" : "k_reinit_jacobi");
+    if (jp.kind == 2 && F32) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "k_reinit_jacobi_f32_sh<%d>", jp.wx);
+    else if (jp.kind == 2) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "k_reinit_jacobi_sh<%d,%d>", jp.wx, jp.by);
+    else snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, F32 ? "k_reinit_jacobi_f32<%s>" : (strict ? "k_reinit_jacobi<true,%s>" : "k_reinit_jacobi<false,%s>"), jp.kind == 1 ? "true" : "false");
+    g_prof.kernel = g_prof.kernel_buf;
     if (bufs[nsw & 1] != d_phi)
         HIPCHK(hipMemcpyAsync(d_phi, bufs[nsw & 1], n * sizeof(T), hipMemcpyDeviceToDevice, st));
     if (rms_trace && trace_cap > 0 && nsw > 0)
@@ -1108,7 +1112,10 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         g_prof.bc_ms = g_prof.finish_ms = 0;
         g_prof.sweeps = nsw;
         g_prof.sweep_launches = launches;
-        g_prof.kernel = !slots_loop ? (stream ? "k_reinit_gs_stream" : "k_reinit_gs_persist") : (skew ? "k_reinit_gs_skew" : "k_reinit_gs_box");
+        if (skew) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "%s<16,%d,%d,%d,%s>", !slots_loop ? (stream ? "k_reinit_gs_stream" : "k_reinit_gs_persist") : "k_reinit_gs_skew",
+                           wy, wz, by, strict ? "true" : "false");
+        else snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "k_reinit_gs_box<%d,%d,%s>", ta, nyc, strict ? "true" : "false");
+        g_prof.kernel = g_prof.kernel_buf;
     }
     if (host_ctl[2] == 2) {
         // A block of the dataflow launch waited 4 s for a predecessor: never observed, but the launch relies on

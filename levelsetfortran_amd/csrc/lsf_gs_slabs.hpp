@@ -73,6 +73,26 @@ thread_local SlabReport g_slab_report;
 
 } // namespace lsfs
 
+#ifdef LSF_EXPERIMENTS
+// LSF_SLAB_MODEL="d/D" (experiment builds only; the field comes out WRONG): ONE slab of a D-slab run, alone on its device, with
+// everything it would wait for from its neighbours granted in advance -- the flags of every tile outside its columns and the
+// verdict of every sweep.  Its launch then takes the time a device of a D-device run needs for its share of the tile graph
+// when communication is free: the throughput term of the scaling model (profiles/micro/slab_model.sh).
+static __global__ __launch_bounds__(256) void k_slab_model_preset(int* tile_done, int* verdict, const int* sweep_tab, int ns, int nM, int nTj, int nTk,
+                                                                  int tk_lo, int tk_hi)
+{
+    const long per_sweep = (long)nM * nTj * nTk;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)ns * per_sweep; i += (long)gridDim.x * 256) {
+        const int s = (int)(i / per_sweep);
+        const int C = (int)((i - (long)s * per_sweep) / ((long)nM * nTj));
+        const int tk = sweep_tab[4 * s + 2] > 0 ? C : nTk - 1 - C;
+        if (tk < tk_lo || tk >= tk_hi) tile_done[i] = 1;
+    }
+    if (blockIdx.x == 0)
+        for (int q = threadIdx.x; q < ns; q += 256) verdict[q] = 1;
+}
+#endif
+
 // phi: HOST array in the caller's layout.  devices[0 .. ndev): one slab each, bottom (k = 0) to top.
 int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, double h, double tol, int mode, const int* devices, int ndev,
                     int* sweeps_done, double* rms_trace, int trace_cap)
@@ -106,6 +126,14 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
     auto m_hi = [&](int B, int C) { return (nyc * B + nyc - 1 + nzc * C + nzc - 1 + knx - 2) / ta; };
     const uint32_t last_packed = (uint32_t)m_hi(nTj - 1, nTk - 1) | ((uint32_t)(nTj - 1) << 10) | ((uint32_t)(nTk - 1) << 20);
 
+    int mod_d = -1, mod_D = 0; // LSF_SLAB_MODEL (experiment builds): this call's one slab is slab mod_d of mod_D
+#ifdef LSF_EXPERIMENTS
+    if (const char* e = getenv("LSF_SLAB_MODEL")) {
+        if (ndev != 1 || sscanf(e, "%d/%d", &mod_d, &mod_D) != 2 || mod_d < 0 || mod_d >= mod_D || mod_D > nTk)
+            return fail(LSF_ERR_INVALID, "LSF_SLAB_MODEL=d/D needs one device and 0 <= d < D <= tile layers in z");
+    }
+#endif
+    const bool model = mod_D > 0;
     DeviceRestore restore_;
     Slabs S;
     S.s.resize(ndev);
@@ -162,9 +190,10 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
     for (int d = 0; d < ndev; ++d) {
         Slab& b = S.s[d];
         b.device = devices[d];
-        b.tk_lo = (int)((long)nTk * d / ndev), b.tk_hi = (int)((long)nTk * (d + 1) / ndev);
+        const int gd_ = model ? mod_d : d, gD_ = model ? mod_D : ndev; // this slab's place among the slabs of the run
+        b.tk_lo = (int)((long)nTk * gd_ / gD_), b.tk_hi = (int)((long)nTk * (gd_ + 1) / gD_);
         const int k_own_lo = 1 + b.tk_lo * nzc, k_own_hi = std::min(1 + b.tk_hi * nzc, nz); // interior planes [lo, hi)
-        b.ka = d == 0 ? 0 : k_own_lo - 3, b.kb = d == ndev - 1 ? nz : std::min(k_own_hi + 2, nz);
+        b.ka = gd_ == 0 ? 0 : k_own_lo - 3, b.kb = gd_ == gD_ - 1 ? nz : std::min(k_own_hi + 2, nz);
         g_device = b.device;
         if ((rc = ensure_device())) return rc;
         HIPCHK(hipStreamCreateWithFlags(&b.st, hipStreamNonBlocking));
@@ -180,6 +209,7 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
         const int BATCHcap = std::min(DF_BATCH, max_sweeps);
         if ((rc = slab_alloc(b, (void**)&b.tile_done, (size_t)BATCHcap * per_sweep * sizeof(int), fine))) return rc;
         if ((rc = slab_alloc(b, (void**)&b.colsum, (size_t)4 * ncol * sizeof(double), fine))) return rc;
+        HIPCHK(hipMemset(b.colsum, 0, (size_t)4 * ncol * sizeof(double)));
         if ((rc = slab_alloc(b, (void**)&b.trace, (size_t)max_sweeps * sizeof(double), fine))) return rc;
         if ((rc = get_sk_tables(wy, wz, by, &b.tables))) return rc;
         // this slab's tiles per hyperplane: frame C runs along z in sweeps with sk > 0 (C = tk), against it otherwise
@@ -336,6 +366,9 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
             HIPCHK(hipMemsetAsync(b.tile_done, 0, (size_t)ns * per_sweep * sizeof(int), b.st));
             hipLaunchKernelGGL(k_build_order_slab, dim3(nslots), dim3(256), 0, b.st, b.order, (const uint32_t*)b.tiles[0], (const uint32_t*)b.tiles[1],
                                m_poff, m_poff + np + 1, m_tab, m_start, m_base, ns, np);
+#ifdef LSF_EXPERIMENTS
+            if (model) hipLaunchKernelGGL(k_slab_model_preset, dim3(1024), dim3(256), 0, b.st, b.tile_done, b.ctlblk + 16, m_tab, ns, nM, nTj, nTk, b.tk_lo, b.tk_hi);
+#endif
         }
         for (Slab& b : S.s) {
             HIPCHK(hipSetDevice(b.device));
@@ -424,7 +457,8 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
         Slab& b = S.s[d];
         HIPCHK(hipSetDevice(b.device));
         const int k_own_lo = 1 + b.tk_lo * nzc, k_own_hi = std::min(1 + b.tk_hi * nzc, nz);
-        const int g_lo = d == 0 ? 0 : k_own_lo, g_hi = d == ndev - 1 ? nz : k_own_hi - 1; // inclusive
+        const int gd_ = model ? mod_d : d, gD_ = model ? mod_D : ndev;
+        const int g_lo = gd_ == 0 ? 0 : k_own_lo, g_hi = gd_ == gD_ - 1 ? nz : k_own_hi - 1; // inclusive
         const size_t planes = (size_t)(g_hi - g_lo + 1);
         const double* res = b.fld[nsw % nbuf] + (size_t)(g_lo - b.ka) * pl;
         if (tr) {

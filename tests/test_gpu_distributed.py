@@ -108,10 +108,18 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
-    cells = 2 * 4 * 94.0 ** 3
-    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 4 - cells) < 1e-6 * cells  # value = cells of ALL ranks / time
     ent = d["decomposed"]["entries"]
     weak = [e for e in ent if e["scaling"] == "weak"]
+    # N > 1: the headline is the path that communicates (weak-scaling decomposed Jacobi sweep), stated in metric and config; the
+    # replicas of the exact ordering are an entry of their own, and so is the one-GPU rate of the headline's own path
+    assert d["headline_path"] == "decomposed-jacobi-weak" and "block-decomposed Jacobi" in d["metric"] and "Jacobi" in d["config"]["ordering"]
+    assert d["value"] == weak[0]["value"] and d["ms_per_step"] == weak[0]["ms_per_step"] and d["config"]["grid"] == [96, 96, 192]
+    cells = 4 * 94.0 * 94.0 * 190.0
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 4 - cells) < 1e-6 * cells  # value = cells of the whole job / time
+    rep = d["replicas_gs"]
+    cells_rep = 2 * 4 * 94.0 ** 3
+    assert abs(rep["value"] * rep["ms_per_step"] * 1e-3 * 4 - cells_rep) < 1e-6 * cells_rep and "replicas" in rep["note"]
+    assert d["same_path_one_gpu"]["value"] > 0
     strong = [e for e in ent if e["scaling"] == "strong"]
     assert len(weak) == 1 and weak[0]["value"] > 0 and weak[0]["global_grid"] == [96, 96, 192] and weak[0]["dims"] == [1, 1, 2]
     # fixed global grid split over the ranks: non-cubic local blocks (48 owned + 3 ghost points along z, the axis two
