@@ -690,658 +690,9 @@ int reinit_f32_core(float* d_phi, const float* d_phiS_in, int nx, int ny, int nz
     return jacobi_loop<float>(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, false, sweeps_done, rms_trace, trace_cap, st);
 }
 
-// lookup tables of a skewed tile shape (lsf_skew.hpp: sk_fill_tables), built once per shape and device
-int get_sk_tables(int wy, int wz, int by, const uint32_t** out)
-{
-    Ctx& c = ctx();
-    const int key = by * 256 + wy * 16 + wz;
-    auto it = c.sk_tables.find(key);
-    if (it == c.sk_tables.end()) {
-        std::vector<uint32_t> h;
-#define LSF_SK_TAB(WY_, WZ_, BY_)                                                            \
-    do {                                                                                     \
-        using T_ = SkTile<16, WY_, WZ_, BY_>;                                                \
-        h.assign((size_t)T_::REL_WORDS + T_::OFF_WORDS, 0u);                                 \
-        sk_fill_tables<16, WY_, WZ_, BY_>(h.data());                                         \
-    } while (0)
-        LSF_SK_SHAPES(LSF_SK_TAB, wy, wz, by);
-#undef LSF_SK_TAB
-        uint32_t* d = nullptr;
-        HIPCHK(hipMalloc((void**)&d, h.size() * sizeof(uint32_t)));
-        HIPCHK(hipMemcpy(d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        it = c.sk_tables.emplace(key, d).first;
-    }
-    *out = it->second;
-    return LSF_OK;
-}
+#include "lsf_host_gs.hpp"
 
-// LSF_GS_SCHEDULE selects how the exact Gauss-Seidel tile graph is executed (all are bit-identical):
-//   "dataflow" (default) skewed tiles, one launch per batch of sweeps, dependencies resolved in the kernel
-//   "skew"               skewed tiles, one launch per time slot (also the fallback of a dataflow launch that timed out)
-//   "slots"              box tiles, overlapped sweeps, one launch per time slot
-//   "planes"             box tiles, one launch per tile hyperplane, one sweep at a time
-thread_local int g_schedule_override = -2; // set while a call is repeated on the slot schedule (see below)
-int gs_schedule()
-{
-    if (g_schedule_override != -2) return g_schedule_override;
-    const char* e = getenv("LSF_GS_SCHEDULE");
-    if (e && std::strcmp(e, "planes") == 0) return 0;
-    if (e && std::strcmp(e, "skew") == 0) return 3;
-    if (e && std::strcmp(e, "slots") == 0) return 1;
-    if (e && std::strcmp(e, "dataflow") == 0) return 5;
-    return -1; // unset: dataflow on skewed tiles
-}
-
-// ---------------------------------------------------------------------------------------------
-// Exact-GS reinit: the dataflow launch (default) and the slot-synchronous schedules with overlapped sweeps.
-// Slot schedules: one launch per time slot; a slot holds the tile hyperplane P = slot - start[g] of every sweep g in
-// flight (at most three).  start[] obeys two spacing rules -- start[g] >= start[g-1] + H(raster flip) so that a tile's
-// neighbours finished the sweep before, and start[g] >= start[g-3] + nPlanes + 1 so that the stop verdict of the sweep
-// whose buffer is overwritten is known -- hence every predecessor of a task ran in an earlier launch.  The BC, the
-// wall mirror and the RMS epilogue are fused into the tile kernel.
-// ---------------------------------------------------------------------------------------------
-int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int nz, int iter, double dx, double h,
-                     double tol, int mode, int first_raster, int* sweeps_done, double* rms_trace, int trace_cap,
-                     hipStream_t st)
-{
-    int rc = check_dims(nx, ny, nz);
-    if (rc) return rc;
-    const bool strict = (mode & LSF_ARITH_STRICT) != 0;
-    Ctx& c = ctx();
-    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
-    const int max_sweeps = iter + 1;
-    const int ta = gs_ta();
-    int nyc = gs_ny();
-    int sched = gs_schedule();
-    // Default: skewed tiles (lsf_skew.hpp), 2 x 2 wavefronts each, dependencies resolved in the kernel (`dataflow`,
-    // one launch per batch of sweeps).  Measured per sweep: dataflow / slot launches on skewed tiles (`skew`) / slot
-    // launches on the box tiles of lsf_boxtile.hpp (`slots`): 256^3 0.97 / 1.24 / 1.75 ms, 512^3 3.25 / 4.61 / 6.83 ms,
-    // 1024^3 24.7 / 25.2 / 38.0 ms.
-    if (sched < 0) sched = 5;
-    bool persist = sched == 5; // k_reinit_gs_stream / k_reinit_gs_persist
-    const bool stream = gs_stream();
-    if (persist) sched = 3;
-    // skewed tiles need TA = 16, NY = 5 and at least two interior cells per axis
-    const bool skew = sched == 3 && ta == 16 && nyc == 5 && nx >= 3 && ny >= 3 && nz >= 3;
-    persist = persist && skew;
-    int wy = 1, wz = 1, by = 5, nzc = 4;
-    if (skew) {
-        gs_skew_w(std::min(nx, ny), nz, strict, &wy, &wz, &by); // (the dataflow launch may swap x and y)
-        nyc = by * wy, nzc = 4 * wz; // rows of a tile in y and z
-    }
-    // Dataflow launch: the kernel marches along ITS x axis; run it on the x <-> y transposed field so that the march axis
-    // is the reference's y, the axis the raster cycle flips in six of its eight transitions (a flip of the march axis
-    // spaces two sweeps by n / 16 time slots, a flip of a cross-section axis by n / 16 + its number of tiles: 70 instead of
-    // 95 slots per sweep at 512^3).  Costs nbuf + 1 work fields (none of them the caller's) and three transpositions per
-    // call; skipped when that does not fit.
-    int nbuf = persist ? gs_nbuf() : 3;
-    bool tr = persist && gs_march() == 1;
-    if (tr) {
-        size_t need = 0, fr = 0, tot = 0;
-        for (Slot q : {S_PONG, S_PONG2, S_PONG3, S_PONG4, S_PHIS})
-            if (q != S_PONG4 || nbuf == 4) need += c.slot[q].bytes >= n * sizeof(double) ? 0 : n * sizeof(double);
-        HIPCHK(hipMemGetInfo(&fr, &tot));
-        if (need + (2ull << 30) > fr) tr = false, nbuf = 3;
-    }
-    const int knx = tr ? ny : nx, kny = tr ? nx : ny; // the kernel's view of the grid
-    auto ksign = [&](int raster, int* out) {           // raster signs in the kernel's axis order
-        const int* r = RASTER_SIGN[raster & 7];
-        out[0] = tr ? r[1] : r[0], out[1] = tr ? r[0] : r[1], out[2] = r[2];
-    };
-    const Slot pong[4] = {S_PONG, S_PONG2, S_PONG3, S_PONG4};
-    for (int q = 0; q < (tr ? nbuf : nbuf - 1); ++q)
-        if ((rc = ws(c.slot[pong[q]], n * sizeof(double)))) return rc;
-    const double* d_phiS = d_phiS_in;
-    if (tr) {
-        if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
-        const dim3 tg(cdiv(nx + 1, 32), cdiv(ny + 1, 32), (unsigned)std::min(nz + 1, 1024));
-        // phiS = phi on entry (subs.f90:731): one pass over phi writes both transposed copies unless the caller has its own
-        hipLaunchKernelGGL(k_transpose_xy, tg, dim3(256), 0, st, (const double*)d_phi, (double*)c.slot[S_PONG].p, nx + 1, ny + 1,
-                           (long)(nz + 1), d_phiS_in ? (double*)nullptr : (double*)c.slot[S_PHIS].p);
-        if (d_phiS_in)
-            hipLaunchKernelGGL(k_transpose_xy, tg, dim3(256), 0, st, d_phiS_in, (double*)c.slot[S_PHIS].p, nx + 1, ny + 1,
-                               (long)(nz + 1), (double*)nullptr);
-        d_phiS = (const double*)c.slot[S_PHIS].p;
-    } else if (!d_phiS) {
-        if ((rc = ws(c.slot[S_PHIS], n * sizeof(double)))) return rc;
-        HIPCHK(hipMemcpyAsync(c.slot[S_PHIS].p, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        d_phiS = (const double*)c.slot[S_PHIS].p;
-    }
-    const bool overlap = sched != 0; // "planes": one sweep at a time (start[g+1] = start[g] + nPlanes)
-    const int nTi = cdiv(knx - 1, ta), nTj = cdiv(kny - 1, nyc), nTk = cdiv(nz - 1, nzc);
-    const int nT[3] = {nTi, nTj, nTk};
-    TileList* tl = nullptr;
-    if (skew) rc = get_skew_tiles(knx - 1, nTj, nTk, ta, nyc, nzc, &tl);
-    else rc = get_tiles(nTi, nTj, nTk, &tl);
-    if (rc) return rc;
-    const int np = (int)tl->off.size() - 1;
-    if ((rc = ws(c.slot[S_CTL], 64))) return rc;
-    if ((rc = ws(c.slot[S_TRACE], (size_t)max_sweeps * sizeof(double)))) return rc;
-    if ((rc = ws(c.slot[S_COLSUM], (size_t)4 * nTj * nTk * sizeof(double)))) return rc;
-    int* ctl = (int*)c.slot[S_CTL].p;
-    HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
-    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(ctl + 4), 0x7fffffff, 1, st)); // ctl[4]: never 0 (k_reinit_gs_persist: the flag of an absent upstream tile)
-
-    // nbuf field buffers in rotation: sweep g overwrites the result of sweep g - nbuf, so it has to wait for the
-    // stop verdict of that sweep only, and consecutive sweeps are spaced by the raster-flip rule alone.
-    GsArgs fa;
-    std::memset(&fa, 0, sizeof fa);
-    if (tr) {
-        for (int q = 0; q < nbuf; ++q) fa.buf[q] = (double*)c.slot[pong[q]].p;
-    } else {
-        fa.buf[0] = d_phi;
-        for (int q = 1; q < nbuf; ++q) fa.buf[q] = (double*)c.slot[pong[q - 1]].p;
-    }
-    fa.nbuf = nbuf;
-    fa.quirk_axis = tr ? 0 : 1; // subs.f90:576 concerns the reference's y axis
-    fa.phiS = d_phiS;
-    fa.nx = knx, fa.ny = kny, fa.nz = nz, fa.nTi = nTi, fa.nTj = nTj, fa.nTk = nTk;
-    fa.dx = dx, fa.h = h;
-    fa.colsum = (double*)c.slot[S_COLSUM].p;
-    fa.trace = (double*)c.slot[S_TRACE].p;
-    fa.trace_cap = max_sweeps;
-    fa.den = rms_denominator(nx, ny, nz);
-    fa.tol = tol;
-    fa.ctl = ctl;
-    fa.nTiles = (long)nTi * nTj * nTk;
-    fa.last_packed = tl->last;
-    if (skew && !getenv("LSF_GS_NO_TABLES") && (rc = get_sk_tables(wy, wz, by, &fa.tables))) return rc;
-
-    // start slot of sweep g, generated on demand (slot schedules; never transposed)
-    std::vector<long> start{0};
-    auto start_of = [&](int g) -> long {
-        while ((int)start.size() <= g) {
-            const int q = (int)start.size();
-            const int* da = RASTER_SIGN[(first_raster + q - 1) & 7];
-            const int* db = RASTER_SIGN[(first_raster + q) & 7];
-            long H = 2;
-            for (int ax = 0; ax < 3; ++ax)
-                if (da[ax] != db[ax]) H += nT[ax] - 1;
-            if (skew) H = skew_spacing(da, db, nx, ny, nz, ta, nyc, nzc);
-            long s0 = start[q - 1] + H;
-            if (q >= 3) s0 = std::max(s0, start[q - 3] + np + 1);
-            if (!overlap) s0 = start[q - 1] + np;
-            start.push_back(s0);
-        }
-        return start[g];
-    };
-    int host_ctl[4] = {0, 0, 0, 0};
-    prof_begin();
-    long launches = 0;
-    bool marked = false;
-    if (persist) {
-        // Dataflow schedule (k_reinit_gs_persist): one launch per batch of up to DF_BATCH = 256 sweeps, one block per tile,
-        // dependencies resolved in the kernel.  What depends on the grid, the raster phase of the batch's first sweep and the
-        // number of sweeps (start slots, entries per slot, spacing table) is small and cached on the device; the task list
-        // itself is rebuilt by k_build_order in front of every launch.
-        const long ntiles = tl->off[np];
-        // sweeps per launch: up to 256 (a batch costs about one sweep time of fill and drain, measured 26.6 / 50.0 / 73.9 /
-        // 97.4 ms for 8 / 16 / 24 / 32 sweeps at 512^3; 256^3 to convergence: 0.645 -> 0.628 ms per sweep against 64 per
-        // launch), fewer on very large grids so that the task list stays below 512 MB; a multiple of 8 keeps the raster
-        // phase, hence the cached plan, the same
-        // (calls of up to 64 sweeps keep the 64-sweep layout of their control arrays: what bench.py times)
-        int BATCH = (int)std::max<long>(8, std::min<long>(max_sweeps <= 64 ? 64 : DF_BATCH, (512L << 20) / (ntiles * 8) / 8 * 8));
-        if (const char* e = getenv("LSF_DF_BATCH")) BATCH = std::max(8, std::min(BATCH, atoi(e) / 8 * 8)); // test hook: batch boundaries
-        const int nM = (knx - 2 + nyc * nTj - 1 + nzc * nTk - 1) / ta + 1; // m_max + 1 (get_skew_tiles)
-        const size_t tile_flags = (size_t)BATCH * nM * nTj * nTk;
-        // hyperplane counters | 4 KB | leading-hyperplane counters of the sweeps | 4 KB | ticket: the three are polled / updated at
-        // very different rates (see DF_PAD)
-        constexpr size_t DF_PAD = LSF_DF_PAD;
-        if ((rc = ws(c.slot[S_PLANECNT], ((size_t)BATCH * np + 2 * DF_PAD + BATCH + 16) * sizeof(int)))) return rc;
-        if ((rc = ws(c.slot[S_BFLAG], tile_flags * sizeof(int)))) return rc;
-        if ((rc = ws(c.slot[S_ORDER], (size_t)std::min(BATCH, max_sweeps) * ntiles * sizeof(uint2)))) return rc;
-        int* d_cnt = (int*)c.slot[S_PLANECNT].p;
-        int* d_done = d_cnt + (size_t)BATCH * np + DF_PAD;
-        int* d_ticket = d_done + BATCH + DF_PAD;
-        unsigned long long* d_dbg = nullptr;
-        // per-tile wait / work times of the dataflow launch: three contended atomics per tile (+70 % run time), so its own
-        // switch and not part of LSF_TRACE, whose per-call times are meant to be read as measurements
-        if (getenv("LSF_TRACE_TILES")) {
-            if ((rc = ws(c.slot[S_DBG], 128))) return rc;
-            d_dbg = (unsigned long long*)c.slot[S_DBG].p;
-        }
-        if (c.plans.size() > 64) { // bounded: every earlier call has synchronised its stream before returning
-            for (auto& kv : c.plans)
-                if (kv.second.d_meta) HIPCHK(hipFree(kv.second.d_meta));
-            c.plans.clear();
-        }
-        for (int g0 = 0; g0 < max_sweeps; g0 += BATCH) {
-            const int ns = std::min(BATCH, max_sweeps - g0), phase = (first_raster + g0) & 7;
-            const std::array<int, 6> key{knx, kny, nz, phase, ns, wy * 16 + wz + 256 * (int)tr + 1024 * nbuf + 8192 * by};
-            auto it = c.plans.find(key);
-            if (it == c.plans.end()) {
-                BatchPlan bp;
-                std::vector<int> st0(ns, 0), tab(4 * DF_BATCH, 0);
-                for (int q = 0; q < ns; ++q) {
-                    int da[3], db[3];
-                    ksign(phase + q, db);
-                    for (int ax = 0; ax < 3; ++ax) tab[4 * q + ax] = db[ax];
-                    if (q == 0) continue;
-                    ksign(phase + q - 1, da);
-                    const long H = skew_spacing(da, db, knx, kny, nz, ta, nyc, nzc);
-                    tab[4 * q + 3] = (int)H;
-                    long s0 = st0[q - 1] + H;
-                    if (q >= nbuf) s0 = std::max<long>(s0, st0[q - nbuf] + np + 1); // list order respects condition (c)
-                    st0[q] = (int)s0;
-                }
-                bp.nslots = st0[ns - 1] + np;
-                // entries per slot: hyperplane slot - st0[q] of every sweep q in flight
-                std::vector<unsigned> base((size_t)bp.nslots + 1, 0u);
-                int lo_s = 0;
-                for (int slot = 0; slot < bp.nslots; ++slot) {
-                    unsigned cnt = 0;
-                    for (int q = lo_s; q < ns && st0[q] <= slot; ++q) {
-                        const int P = slot - st0[q];
-                        if (P < np) cnt += (unsigned)(tl->off[P + 1] - tl->off[P]);
-                    }
-                    base[slot + 1] = base[slot] + cnt;
-                    while (lo_s < ns && st0[lo_s] + np <= slot + 1) ++lo_s;
-                }
-                bp.total = (long)base[bp.nslots];
-                if (bp.total != (long)ns * ntiles) return fail(LSF_ERR_HIP, "internal: batch plan does not cover every tile");
-                std::vector<int> meta;
-                meta.insert(meta.end(), st0.begin(), st0.end());
-                for (unsigned v : base) meta.push_back((int)v);
-                while (meta.size() % 4) meta.push_back(0); // the kernels read a sweep's four table entries as one 16-byte load
-                meta.insert(meta.end(), tab.begin(), tab.end());
-                for (int P = 0; P < np; ++P) meta.push_back(tl->off[P + 1] - tl->off[P]);
-                meta.insert(meta.end(), tl->off.begin(), tl->off.end());
-                HIPCHK(hipMalloc((void**)&bp.d_meta, meta.size() * sizeof(int)));
-                HIPCHK(hipMemcpy(bp.d_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
-                it = c.plans.emplace(key, bp).first;
-            }
-            const BatchPlan& bp = it->second;
-            const int* m_start = bp.d_meta;
-            const unsigned* m_base = (const unsigned*)(bp.d_meta + ns);
-            const int* m_tab = bp.d_meta + (ns + bp.nslots + 1 + 3) / 4 * 4; // 16-byte aligned (hipMalloc aligns the block)
-            const int* m_psize = m_tab + 4 * DF_BATCH;
-            const int* m_poff = m_psize + np;
-            if (!marked) prof_mark(st), marked = true; // the timed region starts once the first plan exists
-            HIPCHK(hipMemsetAsync(d_cnt, 0, ((size_t)BATCH * np + 2 * DF_PAD + BATCH + 16) * sizeof(int), st)); // counters, ticket
-            HIPCHK(hipMemsetAsync(c.slot[S_BFLAG].p, 0, (size_t)ns * nM * nTj * nTk * sizeof(int), st));
-            if (d_dbg) HIPCHK(hipMemsetAsync(d_dbg, 0, 128, st));
-            hipLaunchKernelGGL(k_build_order, dim3(bp.nslots), dim3(256), 0, st, (uint2*)c.slot[S_ORDER].p, (const uint32_t*)tl->d,
-                               m_poff, m_start, m_base, ns, np);
-            fa.sweep_tab = m_tab, fa.plane_size = m_psize;
-            fa.order = (const uint2*)c.slot[S_ORDER].p, fa.total = bp.total;
-            fa.nsweeps = ns, fa.g0 = g0, fa.np = np;
-            fa.plane_cnt = d_cnt, fa.planes_done = d_done, fa.ticket = d_ticket;
-            fa.tile_done = (int*)c.slot[S_BFLAG].p, fa.nM = nM;
-            fa.dbg = d_dbg;
-            fa.timeout_ticks = FLOW_TIMEOUT_TICKS;
-            if (const char* e = getenv("LSF_GS_TIMEOUT_TICKS")) fa.timeout_ticks = strtoull(e, nullptr, 10); // test hook
-            // one block per tile; a block takes its tile from the ticket counter, so the grid only has to be large enough
-            // (2-D: gridDim.x * blockDim.x must stay below 2^32)
-            const dim3 grid((unsigned)std::min<long>(fa.total, 65536), (unsigned)((fa.total + 65535) / 65536));
-#define LSF_LAUNCH_DF(WY_, WZ_, BY_)                                                                             \
-    do {                                                                                                         \
-        if (strict) hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, BY_, true>), grid, dim3(64 * WY_ * WZ_), 0, st, fa); \
-        else hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, BY_, false>), grid, dim3(64 * WY_ * WZ_), 0, st, fa);       \
-    } while (0)
-            // Default: one block per tile (k_reinit_gs_persist).  LSF_GS_STREAM=1: the launch with column continuation
-            // (k_reinit_gs_stream: resident blocks that loop over tiles and carry on down a tile column; lsf_stream.hip);
-            // LSF_GS_CONT=0: that loop without continuation (every tile acquired from the list).
-            if (stream) {
-                fa.cont_on = gs_cont();
-                int cus = 0;
-                HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device));
-                const hipError_t le = (hipError_t)launch_gs_stream(wy, wz, by, strict, st, fa, cus, nullptr);
-                if (le != hipSuccess) return fail(LSF_ERR_HIP, std::string("k_reinit_gs_stream: ") + hipGetErrorString(le));
-            } else {
-                LSF_SK_SHAPES(LSF_LAUNCH_DF, wy, wz, by);
-            }
-#undef LSF_LAUNCH_DF
-            ++launches;
-            if (g0 + BATCH < max_sweeps || d_dbg) { // stop flag between batches (later batches would exit at once anyway)
-                HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
-                if (d_dbg) {
-                    unsigned long long hd[16];
-                    HIPCHK(hipMemcpy(hd, d_dbg, sizeof hd, hipMemcpyDeviceToHost));
-                    if (stream)
-                        fprintf(stderr, "[lsf] column continuation: %llu of %llu tiles continued; not continued: end of column %llu, previous sweep not past %llu, "
-                                "cross tiles unclaimed %llu, claim lost %llu\n", hd[8], hd[2], hd[9], hd[10], hd[11], hd[12]);
-#ifdef LSF_EXPERIMENTS
-                    if (hd[7])
-                        fprintf(stderr, "[lsf] tile phases (us per tile): row table %.2f, load %.2f, march %.2f, write back %.2f\n",
-                                hd[3] / 100.0 / hd[7], hd[4] / 100.0 / hd[7], hd[5] / 100.0 / hd[7], hd[6] / 100.0 / hd[7]);
-#endif
-                    fprintf(stderr, "[lsf] dataflow batch of %d sweeps: %llu tiles, per tile: take+wait %.2f us, work+publish %.2f us\n", ns,
-                            hd[2], hd[2] ? hd[0] / 100.0 / hd[2] : 0.0, hd[2] ? hd[1] / 100.0 / hd[2] : 0.0);
-                }
-                if (host_ctl[0]) break;
-            }
-        }
-    }
-    if (!marked) prof_mark(st);
-    const bool slots_loop = !persist;
-#ifdef LSF_EXPERIMENTS
-    if (slots_loop && skew && getenv("LSF_TRACE_TILES")) {
-        if ((rc = ws(c.slot[S_DBG], 64))) return rc;
-        fa.dbg = (unsigned long long*)c.slot[S_DBG].p;
-        HIPCHK(hipMemsetAsync(fa.dbg, 0, 64, st));
-    }
-#endif
-    auto launch_tiles = [&](int grid, hipStream_t s_) {
-        if (skew) {
-#define LSF_LAUNCH_SKEW(WY_, WZ_, BY_)                                                                                     \
-    do {                                                                                                                   \
-        if (strict)                                                                                                        \
-            hipLaunchKernelGGL((k_reinit_gs_skew<16, WY_, WZ_, BY_, true>), dim3(grid), dim3(64 * WY_ * WZ_), 0, s_, fa);  \
-        else                                                                                                               \
-            hipLaunchKernelGGL((k_reinit_gs_skew<16, WY_, WZ_, BY_, false>), dim3(grid), dim3(64 * WY_ * WZ_), 0, s_, fa); \
-    } while (0)
-            LSF_SK_SHAPES(LSF_LAUNCH_SKEW, wy, wz, by);
-#undef LSF_LAUNCH_SKEW
-            return;
-        }
-#define LSF_LAUNCH_SLOT(TA_, NY_, ST_) \
-    hipLaunchKernelGGL((k_reinit_gs_box<TA_, NY_, ST_>), dim3(grid), dim3(64), 0, s_, fa)
-#define LSF_LAUNCH_SLOT_NY(TA_, ST_)           \
-    do {                                       \
-        if (nyc == 5) LSF_LAUNCH_SLOT(TA_, 5, ST_); \
-        else LSF_LAUNCH_SLOT(TA_, 4, ST_);     \
-    } while (0)
-        if (strict) {
-            if (ta == 16) LSF_LAUNCH_SLOT_NY(16, true);
-            else LSF_LAUNCH_SLOT_NY(32, true);
-        } else {
-            if (ta == 16) LSF_LAUNCH_SLOT_NY(16, false);
-            else LSF_LAUNCH_SLOT_NY(32, false);
-        }
-#undef LSF_LAUNCH_SLOT_NY
-#undef LSF_LAUNCH_SLOT
-    };
-    int lo = 0;            // first sweep that still has hyperplanes to launch
-    int epilogues = 0;     // sweeps whose last hyperplane has been launched
-    bool stop = false;
-    for (long slot = 0; slots_loop && !stop && lo < max_sweeps; ++slot) {
-        int nseg = 0, grid = 0;
-#ifdef LSF_EXPERIMENTS // never in the product library: profiles/micro builds its own copy with -DLSF_EXPERIMENTS
-        // timing experiment only (results are wrong): every tile of a sweep in ONE launch = the pure work term
-        static const bool nodeps = getenv("LSF_GS_NODEPS_EXPERIMENT") != nullptr;
-#else
-        constexpr bool nodeps = false;
-#endif
-        for (int g = lo; g < max_sweeps && start_of(g) <= slot; ++g) {
-            const long P = slot - start_of(g);
-            if (P >= np) continue;
-            int cnt = tl->off[P + 1] - tl->off[P];
-            if (nodeps) cnt = P == 0 ? tl->off[np] : 0;
-            if (cnt <= 0) continue;
-            if (nseg == 4) return fail(LSF_ERR_HIP, "internal: more than four sweeps in flight");
-            fa.seg_tiles[nseg] = tl->d + tl->off[P];
-            grid += cnt;
-            fa.seg_end[nseg] = grid;
-            fa.seg_g[nseg] = g;
-            for (int ax = 0; ax < 3; ++ax) fa.seg_sign[nseg][ax] = RASTER_SIGN[(first_raster + g) & 7][ax];
-            ++nseg;
-            if (P == np - 1) ++epilogues;
-        }
-        while (lo < max_sweeps && start_of(lo) + np <= slot + 1) ++lo;
-        for (int q = nseg; q < 4; ++q) fa.seg_end[q] = grid;
-        if (grid > 0) {
-            launch_tiles(grid, st);
-            ++launches;
-        }
-        if (epilogues >= CHECK_EVERY && lo < max_sweeps) {
-            epilogues = 0;
-            HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (host_ctl[0]) stop = true;
-        }
-    }
-    prof_mark(st);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-#ifdef LSF_EXPERIMENTS
-    if (fa.dbg) {
-        unsigned long long hd[8];
-        HIPCHK(hipMemcpy(hd, fa.dbg, sizeof hd, hipMemcpyDeviceToHost));
-        if (hd[7])
-            fprintf(stderr, "[lsf] tile phases (us per tile, %llu tiles): row table %.2f, load %.2f, march %.2f, write back %.2f\n", hd[7],
-                    hd[3] / 100.0 / hd[7], hd[4] / 100.0 / hd[7], hd[5] / 100.0 / hd[7], hd[6] / 100.0 / hd[7]);
-    }
-#endif
-    const int nsw = host_ctl[1];
-    if (g_prof.on && g_prof.ev.size() >= 2) {
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, g_prof.ev[0], g_prof.ev[1]);
-        g_prof.sweep_ms = ms;
-        g_prof.bc_ms = g_prof.finish_ms = 0;
-        g_prof.sweeps = nsw;
-        g_prof.sweep_launches = launches;
-        if (skew) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "%s<16,%d,%d,%d,%s>", !slots_loop ? (stream ? "k_reinit_gs_stream" : "k_reinit_gs_persist") : "k_reinit_gs_skew",
-                           wy, wz, by, strict ? "true" : "false");
-        else snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "k_reinit_gs_box<%d,%d,%s>", ta, nyc, strict ? "true" : "false");
-        g_prof.kernel = g_prof.kernel_buf;
-    }
-    if (host_ctl[2] == 2) {
-        // A block of the dataflow launch waited 4 s for a predecessor: never observed, but the launch relies on
-        // nothing else going wrong with the device.  When the call's input is still around (the transposed launch never
-        // touches the caller's field; otherwise phiS was copied from it on entry) repeat the call on the slot schedule,
-        // whose dependencies are launch boundaries.
-        if ((tr || !d_phiS_in) && g_schedule_override == -2) {
-            fprintf(stderr, "[lsf] dataflow launch timed out; repeating the call with slot launches\n");
-            if (!tr) HIPCHK(hipMemcpyAsync(d_phi, c.slot[S_PHIS].p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-            g_schedule_override = 3;
-            rc = reinit_slot_core(d_phi, d_phiS_in, nx, ny, nz, iter, dx, h, tol, mode, first_raster, sweeps_done, rms_trace,
-                                  trace_cap, st);
-            g_schedule_override = -2;
-            return rc;
-        }
-        return fail(LSF_ERR_HIP, "exact-GS dataflow schedule timed out waiting for a tile");
-    }
-    if (tr) { // back to the caller's layout: the kernel's field has extents (ny + 1, nx + 1, nz + 1)
-        const dim3 tg(cdiv(ny + 1, 32), cdiv(nx + 1, 32), (unsigned)std::min(nz + 1, 1024));
-        hipLaunchKernelGGL(k_transpose_xy, tg, dim3(256), 0, st, (const double*)fa.buf[nsw % nbuf], d_phi, ny + 1, nx + 1,
-                           (long)(nz + 1), (double*)nullptr);
-    } else if (fa.buf[nsw % nbuf] != d_phi)
-        HIPCHK(hipMemcpyAsync(d_phi, fa.buf[nsw % nbuf], n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (rms_trace && trace_cap > 0 && nsw > 0)
-        HIPCHK(hipMemcpyAsync(rms_trace, c.slot[S_TRACE].p, sizeof(double) * (size_t)std::min(nsw, trace_cap),
-                              hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (sweeps_done) *sweeps_done = nsw;
-    if (host_ctl[2] == 1) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, subs.f90:926)");
-    return LSF_OK;
-}
-
-int narrowband_core(const double* d_phi, int32_t* d_nb, int32_t* d_sb, size_t n, double dx, hipStream_t st)
-{
-    const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_narrowband, dim3(grid), dim3(256), 0, st, d_phi, d_nb, d_sb, (long)n, dx);
-    HIPCHK(hipGetLastError());
-    return LSF_OK;
-}
-
-constexpr int MM_MAX_FIX = 32;   // most fix passes ever enqueued per min/max iteration
-constexpr int MM_FIX_START = 16; // adaptive mode: passes enqueued per iteration until the first host check
-// how the exact ordering of the min/max flow is produced
-enum MinmaxExact { MM_TILES = 0, MM_FP_ADAPTIVE = 1, MM_FP_FULL = 2 };
-
-int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int nz, int iter, double dx,
-                     double h1, double tol, int mode, int* iters_done, double* rms_trace, int trace_cap,
-                     hipStream_t st, int exact_mode, bool* inexact)
-{
-    int rc = check_dims(nx, ny, nz);
-    if (rc) return rc;
-    if (iter < 0) return fail(LSF_ERR_INVALID, "iter must be >= 0");
-    const int order = mode & LSF_ORDER_MASK;
-    if (order != LSF_ORDER_GS && order != LSF_ORDER_JACOBI) return fail(LSF_ERR_INVALID, "unknown ordering");
-    if (!d_phi || !d_nb || !d_sb) return fail(LSF_ERR_INVALID, "NULL field");
-    Ctx& c = ctx();
-    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
-    if ((rc = ws(c.slot[S_PONG], n * sizeof(double)))) return rc;
-    if ((rc = ws(c.slot[S_CTL], 64))) return rc;
-    if ((rc = ws(c.slot[S_TRACE], (size_t)std::max(iter, 1) * sizeof(double)))) return rc;
-    int* ctl = (int*)c.slot[S_CTL].p;
-    double* d_trace = (double*)c.slot[S_TRACE].p;
-    HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
-
-    TileList* tl = nullptr;
-    int nTi = 0, nTj = 0, nTk = 0, jblocks = 0;
-    long n_part;
-    const bool fixed_point = order == LSF_ORDER_GS && exact_mode != MM_TILES;
-    const long fp_blocks = (long)((n + MM_CH - 1) / MM_CH);  // blocks of the scan
-    const long fp_chunks = (long)((n + MM_SUB - 1) / MM_SUB); // chunks: flags, stamps, RMS partials
-    int *bflag = nullptr, *chg = nullptr, *stamp = nullptr;
-    constexpr size_t CHG_BYTES = (MM_MAX_FIX + 1) * sizeof(int);
-    double* part2 = nullptr;
-    if (fixed_point) {
-        n_part = fp_chunks;
-        if ((rc = ws(c.slot[S_BFLAG], (size_t)fp_chunks * sizeof(int)))) return rc;
-        if ((rc = ws(c.slot[S_CHG], CHG_BYTES))) return rc;
-        if ((rc = ws(c.slot[S_STAMP], (size_t)fp_chunks * sizeof(int)))) return rc;
-        if ((rc = ws(c.slot[S_PART2], 256 * sizeof(double)))) return rc;
-        bflag = (int*)c.slot[S_BFLAG].p;
-        chg = (int*)c.slot[S_CHG].p;
-        stamp = (int*)c.slot[S_STAMP].p;
-        HIPCHK(hipMemsetAsync(stamp, 0, (size_t)fp_chunks * sizeof(int), st));
-        part2 = (double*)c.slot[S_PART2].p;
-    } else if (order == LSF_ORDER_GS) {
-        nTi = cdiv(nx + 1, MM_TA), nTj = cdiv(ny + 1, 8), nTk = cdiv(nz + 1, 8);
-        if ((rc = get_tiles(nTi, nTj, nTk, &tl))) return rc;
-        n_part = (long)nTi * nTj * nTk;
-    } else {
-        jblocks = (int)std::min<size_t>((n + 255) / 256, 8192);
-        n_part = jblocks;
-    }
-    if ((rc = ws(c.slot[S_PART], (size_t)n_part * sizeof(double)))) return rc;
-    double* part = (double*)c.slot[S_PART].p;
-    const double den = rms_denominator(nx, ny, nz);
-
-    double* bufs[2] = {d_phi, (double*)c.slot[S_PONG].p};
-    int host_ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const char* tfp = getenv("LSF_TRACE_MINMAX");
-    const bool trace_fp = tfp && atoi(tfp) != 0;
-    // Fix passes enqueued per iteration.  A pass that finds the fixed point certified returns at once, but an empty
-    // launch still costs ~6 us, so the count follows what the field needs (ctl[4] = most passes that changed cells,
-    // read with the stop flag every CHECK_EVERY iterations): three times that plus four.  Too few -> ctl[3], the
-    // caller repeats the call with MM_MAX_FIX passes.  Large grids skip the adaptation (minmax_core): their chains of
-    // sign flips grow fast (1024^3 two spheres: 4, 7, 9, 16 passes in iterations 4..8 of a call) and 32 launches are
-    // 4 % of an iteration there.
-    int cap = exact_mode == MM_FP_FULL ? MM_MAX_FIX : MM_FIX_START;
-    if (const char* e = getenv("LSF_MINMAX_FIX_START")) // test hook: start with too few passes to exercise the rerun
-        if (exact_mode == MM_FP_ADAPTIVE) cap = std::min(MM_MAX_FIX, std::max(1, atoi(e)));
-    for (int it = 0; it < iter; ++it) { // DO n = 1,iter (set3d.f90:394)
-        const double* A = bufs[it & 1];
-        double* B = bufs[(it + 1) & 1];
-        const int32_t* mask = it == 0 ? d_nb : nullptr;
-        if (fixed_point) {
-            HIPCHK(hipMemsetAsync(chg, 0, CHG_BYTES, st));
-            const dim3 g((unsigned)fp_blocks), b(256);
-            const dim3 gwide((unsigned)std::min<long>(cdiv(fp_chunks, 64), 4096)), gthin((unsigned)std::min<long>(cdiv(fp_chunks, 64), 1024));
-            const int epoch0 = it * (MM_MAX_FIX + 1) + 1; // stamps of this iteration: epoch0+1 .. epoch0+MM_MAX_FIX
-            hipLaunchKernelGGL((k_minmax_fp<0>), g, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, stamp, fp_blocks, 0, 0,
-                               (const int*)nullptr, (int*)nullptr, part, ctl);
-            for (int f = 0; f < cap; ++f)
-                hipLaunchKernelGGL((k_minmax_fp<1>), f < 3 ? gwide : gthin, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag,
-                                   stamp, fp_chunks, epoch0 + f, f == 0 ? 1 : 0,
-                                   f == 0 ? (const int*)nullptr : (const int*)(chg + f - 1), chg + f, part, ctl);
-            // pass 2 also records how many fix passes changed cells (first = cap) and flags an uncertified iteration
-            hipLaunchKernelGGL((k_minmax_fp<2>), gwide, b, 0, st, A, B, mask, nx, ny, nz, dx, h1, bflag, stamp, fp_chunks, 0,
-                               cap, (const int*)(chg + cap - 1), (int*)nullptr, part, ctl);
-            hipLaunchKernelGGL(k_reduce_slices, dim3(256), dim3(256), 0, st, (const double*)part, fp_chunks, part2);
-            hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, (const double*)part2, 256L, den, tol, d_trace,
-                               std::max(iter, 1), ctl);
-        } else if (order == LSF_ORDER_GS) {
-            const int nplanes = (int)tl->off.size() - 1;
-            for (int P = 0; P < nplanes; ++P) {
-                const int cnt = tl->off[P + 1] - tl->off[P];
-                if (cnt <= 0) continue;
-                hipLaunchKernelGGL((k_minmax_gs_plane<MM_TA>), dim3(cnt), dim3(64), 0, st, A, B, mask, nx, ny, nz,
-                                   tl->d + tl->off[P], nTi, nTj, nTk, dx, h1, part, ctl);
-            }
-        } else {
-            hipLaunchKernelGGL(k_minmax_jacobi, dim3(jblocks), dim3(256), 0, st, A, B, mask, nx, ny, nz, dx, h1, part,
-                               ctl);
-        }
-        if (!fixed_point)
-            hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, part, n_part, den, tol, d_trace, std::max(iter, 1),
-                               ctl);
-        if (fixed_point && trace_fp) {
-            int hc[MM_MAX_FIX + 1] = {0};
-            HIPCHK(hipMemcpyAsync(hc, chg, sizeof hc, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            fprintf(stderr, "[lsf] min/max iteration %d: chunks changed per fix pass:", it + 1);
-            for (int f = 0; f < MM_MAX_FIX; ++f) fprintf(stderr, " %d", hc[f]);
-            fprintf(stderr, "\n");
-        }
-        // the adaptive pass count looks at the device early (after iterations 1, 2 and 4), then with the stop flag
-        const bool early = fixed_point && exact_mode == MM_FP_ADAPTIVE && (it == 0 || it == 1 || it == 3);
-        if (((it + 1) % CHECK_EVERY == 0 || early) && it + 1 < iter) {
-            HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (host_ctl[0] || host_ctl[3]) break;
-            if (exact_mode == MM_FP_ADAPTIVE) cap = std::min(MM_MAX_FIX, std::max(8, 3 * host_ctl[4] + 4));
-        }
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (fixed_point && getenv("LSF_TRACE")) {
-        int hc[MM_MAX_FIX + 1] = {0};
-        HIPCHK(hipMemcpy(hc, chg, sizeof hc, hipMemcpyDeviceToHost));
-        int used = 0;
-        for (int f = 0; f < MM_MAX_FIX; ++f) used += hc[f] != 0;
-        fprintf(stderr, "[lsf] min/max fixed point: last iteration needed %d fix passes that changed cells (%d enqueued)%s\n",
-                used, cap, host_ctl[3] ? "; NOT certified -> rerun" : "");
-    }
-    if (inexact) *inexact = host_ctl[3] != 0;
-    if (host_ctl[3]) return LSF_OK; // caller restores the input and reruns with the tile wavefront
-    const int nit = host_ctl[1];
-    const bool stopped_early = host_ctl[0] != 0; // converged or NaN: EXIT/STOP before narrowBand
-    // masks the host would hold now (set3d.f90:448-460)
-    if (nit >= 1) {
-        const double* src = nullptr;
-        if (!stopped_early) src = bufs[nit & 1];                  // band refreshed after the last iteration
-        else if (nit >= 2) src = bufs[(nit - 1) & 1];             // refreshed after iteration nit-1
-        if (src && (rc = narrowband_core(src, d_nb, d_sb, n, dx, st))) return rc;
-    }
-    if (bufs[nit & 1] != d_phi)
-        HIPCHK(hipMemcpyAsync(d_phi, bufs[nit & 1], n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (rms_trace && trace_cap > 0 && nit > 0)
-        HIPCHK(hipMemcpyAsync(rms_trace, d_trace, sizeof(double) * (size_t)std::min(nit, trace_cap),
-                              hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (iters_done) *iters_done = nit;
-    if (host_ctl[2]) return fail(LSF_ERR_NAN, "RMS became NaN (the reference STOPs here, set3d.f90:458)");
-    return LSF_OK;
-}
-
-// Exact ordering: fixed-point passes (fast), as many per iteration as the field has needed so far; if a fixed point is
-// ever not certified, restore the input and redo the call with MM_MAX_FIX passes per iteration, and if that is still
-// not enough (never observed) with the tile-hyperplane wavefront.
-int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int nz, int iter, double dx,
-                double h1, double tol, int mode, int* iters_done, double* rms_trace, int trace_cap,
-                hipStream_t st)
-{
-    const char* e = getenv("LSF_MINMAX_TILES");
-    const bool force_tiles = e && atoi(e) != 0;
-    if ((mode & LSF_ORDER_MASK) != LSF_ORDER_GS || force_tiles || !d_phi || !d_nb || !d_sb || iter <= 0 ||
-        check_dims(nx, ny, nz))
-        return minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace,
-                                trace_cap, st, MM_TILES, nullptr);
-    Ctx& c = ctx();
-    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
-    // an uncertified attempt returns before it touches the masks, so only phi needs a copy to start over from
-    int rc = ws(c.slot[S_BACKUP], n * sizeof(double));
-    if (rc) return rc;
-    char* bk = (char*)c.slot[S_BACKUP].p;
-    HIPCHK(hipMemcpyAsync(bk, d_phi, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    for (int exact_mode : {MM_FP_ADAPTIVE, MM_FP_FULL}) {
-        if (exact_mode == MM_FP_ADAPTIVE && n >= (size_t)200000000) continue; // >= ~585^3: always the full count
-        bool inexact = false;
-        rc = minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap,
-                              st, exact_mode, &inexact);
-        if (rc != LSF_OK || !inexact) return rc;
-        HIPCHK(hipMemcpyAsync(d_phi, bk, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    }
-    return minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap,
-                            st, MM_TILES, nullptr);
-}
+#include "lsf_host_minmax.hpp"
 
 int box_ok(const lsf_box* b, const int lo[3], const int hi[3])
 {
@@ -1857,167 +1208,7 @@ int lsf_advect_nodes(const double* phi, const int32_t* phiSB, int nx, int ny, in
                                    surfXX, nSurfNode, iters, nullptr);
 }
 
-// ---- device-resident chain (include/lsf.h) -------------------------------------------------------
-int lsf_mirror(int flags)
-{
-    if (flags & ~(LSF_MIRROR_TRUST | LSF_MIRROR_LAZY)) return fail(LSF_ERR_INVALID, "unknown mirror flag");
-    int rc = ensure_device();
-    if (rc) return rc;
-    Ctx& c = ctx();
-    if ((c.mirror & LSF_MIRROR_LAZY) && !(flags & LSF_MIRROR_LAZY)) {
-        // leaving the lazy mode: bring every stale host array up to date
-        struct { Twin* t; Slot s; } all[] = {{&c.twin_phi, S_HPHI}, {&c.twin_nb, S_HNB}, {&c.twin_sb, S_HSB}, {&c.twin_snap, S_SNAP}};
-        for (auto& e : all)
-            if (e.t->host_stale && e.t->host) {
-                HIPCHK(hipMemcpy(const_cast<void*>(e.t->host), c.slot[e.s].p, e.t->bytes, hipMemcpyDeviceToHost));
-                e.t->host_stale = false;
-            }
-    }
-    c.mirror = flags;
-    return LSF_OK;
-}
-
-int lsf_mirror_sync(void* host)
-{
-    int rc = ensure_device();
-    if (rc) return rc;
-    if (!host) return fail(LSF_ERR_INVALID, "NULL pointer");
-    Ctx& c = ctx();
-    Twin* t = nullptr;
-    Slot s = S_HPHI;
-    if (!twin_of(c, host, 0, &t, &s)) return LSF_OK; // no twin: the host copy is the only one
-    if (t->host_stale) {
-        HIPCHK(hipMemcpy(host, c.slot[s].p, t->bytes, hipMemcpyDeviceToHost));
-        t->host_stale = false;
-    }
-    return LSF_OK;
-}
-
-int lsf_mirror_forget(const void* host)
-{
-    int rc = ensure_device();
-    if (rc) return rc;
-    if (!host) return fail(LSF_ERR_INVALID, "NULL pointer");
-    Ctx& c = ctx();
-    for (Twin* t : {&c.twin_phi, &c.twin_nb, &c.twin_sb, &c.twin_snap})
-        if (t->host == host) twin_drop(*t);
-    return LSF_OK;
-}
-
-int lsf_snapshot(const double* phi, double* phiO, int nx, int ny, int nz)
-{
-    Trace trace_("lsf_snapshot");
-    int rc = ensure_device();
-    if (rc) return rc;
-    if ((rc = check_dims(nx, ny, nz))) return rc;
-    if (!phi || !phiO) return fail(LSF_ERR_INVALID, "NULL field");
-    Ctx& c = ctx();
-    const size_t bytes = (size_t)(nx + 1) * (ny + 1) * (nz + 1) * sizeof(double);
-    const void* d = (c.mirror & (LSF_MIRROR_TRUST | LSF_MIRROR_LAZY)) ? twin_of(c, phi, bytes) : nullptr;
-    if (!d) { // no usable twin: the plain host copy of set3d.f90:311
-        std::memcpy(phiO, phi, bytes);
-        if (c.twin_snap.host == phiO) twin_drop(c.twin_snap); // the host copy just written is the newer one
-        return LSF_OK;
-    }
-    if ((rc = twin_claim(c, c.twin_snap, S_SNAP, phiO, bytes))) return rc;
-    HIPCHK(hipMemcpy(c.slot[S_SNAP].p, d, bytes, hipMemcpyDeviceToDevice));
-    return twin_out(c, c.twin_snap, S_SNAP, phiO, bytes);
-}
-
-int lsf_sumsq_diff(const double* phi, const double* phiO, int nx, int ny, int nz, double* sum)
-{
-    Trace trace_("lsf_sumsq_diff");
-    int rc = ensure_device();
-    if (rc) return rc;
-    if ((rc = check_dims(nx, ny, nz))) return rc;
-    if (!phi || !phiO || !sum) return fail(LSF_ERR_INVALID, "NULL pointer");
-    Ctx& c = ctx();
-    const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
-    if ((rc = twin_in(c, c.twin_phi, S_HPHI, phi, n * sizeof(double)))) return rc;
-    if ((rc = twin_in(c, c.twin_snap, S_SNAP, phiO, n * sizeof(double)))) return rc;
-    const int grid = 2048;
-    if ((rc = ws(c.slot[S_PART2], (grid + 1) * sizeof(double)))) return rc;
-    double* part = (double*)c.slot[S_PART2].p;
-    hipLaunchKernelGGL(k_sumsq_diff, dim3(grid), dim3(256), 0, nullptr, (const double*)c.slot[S_HPHI].p,
-                       (const double*)c.slot[S_SNAP].p, (long)n, part);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(RED_T), 0, nullptr, (const double*)part, (long)grid, part + grid);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(sum, part + grid, sizeof(double), hipMemcpyDeviceToHost));
-    return LSF_OK;
-}
-
-int lsf_write_vti(const char* path, const double* phi, int nx, int ny, int nz, double dx, const double xLo[3])
-{
-    Trace trace_("lsf_write_vti");
-    if (!path || !phi || !xLo) return fail(LSF_ERR_INVALID, "NULL pointer");
-    int rc = check_dims(nx, ny, nz);
-    if (rc) return rc;
-    const size_t npts = (size_t)(nx + 1) * (ny + 1) * (nz + 1), bytes = npts * sizeof(double);
-    FILE* f = fopen(path, "wb");
-    if (!f) return fail(LSF_ERR_INVALID, std::string("cannot open ") + path);
-    // header: the reference's text (set3d.f90:324-345): extent '(3(A3,I6))', origin and spacing '(3(F20.8,A1))' TRIMmed
-    char extent[96], origin[96], spacing[96];
-    snprintf(extent, sizeof extent, " 0 %6d 0 %6d 0 %6d", nx, ny, nz);
-    snprintf(origin, sizeof origin, "%20.8f %20.8f %20.8f", xLo[0], xLo[1], xLo[2]);
-    snprintf(spacing, sizeof spacing, "%20.8f %20.8f %20.8f", dx, dx, dx);
-    // LSF_VTI_WIDE=1 writes the 64-bit count for any size (include/lsf.h): the wide header can be exercised without a 4 GB field
-    const char* wide_env = getenv("LSF_VTI_WIDE");
-    const bool wide = bytes > 0xffffffffull || (wide_env && atoi(wide_env) != 0);
-    fprintf(f, "<?xml version=\"1.0\"?>\n");
-    fprintf(f, "<VTKFile type=\"ImageData\" version=\"0.1\" byte_order=\"LittleEndian\"%s>\n", wide ? " header_type=\"UInt64\"" : "");
-    fprintf(f, "<ImageData WholeExtent=\"%s\" Origin=\"%s\" Spacing=\"%s\">\n", extent, origin, spacing);
-    fprintf(f, "<Piece Extent=\"%s\">\n<PointData Scalars=\"phi\">\n", extent);
-    fprintf(f, "<DataArray type=\"Float64\" Name=\"phi\" format=\"appended\" offset=\"%16d\"/>\n", 0);
-    fprintf(f, "</PointData>\n</Piece>\n</ImageData>\n<AppendedData encoding=\"raw\">\n_");
-    if (wide) {
-        const uint64_t cnt = bytes;
-        fwrite(&cnt, sizeof cnt, 1, f);
-    } else {
-        const uint32_t cnt = (uint32_t)bytes;
-        fwrite(&cnt, sizeof cnt, 1, f);
-    }
-    bool ok = true;
-    const void* d = nullptr;
-    if (hipGetDeviceCount(&rc) == hipSuccess && rc > 0 && ensure_device() == LSF_OK) d = twin_of(ctx(), phi, bytes);
-    (void)hipGetLastError();
-    if (d) {
-        // stream from the device twin: chunk n + 1 is copied into one pinned buffer while chunk n is written from the other
-        const size_t CH = 64u << 20;
-        void* pin[2] = {nullptr, nullptr};
-        hipStream_t st = nullptr;
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        if (hipHostMalloc(&pin[0], CH, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&pin[1], CH, hipHostMallocDefault) != hipSuccess ||
-            hipStreamCreate(&st) != hipSuccess || hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) {
-            ok = false;
-        } else {
-            const size_t nch = (bytes + CH - 1) / CH;
-            auto issue = [&](size_t q) {
-                const size_t off = q * CH, len = std::min(CH, bytes - off);
-                return hipMemcpyAsync(pin[q & 1], (const char*)d + off, len, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                       hipEventRecord(ev[q & 1], st) == hipSuccess;
-            };
-            ok = issue(0);
-            for (size_t q = 0; q < nch && ok; ++q) {
-                if (q + 1 < nch) ok = issue(q + 1);
-                ok = ok && hipEventSynchronize(ev[q & 1]) == hipSuccess;
-                const size_t len = std::min(CH, bytes - q * CH);
-                ok = ok && fwrite(pin[q & 1], 1, len, f) == len;
-            }
-        }
-        if (st) (void)hipStreamSynchronize(st);
-        for (int q = 0; q < 2; ++q) {
-            if (ev[q]) (void)hipEventDestroy(ev[q]);
-            if (pin[q]) (void)hipHostFree(pin[q]);
-        }
-        if (st) (void)hipStreamDestroy(st);
-    } else {
-        ok = fwrite(phi, 1, bytes, f) == bytes;
-    }
-    fprintf(f, "\n</AppendedData>\n</VTKFile>\n");
-    ok = (fclose(f) == 0) && ok;
-    if (!ok) return fail(LSF_ERR_HIP, std::string("writing ") + path + " failed");
-    return LSF_OK;
-}
+#include "lsf_host_chain.hpp"
 
 int lsf_jacobi_sweep_box(const double* d_in, double* d_out, const double* d_phiS, const lsf_box* box,
                          const int lo[3], const int hi[3], double dx, double h, int mode, double* d_sumsq,
@@ -2158,105 +1349,7 @@ int lsf_reinit_f32(float* phi, int nx, int ny, int nz, int iter, double dx, doub
     return rc;
 }
 
-// ---- binary STL with the reference's vertex merge (subs.f90:17-121) --------------------------------------------
-namespace {
-struct StlResult {
-    std::vector<float> nodes;   // 3 per node
-    std::vector<int32_t> elem;  // 3 per triangle, 1-based
-};
-thread_local StlResult g_stl;
-} // namespace
-
-int lsf_stl_read(const char* path, int* nSurfElem, int* nSurfNode)
-{
-    Trace trace_("lsf_stl_read");
-    if (!path || !nSurfElem || !nSurfNode) return fail(LSF_ERR_INVALID, "NULL pointer");
-    FILE* f = fopen(path, "rb");
-    if (!f) return fail(LSF_ERR_INVALID, std::string("cannot open ") + path);
-    unsigned char head[84];
-    if (fread(head, 1, 84, f) != 84) {
-        fclose(f);
-        return fail(LSF_ERR_INVALID, "STL file shorter than its header");
-    }
-    int32_t ntri = 0;
-    std::memcpy(&ntri, head + 80, 4); // subs.f90:38-39
-    if (ntri < 1) {
-        fclose(f);
-        return fail(LSF_ERR_INVALID, "STL file holds no triangle");
-    }
-    std::vector<unsigned char> rec((size_t)ntri * 50); // normal, 3 vertices (REAL*4), INTEGER*2 padding: subs.f90:47-53
-    const size_t got = fread(rec.data(), 1, rec.size(), f);
-    fclose(f);
-    if (got != rec.size()) return fail(LSF_ERR_INVALID, "STL file shorter than its triangle count");
-    StlResult& R = g_stl;
-    R.nodes.clear();
-    R.elem.assign((size_t)ntri * 3, 0);
-    // Merge (subs.f90:64-93).  Two REAL*4 values can differ by less than 1e-13 without being equal only below 2^-19
-    // (above it neighbouring floats are >= 1.1e-13 apart, also across that threshold), so a coordinate is keyed by its
-    // bits when it is large and by one shared key when it is small; candidates of a key are kept in node order and tested
-    // with the reference's own predicate, the first one inside the search bound wins.
-    struct Key {
-        uint32_t a, b, c;
-        bool operator==(const Key& o) const { return a == o.a && b == o.b && c == o.c; }
-    };
-    struct KeyHash {
-        size_t operator()(const Key& k) const { return ((size_t)k.a * 0x9E3779B1u) ^ ((size_t)k.b * 0x85EBCA77u << 1) ^ ((size_t)k.c * 0xC2B2AE3Du << 2); }
-    };
-    auto key1 = [](float v) -> uint32_t {
-        if (std::fabs(v) < 1.9073486328125e-06f) return 0xFFFFFFFFu; // 2^-19
-        uint32_t u;
-        std::memcpy(&u, &v, 4);
-        return u == 0x80000000u ? 0u : u;
-    };
-    std::unordered_map<Key, std::vector<int32_t>, KeyHash> map;
-    map.reserve((size_t)ntri);
-    int32_t bound = 3, k = 0; // nSurfNode (search bound) and the number of nodes so far
-    for (int32_t n = 0; n < ntri; ++n) {
-        for (int p = 0; p < 3; ++p) {
-            float v[3];
-            std::memcpy(v, rec.data() + (size_t)n * 50 + 12 + 12 * p, 12);
-            const Key key{key1(v[0]), key1(v[1]), key1(v[2])};
-            int32_t share = 0;
-            auto it = map.find(key);
-            if (it != map.end())
-                for (int32_t cand : it->second) { // ascending node numbers
-                    if (cand > bound) break;
-                    const float* q = &R.nodes[(size_t)(cand - 1) * 3];
-                    if ((double)std::fabs(q[0] - v[0]) < 1.e-13 && (double)std::fabs(q[1] - v[1]) < 1.e-13 &&
-                        (double)std::fabs(q[2] - v[2]) < 1.e-13) {
-                        share = cand;
-                        break;
-                    }
-                }
-            if (share > 0) {
-                R.elem[(size_t)n * 3 + p] = share;
-            } else {
-                ++k;
-                R.nodes.insert(R.nodes.end(), v, v + 3);
-                R.elem[(size_t)n * 3 + p] = k;
-                map[key].push_back(k);
-            }
-        }
-        bound = k; // subs.f90:91
-    }
-    *nSurfElem = ntri;
-    *nSurfNode = k;
-    return LSF_OK;
-}
-
-int lsf_stl_get(double* surfX, int32_t* surfElem)
-{
-    if (!surfX || !surfElem) return fail(LSF_ERR_INVALID, "NULL pointer");
-    StlResult& R = g_stl;
-    if (R.elem.empty()) return fail(LSF_ERR_INVALID, "lsf_stl_get without lsf_stl_read");
-    const size_t nn = R.nodes.size() / 3, nt = R.elem.size() / 3;
-    for (size_t q = 0; q < nn; ++q)
-        for (int c = 0; c < 3; ++c) surfX[q + nn * c] = (double)R.nodes[q * 3 + c]; // REAL*4 -> REAL(8), subs.f90:99-103
-    for (size_t t = 0; t < nt; ++t)
-        for (int p = 0; p < 3; ++p) surfElem[t + nt * p] = R.elem[t * 3 + p];
-    R = StlResult{};
-    return LSF_OK;
-}
+#include "lsf_host_stl.hpp"
 
 // ---- lsf_box_reserve --------------------------------------------------------------------------------
 int lsf_box_reserve(void* stream, size_t max_partials)
@@ -2277,44 +1370,8 @@ int lsf_box_reserve(void* stream, size_t max_partials)
 // ---- one process, every GPU: lsf_multi_* / lsf_reinit_multi (lsf_multi.hpp) ------------------------------
 #include "lsf_multi.hpp"
 
-namespace lsfm {
-bool Rccl::load(std::string* err)
-{
-    if (lib) return true;
-    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (lib) break;
-    }
-    if (!lib) {
-        *err = std::string("RCCL transport requested but librccl.so cannot be loaded: ") + dlerror();
-        return false;
-    }
-    auto sym = [&](const char* n) { return dlsym(lib, n); };
-    GetVersion = (int (*)(int*))sym("ncclGetVersion");
-    GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
-    CommInitAll = (int (*)(void**, int, const int*))sym("ncclCommInitAll");
-    CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
-    GroupStart = (int (*)())sym("ncclGroupStart");
-    GroupEnd = (int (*)())sym("ncclGroupEnd");
-    Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
-    Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
-    if (!GetErrorString || !CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv) {
-        *err = "librccl.so lacks a symbol of the point-to-point API";
-        dlclose(lib);
-        lib = nullptr;
-        return false;
-    }
-    if (GetVersion) (void)GetVersion(&version);
-    return true;
-}
-Rccl::~Rccl()
-{
-    for (void* c : comms)
-        if (c && CommDestroy) (void)CommDestroy(c);
-    comms.clear();
-    // the library stays loaded: RCCL keeps threads and device state of its own
-}
-} // namespace lsfm
+#include "lsf_rccl.hpp"
+
 
 // process-wide defaults of lsf_multi_create (lsf_multi_defaults; LSF_MULTI_TRANSPORT = peer | rccl | mock and
 // LSF_MULTI_CHECK_EVERY in the environment override them: the Fortran host has no other way in)

@@ -24,17 +24,6 @@
 
 #include "lsf_boxtile.hpp"
 
-// Build-time experiments on the three-lanes-per-cell march, both measured and left off (profiles/r03_gs_march_ab.txt):
-//   LSF_SKEW_ALLW = 1    a second instance of the march for tiles whose every cell takes the WENO branch (no step masks,
-//                        no first-order branch: -11 % vector instructions per step) -- 5 % SLOWER at 512^3 (2.81 against
-//                        2.67 ms per sweep): the kernel grows from 44 to 52 KB and two variants are live on a CU pair at once
-//   LSF_SKEW_UNROLL = 8  the march as a loop of two iterations of eight steps (half the code) -- 20 % slower
-#ifndef LSF_SKEW_ALLW
-#define LSF_SKEW_ALLW 0
-#endif
-#ifndef LSF_SKEW_UNROLL
-#define LSF_SKEW_UNROLL 16 // marching steps per iteration of the march loop
-#endif
 // 16-byte loads and stores for tiles whose whole LDS image lies inside the grid (see skew_tile, "wide path"): 0 = never,
 // 1 = one lane per cell only (default), 2 = both lane maps.  Measured at 512^3 (profiles/r03_wide_ab.txt, one box): one lane
 // per cell 2.89 against 2.97 ms per sweep, HBM traffic unchanged (2.76 x algorithmic); three lanes per cell 2.68 against
@@ -56,9 +45,6 @@
 // along wins, which is what the one-block-per-tile launch does by itself (its blocks age).
 #ifndef LSF_STREAM_PRIO
 #define LSF_STREAM_PRIO 1
-#endif
-#ifndef LSF_PERSIST_PRIO
-#define LSF_PERSIST_PRIO 0 // k_reinit_gs_persist: priority by the age of the tile's sweep (sk_sweep_prio): measured SLOWER (2.57 -> 2.71 ms, STRICT 4.48 -> 5.11 at 512^3)
 #endif
 #ifndef LSF_POLL_SLEEP
 #define LSF_POLL_SLEEP 16 // 64-cycle units between two looks of a waiting tile at its flags
@@ -231,18 +217,6 @@ __device__ __forceinline__ void sk_march_prio(int u)
     else if (u == 12) __builtin_amdgcn_s_setprio(3);
 }
 
-// Priority by the age of the tile's sweep: the sweeps of a batch follow each other at the spacing their raster flips dictate, so
-// the time per sweep is (spacing in hyperplanes) x (time the OLDEST sweep in flight needs per hyperplane) whenever the chip is not
-// saturated -- the tiles of that sweep are the critical path, everything behind them fills gaps.  lag = sweeps between this
-// tile's sweep and the oldest unfinished one.
-__device__ __forceinline__ void sk_sweep_prio(int lag)
-{
-    if (lag <= 0) __builtin_amdgcn_s_setprio(3);
-    else if (lag == 1) __builtin_amdgcn_s_setprio(2);
-    else if (lag == 2) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-}
-
 // LDS of one tile: declared by the kernel (a kernel that runs several tiles one after the other, or two tile functions, has one)
 template <class T>
 struct SkShared {
@@ -290,13 +264,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
     const int ncol = a.nTj * a.nTk;
 
-#ifndef LSF_SLAB_AGENT_SCOPE
-#define LSF_SLAB_AGENT_SCOPE 0
-#endif
-#ifndef LSF_GS_SYS_SCOPE
-#define LSF_GS_SYS_SCOPE 0 // experiment: the single launch's loads / stores at system scope too
-#endif
-    constexpr bool SYS = (PUSH && !LSF_SLAB_AGENT_SCOPE) || (SC1 && LSF_GS_SYS_SCOPE);
+    constexpr bool SYS = PUSH; // slabs: the other side of an access may be another device -- system scope
     auto ldp = [](const double* p_) { return SYS ? ld_sys(p_) : (SC1 ? ld_sc1(p_) : *p_); };
     auto stp = [](double* p_, double v_) {
         if (SYS) st_sys(p_, v_);
@@ -633,38 +601,20 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
             }
         }
         // ---- march: TA steps, every lane busy; the wavefronts of a tile meet after every step -----------------
-        // Two instances.  ALLW: every cell of every step of the tile exists and takes the WENO branch (a full tile whose
-        // rows and x range lie inside 3 < index < n - 4: most tiles of a BASELINE-size grid): no per-step masks, no
-        // first-order branch, no clamp on the phiS index.  Otherwise the general form.
-        [[maybe_unused]] const bool allw = deep && j_lo + NYT - 1 < ny - 4 && k_lo + NZT - 1 < nz - 4 &&
-                          X0 - (NYT - 1) - (NZT - 1) >= (si > 0 ? 3 : 4) && X0 + TA - 1 < (si > 0 ? nx - 5 : nx - 4);
-        auto march = [&](auto allw_tag) {
-            constexpr bool ALLW = decltype(allw_tag)::value;
-            const bool x_lane = axis == 0 && bl < 5; // the lane that finishes the cell (bl = 5: the idle lane of a row of lanes)
-            unsigned ps_off = (unsigned)(e_ps.x >> 2) + (unsigned)(e_ps.y + (si > 0 ? TA / 2 : -(TA / 2))); // ALLW: index of step TA / 2
-            constexpr int SU = LSF_SKEW_UNROLL; // steps per iteration of the march loop (8: half the code of 16)
-            static_assert(SU == 8 || SU == 16, "the phiS registers are indexed by t mod 8");
-#pragma unroll 1
-            for (int t0 = 0; t0 < TA; t0 += SU)
+        // (one instance, fully unrolled: a second instance without step masks for tiles whose every cell takes the WENO branch,
+        // -11 % vector instructions per step, was 5 % SLOWER -- the kernel grew from 44 to 52 KB --, the march as a loop of two
+        // iterations of eight steps 20 % slower: profiles/r03_gs_march_ab.txt)
+        {
 #pragma unroll
-            for (int u_ = 0; u_ < SU; ++u_) {
-                const int t = t0 + u_;
-                if constexpr (STREAM && LSF_STREAM_PRIO == 1)
-                    sk_march_prio(u_);
-                const bool active = ALLW ? x_lane : (bool)((act_bits >> t) & 1u) && axis == 0;
+            for (int t = 0; t < TA; ++t) {
+                if constexpr (STREAM && LSF_STREAM_PRIO == 1) sk_march_prio(t);
+                const bool active = (bool)((act_bits >> t) & 1u) && axis == 0;
                 double q[7];
 #pragma unroll
                 for (int mm = 0; mm < 7; ++mm) q[mm] = lds[off[mm] + t];
-                const double pS = ps[u_ & (TA / 2 - 1)];
-                if (t + TA / 2 < TA) {
-                    if constexpr (ALLW) {
-                        ps[u_ & (TA / 2 - 1)] = ps_t[ps_off];
-                        ps_off += (unsigned)(si > 0 ? 1 : -1);
-                    } else {
-                        ps[u_ & (TA / 2 - 1)] = ps_load(t + TA / 2);
-                    }
-                }
-                const bool weno_ok = ALLW ? true : (bool)((weno_bits >> t) & 1u);
+                const double pS = ps[t & (TA / 2 - 1)];
+                if (t + TA / 2 < TA) ps[t & (TA / 2 - 1)] = ps_load(t + TA / 2);
+                const bool weno_ok = (bool)((weno_bits >> t) & 1u);
                 double dm, dp;
                 axis_pair<STRICT>(q, weno_ok, yquirk, dx, floor2, dm, dp);
                 const double gg = axis_godunov<STRICT>(q[3], dm, dp);
@@ -677,12 +627,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
                 }
                 __syncthreads();
             }
-        };
-#if LSF_SKEW_ALLW
-        if (allw) march(std::true_type{});
-        else
-#endif
-            march(std::false_type{});
+        }
     } else {
         // ---- one lane per cell: the lane evaluates the three axes of its cell; 19 LDS reads, one LDS write per cell ----
         int ox[7], oy[7], oz[7]; // LDS index of the stencil value mm - 3 along x / y / z at step 0 (ox[3] = the cell itself)
@@ -1104,7 +1049,6 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                     __builtin_amdgcn_s_sleep(LSF_POLL_SLEEP); // ~0.5 us between looks; 8..64 measured within 2 % of each other
                 }
                 sh_task[3] = swp.x, sh_task[4] = swp.y, sh_task[5] = swp.z;
-                sh_task[7] = a.g0 + s - ld_flag(a.ctl + 1); // sweeps between this tile's and the oldest unfinished one
             }
             sh_task[0] = (int)e.x, sh_task[1] = (int)e.y, sh_task[2] = go;
         }
@@ -1114,7 +1058,6 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
         const uint32_t packed = (uint32_t)uni(sh_task[0]);
         const int sP = uni(sh_task[1]);
         int go = uni(sh_task[2]);
-        if (LSF_PERSIST_PRIO && go) sk_sweep_prio(uni(sh_task[7]));
         const int s = sP & (DF_BATCH - 1), P = (int)((unsigned)sP >> DF_SWEEP_BITS);
         if (go == 0) return;
         const unsigned long long tsB = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;

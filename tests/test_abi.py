@@ -71,3 +71,18 @@ def test_sweep_report_lines_follow_the_reference_protocol():
     assert len(lines) == 3 and lines[-1] == "steady" and "Iteration:  1" in lines[1]
     r = SweepReport(2, [0.5, 0.25], False)
     assert len(r.lines(1, "steady")) == 2 and "Iteration:  2" in r.lines(1, "steady")[1]
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """every getenv("LSF_...") in levelsetfortran_amd/csrc has its row in INTEGRATION.md."""
+    import glob
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = set()
+    for f in glob.glob(os.path.join(root, "levelsetfortran_amd", "csrc", "*.h*")):
+        names |= set(re.findall(r'getenv\("(LSF_[A-Z0-9_]+)"\)', open(f).read()))
+    assert len(names) > 20
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
