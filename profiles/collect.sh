@@ -51,4 +51,4 @@ python3 profiles/summarize.py "$OUT" "$TAG" $((2 * PMC_STEPS))
 bash profiles/sq_pass.sh "$TAG"
 # gpurun only carries gpurun_out/ back: stage the committed summaries there (copy them into profiles/ afterwards)
 mkdir -p "gpurun_out/profiles_$TAG"
-cp profiles/${TAG}_* profiles/traffic.json "gpurun_out/profiles_$TAG/"
+cp profiles/${TAG}_* "gpurun_out/profiles_$TAG/"

@@ -4,7 +4,7 @@
   profiles/<tag>_pmc_hbm.json          HBM bytes per sweep from FETCH_SIZE / WRITE_SIZE, raw and with the
                                        gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 128-B
                                        requests as 64 B for wide coalesced reads -> x2 upper bound)
-  profiles/traffic.json                {kernel: {N: bytes per sweep}} read by bench.py ("traffic")
+  (profiles/traffic.json is written by profiles/ships_summarize.py: keyed by kernel instance and size)
 """
 import csv
 import glob
@@ -107,8 +107,8 @@ if "FETCH_SIZE" in cal:
         e["hbm_calibrated"] = e["fetch_calibrated"] + e["write"] / cc.get("WRITE_SIZE", {"ratio": 1.0})["ratio"]
         traffic[kern] = {"512": e["hbm_calibrated"]}
 json.dump(res, open(os.path.join(here, f"{tag}_pmc_hbm.json"), "w"), indent=1)
-if traffic:
-    json.dump(traffic, open(os.path.join(here, "traffic.json"), "w"), indent=1)
+# (profiles/traffic.json -- what bench.py attaches to `roofline` -- is written by profiles/ships_summarize.py since round 4: keyed by
+# kernel INSTANCE and size; the per-name numbers above stay in <tag>_pmc_hbm.json)
 for name in ("bench_under_rocprof.json", "bench_f32_under_rocprof.json", "bench_s20_under_rocprof.json"):
     b = os.path.join(out_dir, name)
     if os.path.exists(b):
