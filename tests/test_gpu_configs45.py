@@ -43,7 +43,7 @@ def test_config4_1024_fp64_single_sphere_block_equals_oracle(oracle):
     import levelsetfortran_amd as lsf
     from levelsetfortran_amd import fields
 
-    N, s, w = 1024, 2, 44
+    N, s, w = 1024, 8, 123  # eight sweeps; the cells that depend on the block alone: 64^3 (SURVEY.md 8d's block)
     phi, dx = _build(N, ((0.0, 0.0, 0.0),), 1.0, torch.float64)
     h = fields.reinit_step(dx)
     # the sphere's surface crosses the x axis at i = (1.5 - 1.0)/dx = 170.5; centre of the grid in y and z
@@ -56,6 +56,7 @@ def test_config4_1024_fp64_single_sphere_block_equals_oracle(oracle):
     got = _block(phi, lo, w)
     oracle.reinit(blk, w - 1, w - 1, w - 1, s - 1, dx, h, tol=0.0, order=oracle.JACOBI)
     a, b = 4 + 3 * s + 1, w - 5 - 3 * s - 1
+    assert b - a == 64
     assert np.array_equal(got[a:b, a:b, a:b], blk[a:b, a:b, a:b])
     lsf._lib.load().lsf_release_workspace()
 
@@ -64,7 +65,7 @@ def test_config5_1536_fp32_two_spheres_block_tracks_oracle(oracle):
     import levelsetfortran_amd as lsf
     from levelsetfortran_amd import fields
 
-    N, s, w = 1536, 4, 56
+    N, s, w = 1536, 8, 123  # eight sweeps, 64^3 cells compared
     eps = float(np.finfo(np.float32).eps)
     phi, dx = _build(N, ((-0.6, 0.0, 0.0), (0.6, 0.0, 0.0)), 0.5, torch.float32)
     h = fields.reinit_step(dx)
@@ -79,6 +80,7 @@ def test_config5_1536_fp32_two_spheres_block_tracks_oracle(oracle):
     ref = np.asfortranarray(blk32.astype(np.float64))
     oracle.reinit(ref, w - 1, w - 1, w - 1, s - 1, dx, h, tol=0.0, order=oracle.JACOBI)
     a, b = 4 + 3 * s + 1, w - 5 - 3 * s - 1
+    assert b - a == 64
     err = got[a:b, a:b, a:b] - ref[a:b, a:b, a:b]
     # fp32 rounding of phi (6e-8 per update) dominates: a few ulp per sweep (tests/test_gpu_f32.py)
     assert np.abs(err).max() < 4 * s * eps, np.abs(err).max()
