@@ -9,7 +9,7 @@ TAG=${1:-r04}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/ships_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-if [ $# -eq 0 ]; then set -- "512 fast gs" "512 strict gs" "256 fast gs" "256 strict gs" "1024 fast gs" "512 fast jacobi" "512 strict jacobi"; fi
+if [ $# -eq 0 ]; then set -- "512 fast gs" "512 strict gs" "256 fast gs" "256 strict gs" "1024 fast gs" "1024 strict gs" "512 fast jacobi" "512 strict jacobi" "256 fast jacobi" "1024 fast jacobi"; fi
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
 for CFG in "$@"; do
   set -- $CFG; N=$1; A=$2; M=$3; K=32; [ "$N" -ge 1024 ] && K=16
