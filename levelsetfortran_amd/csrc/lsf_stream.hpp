@@ -9,7 +9,8 @@
 namespace lsf {
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Dataflow schedule with COLUMN CONTINUATION (the default launch; k_reinit_gs_persist stays as LSF_GS_STREAM=0).
+// Dataflow schedule with COLUMN CONTINUATION (opt-in: LSF_GS_STREAM=1; the default launch is k_reinit_gs_persist -- this one is
+// bit-identical and 9-20 % slower, for the reasons DESIGN.md section 4.1 "Round 4" and profiles/r04_stream_ab.txt give).
 //
 // A tile (m, B, C) of k_reinit_gs_persist pays, besides its march: a ticket, the row table, the load of 22 (18) entries per
 // row, the drain of its write-through stores, its flag -- and the block that takes tile (m + 1, B, C) pays the look at that flag
@@ -19,15 +20,17 @@ namespace lsf {
 //
 // Who runs what.  tile_done[s][tile] has three states: 0 free, 1 claimed, 2 done (claims are compare-and-swaps 0 -> 1; waiters
 // want 2).  The launch is a fixed number of resident blocks, each a loop:
-//   * ACQUIRE: claim the FIRST free tile of the batch's task list (slot order, as before).  A wavefront looks at 64 entries
-//     at a time from a hint (a.ticket: every entry in front of it is claimed) and moves the hint along.
+//   * ACQUIRE: claim the next free tile of the batch's task list (slot order, as before).  A ticket (a.ticket) is a position of
+//     the list nobody else gets; the 64 lanes of a wavefront look at the 64 entries from it on, and the counter jumps over the
+//     run of entries that continuing blocks have claimed already (claims are permanent: no free entry is ever skipped).
 //   * run the tile (waits as in k_reinit_gs_persist: conditions (b), (c), then (a) between the two load stages), publish it;
 //   * CONTINUE with (m + 1, B, C) if it exists, sweep s - 1 has already passed its neighbourhood (condition (b), checked, not
-//     waited for), its two cross upstream tiles (m + 1, B - 1, C), (m + 1, B, C - 1) are at least CLAIMED, and the claim of the
-//     tile itself succeeds; then wait for the two cross tiles to be DONE between the load stages, as usual.  Otherwise ACQUIRE.
-// No deadlock: a tile claimed by ACQUIRE has every predecessor claimed (they all precede it in the list and the list was
-// claimed up to it); a tile claimed by CONTINUE has its predecessors claimed by the rule above (its own column's by this
-// block).  So every tile anybody waits for is held by a live block, and the unfinished claimed tile that comes first in the
+//     waited for: by the hyperplane counter or, exactly, by stream_prev_sweep_past), its two cross upstream tiles (m + 1, B - 1, C),
+//     (m + 1, B, C - 1) are DONE (LSF_GS_CONT=2, default) or at least CLAIMED (LSF_GS_CONT=1: the block then waits for them
+//     between the load stages, as usual), and the claim of the tile itself succeeds.  Otherwise ACQUIRE.
+// No deadlock: a tile claimed by ACQUIRE has every predecessor claimed or handed out as a ticket to a live block that is about
+// to claim it (they all precede it in the list, and every position in front of the counter is one or the other); a tile claimed
+// by CONTINUE has its predecessors claimed by the rule above (its own column's by this block).  So every tile anybody waits for is held by a live block, and the unfinished claimed tile that comes first in the
 // list waits for nothing: its holder finishes it (a block holds at most the tile it runs).  Every spin is bounded as before.
 // The RMS sums, the hyperplane counters, the stop verdict and the epilogue are those of k_reinit_gs_persist: same bits.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -62,15 +65,19 @@ __device__ __forceinline__ bool stream_prev_sweep_past(const GsArgs& a, int s, i
     const int4 cur = *(const int4*)(a.sweep_tab + 4 * s), prv = *(const int4*)(a.sweep_tab + 4 * (s - 1));
     const int X0 = TA * m - T::NYT * fB - T::NZT * fC;
     // frame coordinates of a cell of the image: Fx = X0 - b - c + k - 3, Fy = NYT fB + b, Fz = NZT fC + c;  in the frame of the
-    // previous sweep an axis whose direction flipped counts from the other wall: F' = (n - 2) - F
+    // previous sweep an axis whose direction flipped counts from the other end: Fx' = (nx - 2) - Fx along the march axis, and
+    // Fy' = (NYT nTj - 1) - Fy, Fz' = (NZT nTk - 1) - Fz across it -- the tiles are anchored at the low wall, so against an axis
+    // the frame starts at the far end of the LAST tile, partial or not (for the rows of a partial last column, which a tile's
+    // halo may reach, that over-estimates the coordinate: a later tile of the previous sweep is asked, never an earlier one)
     const int ex = cur.x == prv.x ? 1 : -1, ey = cur.y == prv.y ? 1 : -1, ez = cur.z == prv.z ? 1 : -1;
-    const int c0 = (ex > 0 ? X0 - 3 : a.nx - 2 - X0 + 3) + (ey > 0 ? T::NYT * fB : a.ny - 2 - T::NYT * fB) + (ez > 0 ? T::NZT * fC : a.nz - 2 - T::NZT * fC);
+    const int c0 = (ex > 0 ? X0 - 3 : a.nx - 2 - X0 + 3) + (ey > 0 ? T::NYT * fB : T::NYT * a.nTj - 1 - T::NYT * fB) +
+                   (ez > 0 ? T::NZT * fC : T::NZT * a.nTk - 1 - T::NZT * fC);
     const int cb = -ex + ey, cc = -ex + ez, ck = ex; // d S' / d b, d c, d k
     const int tj = cur.y > 0 ? fB : a.nTj - 1 - fB, tk = cur.z > 0 ? fC : a.nTk - 1 - fC;
     const int dj = cur.y > 0 ? 1 : -1, dk = cur.z > 0 ? 1 : -1; // absolute column step of one frame column
     auto box_done = [&](int b0, int b1, int c0_, int c1, int k0, int k1, int tj2, int tk2) {
         const int smax = c0 + (cb > 0 ? cb * b1 : cb * b0) + (cc > 0 ? cc * c1 : cc * c0_) + (ck > 0 ? ck * k1 : ck * k0);
-        const int mp = smax / TA; // smax >= 0: the cells are interior cells
+        const int mp = min(smax / TA, a.nM - 1); // smax >= 0: the cells are interior cells (beyond the column's last tile: a flag nobody raises)
         const int fBp = prv.y > 0 ? tj2 : a.nTj - 1 - tj2, fCp = prv.z > 0 ? tk2 : a.nTk - 1 - tk2;
         return ld_flag(a.tile_done + (s - 1) * per_sweep + mp + (long)a.nM * (fBp + (long)a.nTj * fCp));
     };
