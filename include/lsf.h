@@ -233,6 +233,17 @@ int lsf_sumsq_begin(void *stream);
 int lsf_sumsq_end(void *stream);
 
 /* Pack / unpack the local sub-box [lo,hi) to / from a contiguous buffer (i fastest). */
+/* Up to six sub-boxes in ONE launch (the face slabs of a block: a decomposed sweep packs and unpacks three to six of them, and
+ * below ~200^3 points per block each of those launches is shorter than the gap between two launches).  lo / hi: nreg rows of
+ * three; d_bufs[q]: the buffer of sub-box q.  Same element order as lsf_pack_box; empty sub-boxes are skipped. */
+int lsf_pack_boxes(const double *d_field, const lsf_box *box, int nreg, const int (*lo)[3], const int (*hi)[3],
+                   double *const *d_bufs, void *stream);
+int lsf_unpack_boxes(double *d_field, const lsf_box *box, int nreg, const int (*lo)[3], const int (*hi)[3],
+                     double *const *d_bufs, void *stream);
+int lsf_pack_boxes_f32(const float *d_field, const lsf_box *box, int nreg, const int (*lo)[3], const int (*hi)[3],
+                       float *const *d_bufs, void *stream);
+int lsf_unpack_boxes_f32(float *d_field, const lsf_box *box, int nreg, const int (*lo)[3], const int (*hi)[3],
+                         float *const *d_bufs, void *stream);
 int lsf_pack_box(const double *d_field, const lsf_box *box, const int lo[3], const int hi[3],
                  double *d_buf, void *stream);
 int lsf_unpack_box(double *d_field, const lsf_box *box, const int lo[3], const int hi[3],

@@ -103,6 +103,10 @@ SIGNATURES = {
                            c_void_p]),
     "lsf_sumsq_begin": (c_int, [c_void_p]),
     "lsf_sumsq_end": (c_int, [c_void_p]),
+    "lsf_pack_boxes": (c_int, [c_void_p, POINTER(LsfBox), c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lsf_unpack_boxes": (c_int, [c_void_p, POINTER(LsfBox), c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lsf_pack_boxes_f32": (c_int, [c_void_p, POINTER(LsfBox), c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lsf_unpack_boxes_f32": (c_int, [c_void_p, POINTER(LsfBox), c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lsf_pack_box": (c_int, [c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_void_p, c_void_p]),
     "lsf_unpack_box": (c_int, [c_void_p, POINTER(LsfBox), c_int * 3, c_int * 3, c_void_p, c_void_p]),
     "lsf_reinit_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_int,

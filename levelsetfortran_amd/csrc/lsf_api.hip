@@ -806,6 +806,38 @@ int pack_impl(const T* d_field, T* d_field_w, const lsf_box* box, const int lo[3
     return LSF_OK;
 }
 
+template <typename T>
+int pack_multi_impl(const T* d_field, T* d_field_w, const lsf_box* box, int nreg, const int (*lo)[3], const int (*hi)[3], T* const* d_bufs,
+                    int unpack, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (nreg < 0 || nreg > 6) return fail(LSF_ERR_INVALID, "0 to 6 sub-boxes");
+    if (!box || !lo || !hi || !d_bufs || (!d_field && !d_field_w)) return fail(LSF_ERR_INVALID, "NULL pointer");
+    PackRegs r;
+    std::memset(&r, 0, sizeof r);
+    long tot = 0;
+    for (int q = 0; q < nreg; ++q) {
+        if ((rc = box_ok(box, lo[q], hi[q]))) return rc;
+        const int e0 = hi[q][0] - lo[q][0], e1 = hi[q][1] - lo[q][1], e2 = hi[q][2] - lo[q][2];
+        if (e0 <= 0 || e1 <= 0 || e2 <= 0) continue;
+        if (!d_bufs[q]) return fail(LSF_ERR_INVALID, "NULL pointer");
+        if ((double)e0 * e1 * e2 > 2.0e9) return fail(LSF_ERR_INVALID, "a slab of more than 2e9 points");
+        for (int a = 0; a < 3; ++a) r.lo[r.n][a] = lo[q][a], r.e[r.n][a] = hi[q][a] - lo[q][a];
+        r.buf[r.n] = (void*)d_bufs[q];
+        r.start[r.n] = tot;
+        tot += (long)e0 * e1 * e2;
+        ++r.n;
+    }
+    for (int q = r.n; q <= 6; ++q) r.start[q] = tot;
+    if (tot == 0) return LSF_OK;
+    const int grid = (int)std::min<long>((tot + 255) / 256, 8192);
+    const Box bx{box->lx, box->ly, box->lz, box->gx0, box->gy0, box->gz0, box->nx, box->ny, box->nz};
+    hipLaunchKernelGGL(k_pack_multi<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_field, d_field_w, bx, r, unpack);
+    HIPCHK(hipGetLastError());
+    return LSF_OK;
+}
+
 int f32_mode_ok(int mode)
 {
     if ((mode & LSF_ORDER_MASK) != LSF_ORDER_JACOBI || (mode & LSF_ARITH_STRICT))
@@ -1276,6 +1308,23 @@ int lsf_unpack_box(double* d_field, const lsf_box* box, const int lo[3], const i
                    void* stream)
 {
     return pack_impl<double>(nullptr, d_field, box, lo, hi, const_cast<double*>(d_buf), 1, stream);
+}
+
+int lsf_pack_boxes(const double* d_field, const lsf_box* box, int nreg, const int (*lo)[3], const int (*hi)[3], double* const* d_bufs, void* stream)
+{
+    return pack_multi_impl<double>(d_field, nullptr, box, nreg, lo, hi, d_bufs, 0, stream);
+}
+int lsf_unpack_boxes(double* d_field, const lsf_box* box, int nreg, const int (*lo)[3], const int (*hi)[3], double* const* d_bufs, void* stream)
+{
+    return pack_multi_impl<double>(nullptr, d_field, box, nreg, lo, hi, d_bufs, 1, stream);
+}
+int lsf_pack_boxes_f32(const float* d_field, const lsf_box* box, int nreg, const int (*lo)[3], const int (*hi)[3], float* const* d_bufs, void* stream)
+{
+    return pack_multi_impl<float>(d_field, nullptr, box, nreg, lo, hi, d_bufs, 0, stream);
+}
+int lsf_unpack_boxes_f32(float* d_field, const lsf_box* box, int nreg, const int (*lo)[3], const int (*hi)[3], float* const* d_bufs, void* stream)
+{
+    return pack_multi_impl<float>(nullptr, d_field, box, nreg, lo, hi, d_bufs, 1, stream);
 }
 
 int lsf_pack_box_f32(const float* d_field, const lsf_box* box, const int lo[3], const int hi[3], float* d_buf,

@@ -939,4 +939,31 @@ __global__ __launch_bounds__(256) void k_pack(const T* __restrict__ f, T* __rest
     }
 }
 
+// Up to six sub-boxes (the face slabs of a block) in ONE launch: a decomposed sweep packs three to six slabs and unpacks as
+// many -- at 131^3 per rank each of those launches is shorter than the gap between two launches.  bytes = sizeof(T).
+struct PackRegs {
+    int n;
+    int lo[6][3], e[6][3];
+    long start[7]; // prefix sums of the slabs' point counts
+    void* buf[6];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_multi(const T* __restrict__ f, T* __restrict__ fw, Box bx, PackRegs r, int unpack)
+{
+    const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
+    const long total = r.start[r.n];
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < total; p += 256L * gridDim.x) {
+        int q = 0;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) q += (k < r.n && p >= r.start[k]) ? 1 : 0;
+        const int i = (int)(p - r.start[q]);
+        const int e0 = r.e[q][0], e01 = e0 * r.e[q][1]; // a slab is far below 2^31 points
+        const int z = i / e01, rem = i - z * e01, y = rem / e0, x = rem - y * e0;
+        const long g = (r.lo[q][0] + x) + sx * (r.lo[q][1] + y) + sxy * (r.lo[q][2] + z);
+        T* b = (T*)r.buf[q];
+        if (unpack) fw[g] = b[i];
+        else b[i] = f[g];
+    }
+}
+
 } // namespace lsf

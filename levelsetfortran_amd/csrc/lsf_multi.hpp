@@ -56,6 +56,17 @@ struct Reg {
     }
 };
 
+// blocks below this many owned points along their longest axis run a sweep as ONE launch after the exchange (LSF_MULTI_SMALL in
+// the environment: threshold, 0 = never)
+inline bool small_block(const int own[3][2])
+{
+    const char* e = getenv("LSF_MULTI_SMALL");
+    const int thr = e ? atoi(e) : 192;
+    int longest = 0;
+    for (int a = 0; a < 3; ++a) longest = std::max(longest, own[a][1] - own[a][0]);
+    return longest < thr;
+}
+
 struct Geom {
     int dims[3], coords[3], n[3];
     int own[3][2]; // owned global point range [s, e) per axis
@@ -109,7 +120,17 @@ inline bool make_geom(int rank, const int dims[3], const int n[3], Geom* g, std:
     g->rims.clear();
     int cur[3][2];
     std::memcpy(cur, cells, sizeof cur);
-    for (int a = 0; a < 3; ++a) { // peel one axis at a time: the rims are disjoint
+    // Small blocks (north_star's 256^3 on eight GPUs: 131^3 per rank): a sweep is 0.03 ms of arithmetic under seven launches
+    // whose fixed costs are the time (profiles/r04_jacobi_rank_model.txt) -- one sweep launch over all owned cells after the
+    // ghosts have arrived instead of core || exchange, then up to three rims.  Same cells, same kernels per cell, same field.
+    if (small_block(g->own)) {
+        for (int a = 0; a < 3; ++a) g->core.hi[a] = g->core.lo[a]; // empty: nothing runs beside the exchange
+        Reg r;
+        for (int b = 0; b < 3; ++b) r.lo[b] = cells[b][0], r.hi[b] = cells[b][1];
+        g->rims.push_back(r);
+        for (int a = 0; a < 3; ++a) cur[a][0] = cur[a][1] = 0, g->core.lo[a] = g->core.hi[a] = cells[a][0]; // (nothing left to peel)
+    }
+    for (int a = 0; a < 3 && !small_block(g->own); ++a) { // peel one axis at a time: the rims are disjoint
         if (g->core.lo[a] > cur[a][0]) {
             Reg r;
             for (int b = 0; b < 3; ++b) r.lo[b] = cur[b][0], r.hi[b] = cur[b][1];
@@ -314,6 +335,8 @@ template <> struct BoxCalls<double> {
     { return lsf_bc_box(a, b, bx, lo, hi, dx, sum, st); }
     static int pack(const double* f, const lsf_box* bx, const int* lo, const int* hi, double* buf, void* st) { return lsf_pack_box(f, bx, lo, hi, buf, st); }
     static int unpack(double* f, const lsf_box* bx, const int* lo, const int* hi, const double* buf, void* st) { return lsf_unpack_box(f, bx, lo, hi, buf, st); }
+    static int pack_all(const double* f, const lsf_box* bx, int n, const int (*lo)[3], const int (*hi)[3], double* const* bufs, void* st) { return lsf_pack_boxes(f, bx, n, lo, hi, bufs, st); }
+    static int unpack_all(double* f, const lsf_box* bx, int n, const int (*lo)[3], const int (*hi)[3], double* const* bufs, void* st) { return lsf_unpack_boxes(f, bx, n, lo, hi, bufs, st); }
 };
 template <> struct BoxCalls<float> {
     static int sweep(const float* a, float* b, const float* s, const lsf_box* bx, const int* lo, const int* hi, double dx, double h,
@@ -322,6 +345,8 @@ template <> struct BoxCalls<float> {
     { return lsf_bc_box_f32(a, b, bx, lo, hi, dx, sum, st); }
     static int pack(const float* f, const lsf_box* bx, const int* lo, const int* hi, float* buf, void* st) { return lsf_pack_box_f32(f, bx, lo, hi, buf, st); }
     static int unpack(float* f, const lsf_box* bx, const int* lo, const int* hi, const float* buf, void* st) { return lsf_unpack_box_f32(f, bx, lo, hi, buf, st); }
+    static int pack_all(const float* f, const lsf_box* bx, int n, const int (*lo)[3], const int (*hi)[3], float* const* bufs, void* st) { return lsf_pack_boxes_f32(f, bx, n, lo, hi, bufs, st); }
+    static int unpack_all(float* f, const lsf_box* bx, int n, const int (*lo)[3], const int (*hi)[3], float* const* bufs, void* st) { return lsf_unpack_boxes_f32(f, bx, n, lo, hi, bufs, st); }
 };
 
 template <typename T>
@@ -458,6 +483,21 @@ void worker(lsf_multi* M, std::vector<RankState<T>>* ranks, int r, SpinBarrier* 
         return true;
     };
 
+    // the face slabs of the block travel in ONE pack and ONE unpack launch per sweep (lsf_pack_boxes): the faces that have a neighbour
+    int nf = 0, face_of[6], s_lo[6][3], s_hi[6][3], r_lo[6][3], r_hi[6][3];
+    T* s_buf[6];
+    for (int f = 0; f < 6; ++f) {
+        if (R.g.nb[f] < 0) continue;
+        for (int a = 0; a < 3; ++a) s_lo[nf][a] = R.g.send[f].lo[a], s_hi[nf][a] = R.g.send[f].hi[a], r_lo[nf][a] = R.g.recv[f].lo[a], r_hi[nf][a] = R.g.recv[f].hi[a];
+        s_buf[nf] = R.sendb[f];
+        face_of[nf++] = f;
+    }
+    auto unpack_faces = [&](T* a_in, int eq) -> int {
+        T* r_buf[6];
+        for (int k = 0; k < nf; ++k) r_buf[k] = R.recvb[eq][face_of[k]];
+        return C::unpack_all(a_in, &bx, nf, r_lo, r_hi, r_buf, R.comm);
+    };
+
     // ---- comm stream, first half: pack (and, PEER, push) the slabs of sweep s, exchange number e
     auto enqueue_sends = [&](int s, long e) {
         if (R.rc) return;
@@ -466,10 +506,10 @@ void worker(lsf_multi* M, std::vector<RankState<T>>* ranks, int r, SpinBarrier* 
         const T* a_in = R.buf[q];
         // the input of this sweep is the output of the previous one (compute stream)
         if (e > S->seq0) LSFM_HIP(hipStreamWaitEvent(R.comm, R.done[(s - 1) & 1], 0));
+        LSFM_LSF(C::pack_all(a_in, &bx, nf, s_lo, s_hi, s_buf, R.comm));
         for (int f = 0; f < 6; ++f) {
             const int p = R.g.nb[f];
             if (p < 0) continue;
-            LSFM_LSF(C::pack(a_in, &bx, R.g.send[f].lo, R.g.send[f].hi, R.sendb[f], R.comm));
             if (transport == LSF_TRANSPORT_PEER) {
                 RankState<T>& P = (*ranks)[p];
                 LSFM_HIP(hipMemcpyPeerAsync(P.recvb[eq][f ^ 1], P.dev, R.sendb[f], R.dev, (size_t)R.g.send[f].vol() * sizeof(T), R.comm));
@@ -496,8 +536,8 @@ void worker(lsf_multi* M, std::vector<RankState<T>>* ranks, int r, SpinBarrier* 
                 const int p = R.g.nb[f];
                 if (p < 0) continue;
                 LSFM_HIP(hipStreamWaitEvent(R.comm, (*ranks)[p].sent[eq][f ^ 1], 0));
-                LSFM_LSF(C::unpack(a_in, &bx, R.g.recv[f].lo, R.g.recv[f].hi, R.recvb[eq][f], R.comm));
             }
+            LSFM_LSF(unpack_faces(a_in, eq));
         } else if (transport == LSF_TRANSPORT_RCCL) {
             LSFM_NCCL(M->rccl.GroupStart());
             for (int f = 0; f < 6; ++f) {
@@ -508,8 +548,7 @@ void worker(lsf_multi* M, std::vector<RankState<T>>* ranks, int r, SpinBarrier* 
                 LSFM_NCCL(M->rccl.Recv(R.recvb[eq][f], bytes, Rccl::kInt8, p, M->rccl.comms[r], R.comm));
             }
             LSFM_NCCL(M->rccl.GroupEnd());
-            for (int f = 0; f < 6; ++f)
-                if (R.g.nb[f] >= 0) LSFM_LSF(C::unpack(a_in, &bx, R.g.recv[f].lo, R.g.recv[f].hi, R.recvb[eq][f], R.comm));
+            LSFM_LSF(unpack_faces(a_in, eq));
         } else { // MOCK: the group call of the RCCL schedule, carried out by pull copies
             lk.unlock();
             for (int f = 0; f < 6; ++f) { // "recv": the neighbour's slab is packed -> copy it out of its send buffer
@@ -531,8 +570,7 @@ void worker(lsf_multi* M, std::vector<RankState<T>>* ranks, int r, SpinBarrier* 
                 LSFM_HIP(hipStreamWaitEvent(R.comm, (*ranks)[p].taken[eq][f ^ 1], 0));
             }
             lk.lock();
-            for (int f = 0; f < 6; ++f)
-                if (R.g.nb[f] >= 0) LSFM_LSF(C::unpack(a_in, &bx, R.g.recv[f].lo, R.g.recv[f].hi, R.recvb[eq][f], R.comm));
+            LSFM_LSF(unpack_faces(a_in, eq));
         }
         LSFM_HIP(hipEventRecord(R.halo, R.comm));
         // ---- compute stream

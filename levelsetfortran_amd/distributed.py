@@ -121,9 +121,22 @@ def interior_cells_local(b: Block):
     return out
 
 
+def small_block(b: Block) -> bool:
+    """Blocks below LSF_MULTI_SMALL (default 192, 0 = never) owned points along their longest axis run a sweep as ONE launch
+    after the exchange instead of core || exchange + rims: at 131^3 per rank (north_star's 256^3 on eight GPUs) a sweep is
+    0.03 ms of arithmetic under launches whose fixed costs are the time (profiles/r04_jacobi_rank_model.txt).  Same rule as
+    csrc/lsf_multi.hpp."""
+    import os
+
+    thr = int(os.environ.get("LSF_MULTI_SMALL", "192"))
+    return max(e - s for s, e in b.own) < thr
+
+
 def sweep_regions(b: Block):
     """(core, rims): core needs no ghost data; the rims (disjoint boxes) need the halo exchange."""
     cells = interior_cells_local(b)
+    if small_block(b):
+        return [(c[0], c[0]) for c in cells], [[tuple(c) for c in cells]]
     core = []
     for a in range(3):
         lo, hi = cells[a]
@@ -197,6 +210,8 @@ class HipBackend:
         self._bc = getattr(self.lib, "lsf_bc_box" + sfx)
         self._pack = getattr(self.lib, "lsf_pack_box" + sfx)
         self._unpack = getattr(self.lib, "lsf_unpack_box" + sfx)
+        self._pack_all = getattr(self.lib, "lsf_pack_boxes" + sfx)
+        self._unpack_all = getattr(self.lib, "lsf_unpack_boxes" + sfx)
         _lib.check(self.lib.lsf_set_device(device.index or 0))
         self.compute = torch.cuda.current_stream(device)
         self.comm = torch.cuda.Stream(device)
@@ -243,6 +258,20 @@ class HipBackend:
         lo, hi = self._lohi(region)
         self.L.check(self._unpack(f.data_ptr(), ctypes.byref(self._box(b)), lo, hi, buf.data_ptr(),
                                              stream.cuda_stream))
+
+    def _multi(self, fn, f, b, regions, bufs, stream):
+        n = len(regions)
+        lo = (ctypes.c_int * (3 * n))(*[r[a][0] for r in regions for a in range(3)])
+        hi = (ctypes.c_int * (3 * n))(*[r[a][1] for r in regions for a in range(3)])
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in bufs])
+        self.L.check(fn(f.data_ptr(), ctypes.byref(self._box(b)), n, lo, hi, ptrs, stream.cuda_stream))
+
+    def pack_all(self, f, b, regions, bufs, stream):
+        """all face slabs of a block in one launch (include/lsf.h: lsf_pack_boxes)"""
+        self._multi(self._pack_all, f, b, regions, bufs, stream)
+
+    def unpack_all(self, f, b, regions, bufs, stream):
+        self._multi(self._unpack_all, f, b, regions, bufs, stream)
 
     def sumsq_begin(self, stream):
         """bracket the box calls of a sweep: their partial sums are reduced once, by sumsq_end (include/lsf.h)"""
@@ -305,8 +334,11 @@ class DistributedReinit:
         be.wait(be.comm, be.compute)  # f was produced on the compute stream
         with be.stream_ctx(be.comm):
             ops = []
-            for (peer, s_box, _r, _a, _s), sb in zip(self.plan, self.send_bufs):
-                be.pack(f, self.b, s_box, sb, be.comm)
+            if hasattr(be, "pack_all"):  # the three to six face slabs in one launch
+                be.pack_all(f, self.b, [p[1] for p in self.plan], self.send_bufs, be.comm)
+            else:
+                for (peer, s_box, _r, _a, _s), sb in zip(self.plan, self.send_bufs):
+                    be.pack(f, self.b, s_box, sb, be.comm)
             send_bufs, recv_bufs = self.send_bufs, self.recv_bufs
             if self.staging:
                 for hb, sb in zip(self.send_host, self.send_bufs):
@@ -323,8 +355,11 @@ class DistributedReinit:
             if self.staging:
                 for hb, rb in zip(self.recv_host, self.recv_bufs):
                     rb.copy_(hb, non_blocking=True)
-            for (peer, _s, r_box, _a, _sd), rb in zip(self.plan, self.recv_bufs):
-                be.unpack(f, self.b, r_box, rb, be.comm)
+            if hasattr(be, "unpack_all"):
+                be.unpack_all(f, self.b, [p[2] for p in self.plan], self.recv_bufs, be.comm)
+            else:
+                for (peer, _s, r_box, _a, _sd), rb in zip(self.plan, self.recv_bufs):
+                    be.unpack(f, self.b, r_box, rb, be.comm)
 
     # -- one sweep: a_in -> a_out; returns nothing; self.sumsq accumulates the local sum of squares ---
     def sweep(self, a_in, a_out, phiS):

@@ -62,10 +62,8 @@ for G in grids:
         def fake_exchange(fld, dr=dr, be=be, b=b):  # pack + unpack on the comm stream, no transport
             be.wait(be.comm, be.compute)
             with be.stream_ctx(be.comm):
-                for (peer, s_box, _r, _a, _s), sb in zip(dr.plan, dr.send_bufs):
-                    be.pack(fld, b, s_box, sb, be.comm)
-                for (peer, _s, r_box, _a, _sd), rb in zip(dr.plan, dr.recv_bufs):
-                    be.unpack(fld, b, r_box, rb, be.comm)
+                be.pack_all(fld, b, [p[1] for p in dr.plan], dr.send_bufs, be.comm)
+                be.unpack_all(fld, b, [p[2] for p in dr.plan], dr.recv_bufs, be.comm)
 
         dr.exchange = fake_exchange
         rng = tuple((g, g + e) for g, e in zip(b.g0, b.ext))
