@@ -29,9 +29,14 @@ def _single(lsf, phi0, n, iters, dx, h, tol, arith):
 @pytest.mark.parametrize("npts,dims", [((70, 45, 52), (2, 2, 2)), ((70, 45, 52), (2, 2, 1)), ((41, 90, 33), (1, 4, 1)),
                                        ((30, 31, 64), (1, 1, 3)), ((140, 20, 22), (4, 1, 2)), ((36, 36, 36), (1, 1, 1))])
 @pytest.mark.parametrize("arith", ["strict", "fast"])
-def test_multi_equals_single_domain_bitwise(lsf, npts, dims, arith):
+@pytest.mark.parametrize("small", ["192", "0"])
+def test_multi_equals_single_domain_bitwise(lsf, npts, dims, arith, small, monkeypatch):
+    """small = 192 (default): blocks this size run a sweep as ONE launch over all owned cells after the exchange; 0: core beside the
+    exchange, then the rims (what blocks of 192 points and more per axis do).  The face slabs travel in one pack and one unpack
+    launch either way (lsf_pack_boxes).  Both equal the single-domain sweep bit for bit."""
     from levelsetfortran_amd import fields
 
+    monkeypatch.setenv("LSF_MULTI_SMALL", small)
     phi0, dx = fields.two_sphere_phi0(npts)
     n = tuple(v - 1 for v in npts)
     h = fields.reinit_step(dx)

@@ -225,6 +225,8 @@ def test_jacobi_fast_decomposed_equals_single_domain_bitwise(lsf, monkeypatch):
     kernel, y and z rims as thin shared-interface launches) returns the bits of the single-domain FAST sweep."""
     import torch
 
+    monkeypatch.setenv("LSF_MULTI_SMALL", "0")  # this test is about the core + rims split, which small blocks skip by default
+
     from levelsetfortran_amd import distributed as D
     from levelsetfortran_amd import fields
 
@@ -244,10 +246,12 @@ def test_jacobi_fast_decomposed_equals_single_domain_bitwise(lsf, monkeypatch):
     assert nsw == 3 and np.array_equal(be.to_numpy(out, b.ext), _host(whole, phi0.shape))
 
 
-def test_box_building_blocks_single_rank(lsf, oracle, synth):
+def test_box_building_blocks_single_rank(lsf, oracle, synth, monkeypatch):
     """lsf_jacobi_sweep_box + lsf_bc_box + pack/unpack (the multi-GPU pieces) on one GPU, split into
     core + rims exactly as a rank of a 2x2x2 decomposition would."""
     import torch
+
+    monkeypatch.setenv("LSF_MULTI_SMALL", "0")  # the core + rims split of a large block, on a small fixture
 
     from levelsetfortran_amd import distributed as D
 
