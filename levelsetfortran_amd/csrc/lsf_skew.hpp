@@ -1013,7 +1013,6 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : set_word;
                 const int* pd = a.planes_done;
                 const int4 swp = *(const int4*)(a.sweep_tab + 4 * s); // signs and spacing of the sweep: one request
-                const int need1 = s == 0 ? 0 : min(P + swp.w, np);
                 const int need3 = s < a.nbuf ? 0 : np + 1;
                 // absent conditions point at a word that always passes (the stop flag's neighbour ctl[1] >= 0)
                 const int* always = a.ctl + 1;
@@ -1033,6 +1032,11 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                     // that early -- a sweep advances as a front -- but the look is free)
                     const int u0 = ld_flag(w0), u1 = ld_flag(w1), u2 = ld_flag(w2);
                     up_ready = (u0 != 0) & (u1 != 0) & (u2 != 0);
+                    // (the spacing of the sweep is first used HERE, behind the flag loads: computed in front of the loop it made the
+                    // table load a round trip of its own between the order entry and the first look)
+                    int h = swp.w;
+                    asm volatile("" : "+v"(h));
+                    const int need1 = s == 0 ? 0 : min(P + h, np);
                     if (vstop != 0) {
                         go = 2;
                         give_up();
@@ -1232,7 +1236,6 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 const int* w1 = (B >= 1 && m >= m_lo(B - 1, C) && m <= m_hi(B - 1, C)) ? td + m + (long)nM * (B - 1 + (long)a.nTj * C) : set_word;
                 const int* w2 = (C >= 1 && m >= m_lo(B, C - 1) && m <= m_hi(B, C - 1)) ? td + m + (long)nM * (B + (long)a.nTj * (C - 1)) : set_word;
                 const int4 swp = *(const int4*)(a.sweep_tab + 4 * s); // signs and spacing of the sweep: one request
-                const int need1 = s == 0 ? 0 : min(P + swp.w, np);
                 const int* always = a.ctl + 4; // INT_MAX (host)
                 const int* p3 = s == 0 ? always : a.planes_done + s - 1;
                 const int* p3l = (s == 0 || !a.nb_pd[0]) ? always : a.pd_of_nb[0] + s - 1;
@@ -1244,6 +1247,9 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 for (;;) { // stage 1: conditions (b) and (c)
                     const int vstop = ld_flag_sys(a.ctl + 0);
                     const int v3 = ld_flag(p3), v3l = ld_flag_sys(p3l), v3h = ld_flag_sys(p3h), v4 = ld_flag_sys(p4);
+                    int h = swp.w; // first used behind the flag loads: the table load shares their round trip (see k_reinit_gs_persist)
+                    asm volatile("" : "+v"(h));
+                    const int need1 = s == 0 ? 0 : min(P + h, np);
                     if (vstop != 0) {
                         go = 2;
                         give_up();
