@@ -321,6 +321,27 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
             st0[q] = (int)s0;
         }
         const int nslots = st0[ns - 1] + np;
+        // A slab's hyperplane counter counts its LEADING complete hyperplanes, and those in front of its first tile are complete
+        // from the start: the counter (and its mirrors on the neighbours) starts there.  Left at 0 it only moved when the slab's
+        // first tile was done, and until then the neighbour's tiles of the NEXT sweep waited for hyperplanes that hold nothing --
+        // a needless stall between devices, and with slabs that share a device (a ticket loop with a fixed number of blocks) a
+        // deadlock as soon as more such tiles precede the neighbour's first tile in the list than there are blocks (found by the
+        // soak: 154 x 186 x 239 points, single-wavefront tiles, two slabs).
+        std::vector<std::vector<int>> pd_init((size_t)ndev, std::vector<int>((size_t)3 * DF_BATCH, 0));
+        {
+            auto first_plane = [&](const Slab& x, int v) {
+                int P = 0;
+                while (P < np && x.off[v][P + 1] == x.off[v][P]) ++P;
+                return P;
+            };
+            for (int d = 0; d < ndev; ++d)
+                for (int q = 0; q < ns; ++q) {
+                    const int v = tab[4 * q + 2] > 0 ? 0 : 1;
+                    pd_init[d][q] = first_plane(S.s[d], v);
+                    if (!model && d > 0) pd_init[d][DF_BATCH + q] = first_plane(S.s[d - 1], v);
+                    if (!model && d + 1 < ndev) pd_init[d][2 * DF_BATCH + q] = first_plane(S.s[d + 1], v);
+                }
+        }
         for (int d = 0; d < ndev; ++d) {
             Slab& b = S.s[d];
             HIPCHK(hipSetDevice(b.device));
@@ -362,6 +383,7 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
             a.nsweeps = ns, a.g0 = g0;
             // every slab's control words of the batch are clear before any slab starts (the neighbours store into them)
             HIPCHK(hipMemsetAsync(b.ctlblk + 16, 0, (size_t)4 * DF_BATCH * sizeof(int), b.st));
+            HIPCHK(hipMemcpyAsync(b.ctlblk + 16 + DF_BATCH, pd_init[d].data(), (size_t)3 * DF_BATCH * sizeof(int), hipMemcpyHostToDevice, b.st));
             HIPCHK(hipMemsetAsync(b.cnt, 0, ((size_t)DF_BATCH * np + 16) * sizeof(int), b.st));
             HIPCHK(hipMemsetAsync(b.tile_done, 0, (size_t)ns * per_sweep * sizeof(int), b.st));
             hipLaunchKernelGGL(k_build_order_slab, dim3(nslots), dim3(256), 0, b.st, b.order, (const uint32_t*)b.tiles[0], (const uint32_t*)b.tiles[1],
@@ -450,7 +472,27 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
     const int nsw = host_ctl[1];
     g_slab_report.slabs = ndev, g_slab_report.sweeps = nsw, g_slab_report.grid = grid_used, g_slab_report.fine = (int)fine;
     g_slab_report.kernel_ms = *std::max_element(kernel_ms.begin(), kernel_ms.end());
-    if (host_ctl[2] == 2) return fail(LSF_ERR_HIP, "exact ordering across slabs: a tile waited longer than the time-out for a predecessor");
+    if (host_ctl[2] == 2) {
+        // what the first tile to give up on each slab was waiting for (k_reinit_gs_slab, time_out)
+        std::string what;
+        for (int d = 0; d < ndev; ++d) {
+            int w[16] = {0};
+            if (hipSetDevice(S.s[d].device) != hipSuccess || hipMemcpy(w, S.s[d].ctlblk, sizeof w, hipMemcpyDeviceToHost) != hipSuccess || !w[8]) continue;
+            char buf[320];
+            const unsigned pk = (unsigned)w[9];
+            const int s_ = w[10] & (DF_BATCH - 1), P_ = (int)((unsigned)w[10] >> DF_SWEEP_BITS);
+            if (w[8] == 1)
+                snprintf(buf, sizeof buf, "; slab %d: tile (m %u, B %u, C %u) of sweep %d, hyperplane %d, waited for sweep %d to pass hyperplane %d: own counter %d, "
+                         "lower neighbour's %d, upper neighbour's %d, verdict word %d", d, pk & 0x3ff, (pk >> 10) & 0x3ff, (pk >> 20) & 0x3ff, s_, P_, s_ - 1, w[11],
+                         w[12], w[13], w[14], w[15]);
+            else
+                snprintf(buf, sizeof buf, "; slab %d: tile (m %u, B %u, C %u) of sweep %d, hyperplane %d, waited for its upstream tiles: flags along x %d, y %d, z %d",
+                         d, pk & 0x3ff, (pk >> 10) & 0x3ff, (pk >> 20) & 0x3ff, s_, P_, w[11], w[12], w[13]);
+            what += buf;
+        }
+        (void)hipGetLastError();
+        return fail(LSF_ERR_HIP, "exact ordering across slabs: a tile waited longer than the time-out for a predecessor" + what);
+    }
 
     // ---- result: every slab returns the planes it owns (walls k = 0 and k = nz with the first / last slab) ----------------
     for (int d = 0; d < ndev; ++d) {

@@ -1194,7 +1194,7 @@ static __global__ __launch_bounds__(256) void k_build_order_slab(uint2* __restri
 #define LSF_SLAB_WAVES 4
 #endif
 template <int TA, int WY, int WZ, int BY, bool STRICT, bool LOOP>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? (LOOP ? LSF_SLAB_WAVES : 5) : 1)))) void k_reinit_gs_slab(GsArgs args_)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : 2) : (WY == 2 && WZ == 2 ? (LOOP ? LSF_SLAB_WAVES : 5) : 1)))) void k_reinit_gs_slab(GsArgs args_)
 {
     using T = SkTile<TA, WY, WZ, BY>;
     __shared__ SkShared<T> sm;
@@ -1217,7 +1217,14 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
         const long per_sweep = (long)nM * a.nTj * a.nTk;
         const SkPre pre = sk_prefetch<TA, WY, WZ, BY>(a, tid); // in flight while the block takes its ticket and waits for its tile
         auto give_up = [&]() { __hip_atomic_fetch_max(a.ticket, (int)a.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-        auto time_out = [&]() { // tell every slab, so that none of them spins on for a tile that will not come
+        // tell every slab, so that none of them spins on for a tile that will not come; the first tile of this slab to give up leaves
+        // what it was waiting for in ctl[8..15] (the host puts it into the error message)
+        auto time_out = [&](unsigned packed_, int sP_, int stage, int x0, int x1, int x2, int x3, int x4) {
+            int expect = 0;
+            if (__hip_atomic_compare_exchange_strong(a.ctl + 8, &expect, stage, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                st_flag(a.ctl + 9, (int)packed_), st_flag(a.ctl + 10, sP_), st_flag(a.ctl + 11, x0), st_flag(a.ctl + 12, x1);
+                st_flag(a.ctl + 13, x2), st_flag(a.ctl + 14, x3), st_flag(a.ctl + 15, x4);
+            }
             for (int q = 0; q < a.nslab; ++q) st_flag_sys(a.peers->all_ctl[q] + 2, 2), st_flag_sys(a.peers->all_ctl[q] + 0, 1);
         };
         if (tid == 0) {
@@ -1263,7 +1270,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                         break;
                     }
                     if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
-                        time_out();
+                        time_out(e.x, (int)e.y, 1, need1, v3, v3l, v3h, v4);
                         go = 2;
                         break;
                     }
@@ -1295,7 +1302,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                     }
                     if ((v0 != 0) & (v1 != 0) & (v2 != 0)) break;
                     if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
-                        time_out();
+                        time_out(packed, sP, 2, v0, v1, v2, 0, 0);
                         go2 = 2;
                         break;
                     }

@@ -1,8 +1,12 @@
 """randomised soak of the exact ordering: odd grids, 1-3 slabs on one device, tile shapes, both arithmetics, against lsf_reinit;
-and lsf_reinit (dataflow) against the slot launches.  python3 profiles/micro/slab_soak.py [cases=40] [seed=1] [min points] [max points]"""
+lsf_reinit (dataflow) against the slot launches and against the launch with resident blocks and column continuation (LSF_GS_STREAM=1);
+STRICT cases of up to 6e6 cell updates also against the CPU oracle (tests/oracle_lib.py: the reference's bits).
+python3 profiles/micro/slab_soak.py [cases=40] [seed=1] [min points] [max points]"""
 import os, sys, random
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tests')
 import numpy as np
+import oracle_lib
 import levelsetfortran_amd as L
 from levelsetfortran_amd import fields
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -31,6 +35,21 @@ for case in range(n_cases):
     os.environ.pop("LSF_GS_SCHEDULE")
     ok = np.array_equal(slot, want) and r0.count == r1.count
     msgs = []
+    if not ok:
+        msgs.append("slot launches differ")
+    os.environ["LSF_GS_STREAM"] = "1"
+    strm = phi0.copy(order="F")
+    r2 = L.reinit(strm, None, None, *n, sweeps - 1, dx, h, tol=0.0, order="gs", arith=arith)
+    os.environ.pop("LSF_GS_STREAM")
+    if not (np.array_equal(strm, want) and r2.count == r1.count and r2.rms == r1.rms):
+        ok = False; msgs.append("resident-block launch differs")
+    checked_oracle = False
+    if arith == "strict" and float(np.prod(n)) * sweeps <= 6e6:
+        ref = phi0.copy(order="F")
+        oracle_lib.reinit(ref, *n, sweeps - 1, dx, h, tol=0.0)
+        checked_oracle = True
+        if not np.array_equal(ref, want):
+            ok = False; msgs.append("differs from the oracle")
     nzc = 16 if (shape or "").startswith("c") else 4 * int((shape or "2x2").split("x")[-1] if "x" in (shape or "2x2") else 1)
     layers = -(-(n[2] - 1) // nzc)
     for slabs in (1, 2, 3):
@@ -46,6 +65,6 @@ for case in range(n_cases):
         if not good:
             msgs.append(f"slabs={slabs} differs")
     bad += not ok
-    print(case, npts, arith, shape, sweeps, os.environ.get("LSF_DF_BATCH"), "ok" if ok else ("FAIL " + "; ".join(msgs)), flush=True)
+    print(case, npts, arith, shape, sweeps, os.environ.get("LSF_DF_BATCH"), ("ok+oracle" if checked_oracle else "ok") if ok else ("FAIL " + "; ".join(msgs)), flush=True)
 print("failures:", bad)
 sys.exit(1 if bad else 0)

@@ -221,3 +221,16 @@ def test_slabs_single_sweep(lsf):
     """iter = 0: one sweep, one batch of one"""
     want, r1, got, r = _both(lsf, (40, 36, 26), 2, 0, "strict")
     assert r.count == r1.count == 1 and np.array_equal(got, want) and r.rms == r1.rms
+
+
+@pytest.mark.parametrize("arith", ["fast", "strict"])
+def test_slabs_counters_start_at_a_slabs_first_hyperplane(lsf, env, arith):
+    """A slab's hyperplane counter counts its leading complete hyperplanes; those in front of its first tile hold nothing and are
+    complete from the start.  Found by the round-4 soak (profiles/r04_soak.txt): 154 x 186 x 239 points, single-wavefront tiles
+    (60 tile layers in z, 108 tiles per hyperplane), two slabs on one device -- the upper slab's tiles of sweep 2 waited for the
+    lower slab's counter of sweep 1, which stayed at 0 until that slab's first tile (hyperplane 37) was done, and there were more
+    of them in front of it in the list than the ticket loop has blocks: a time-out.  (On slabs with a device each the same wait
+    was a stall, not a deadlock.)"""
+    env["LSF_GS_SKEW_W"] = "c1x1"
+    want, r1, got, r = _both(lsf, (154, 186, 239), 2, 5, arith)
+    assert np.array_equal(got, want) and r.rms == r1.rms and r.count == r1.count == 6
