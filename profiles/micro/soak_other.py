@@ -5,7 +5,7 @@
   M  min/max flow: narrowBand and the exact flow in both executors (fixed-point passes, tile wavefront) against the oracle, bit for
      bit: field, masks, iteration count; the Jacobi flow against the oracle's;
   S  the stop test of the exact ordering (grids of up to 40 000 cells): a tolerance placed between two residuals of the oracle's trace
-     must stop every executor (dataflow launch with random batch length and buffer count, slot launches, resident blocks, two
+     must stop every executor (dataflow launch with random batch length and buffer count, slot launches on skewed and on box tiles, plane launches, resident blocks, two
      slabs) at the oracle's sweep with the oracle's field, STRICT; FAST: the executors among themselves.
 python3 profiles/micro/soak_other.py [cases=60] [seed=1] [min points=8] [max points=80]"""
 import os, random, sys
@@ -124,15 +124,15 @@ for case in range(n_cases):
             assert cnt_o == k + 1
             for arith_ in ("strict", "fast"):
                 first = None
-                for ex in ("dataflow", "skew", "stream", "slabs"):
+                for ex in ("dataflow", "skew", "slots", "planes", "stream", "slabs"):
                     for kk in ("LSF_GS_SCHEDULE", "LSF_GS_STREAM", "LSF_DF_BATCH", "LSF_GS_NBUF"):
                         os.environ.pop(kk, None)
                     if rng.random() < 0.5:
                         os.environ["LSF_DF_BATCH"] = "8"
                     if rng.random() < 0.5:
                         os.environ["LSF_GS_NBUF"] = "3"
-                    if ex == "skew":
-                        os.environ["LSF_GS_SCHEDULE"] = "skew"
+                    if ex in ("skew", "slots", "planes"):
+                        os.environ["LSF_GS_SCHEDULE"] = ex
                     if ex == "stream":
                         os.environ["LSF_GS_STREAM"] = "1"
                     g = phi0.copy(order="F")
@@ -152,7 +152,7 @@ for case in range(n_cases):
                     elif first is None:
                         first = (rr.count, g, rr.rms)
                     elif not (rr.count == first[0] and np.array_equal(g, first[1]) and
-                              (np.allclose(rr.rms, first[2], rtol=1e-12, atol=0) if ex == "skew" else rr.rms == first[2])):  # (slot launches sum the RMS in another order)
+                              (np.allclose(rr.rms, first[2], rtol=1e-12, atol=0) if ex in ("skew", "slots", "planes") else rr.rms == first[2])):  # (slot launches sum the RMS in another order)
                         msgs.append(f"stop fast {ex} differs from the dataflow launch")
                 for kk in ("LSF_GS_SCHEDULE", "LSF_GS_STREAM", "LSF_DF_BATCH", "LSF_GS_NBUF"):
                     os.environ.pop(kk, None)
