@@ -226,6 +226,62 @@ struct SkShared {
     double wsum[T::W];
 };
 
+// The LDS offsets of a lane's stencil at step 0 (skew_tile).  Functions, not lambdas of skew_tile: captured by reference inside the
+// loaders' lambdas the arrays went to scratch memory.
+// Three lanes per cell: index of the stencil value mm - 3 along the lane's axis.
+template <class T>
+__device__ __forceinline__ void sk_lane_offsets3(int axis, int si, int sj, int sk, bool deep, const SkPre& pre, int bc, int cc, int nj, int nk,
+                                                 int (&off)[7])
+{
+    const bool pos = (axis == 0 ? si : (axis == 1 ? sj : sk)) > 0;
+    if (deep) { // one 16-byte load instead of ~25 vector instructions per offset
+        const uint4 pk = pos ? pre.off1 : pre.off0;
+        off[0] = (int)(pk.x & 0xffffu), off[1] = (int)(pk.x >> 16), off[2] = (int)(pk.y & 0xffffu), off[3] = (int)(pk.y >> 16);
+        off[4] = (int)(pk.z & 0xffffu), off[5] = (int)(pk.z >> 16), off[6] = (int)(pk.w & 0xffffu);
+    } else {
+#pragma unroll
+        for (int mm = 0; mm < 7; ++mm) off[mm] = T::lane_off(bc, cc, axis, pos, nj, nk, mm);
+    }
+#pragma unroll
+    for (int mm = 0; mm < 7; ++mm) asm volatile("" : "+v"(off[mm])); // computed where the caller stands, not at the first use
+}
+// One lane per cell: index of the stencil value mm - 3 along x / y / z (ox[3] = the cell itself).
+template <class T>
+__device__ __forceinline__ void sk_lane_offsets1(int si, int sj, int sk, int bc, int cc, int nj, int nk, int (&ox)[7], int (&oy)[7], int (&oz)[7])
+{
+    constexpr int NYT = T::NYT, NZT = T::NZT;
+    if (nj == NYT && nk == NZT) {
+        // full tile: the 19 offsets in ~90 instructions instead of 19 calls of lane_off (~25 each): the row d places up or down
+        // the bundle is d rows (planes) further in the same row group, or in the halo group of that side
+        constexpr int RA_ = T::RA, RH_ = T::RH, PS_ = NYT * T::RA + T::PAD;
+        const int base = T::core_at(cc * NYT + bc) + 3; // the cell itself at step 0
+        const int yu = T::HB + (T::YU0 - T::NCORE + cc * 3 + 3 + bc) * RH_ + 3, yd = T::HB + (T::YD0 - T::NCORE + cc * 3 + bc - NYT) * RH_ - 1;
+        const int zu = T::HB + (T::ZU0 - T::NCORE + (cc + 3) * NYT + bc) * RH_ + 3, zd = T::HB + (T::ZD0 - T::NCORE + (cc - NZT) * NYT + bc) * RH_ - 1;
+        int fy[7], fz[7]; // by frame offset d + 3
+#pragma unroll
+        for (int d = -3; d <= 3; ++d) {
+            const int bq = bc + d, cq = cc + d;
+            fy[d + 3] = bq < 0 ? yu + d * (RH_ + 1) : (bq >= NYT ? yd + d * (RH_ + 1) : base + d * (RA_ + 1));
+            fz[d + 3] = cq < 0 ? zu + d * (NYT * RH_ + 1) : (cq >= NZT ? zd + d * (NYT * RH_ + 1) : base + d * (PS_ + 1));
+        }
+#pragma unroll
+        for (int mm = 0; mm < 7; ++mm) {
+            ox[mm] = base + (si > 0 ? mm - 3 : 3 - mm);
+            oy[mm] = sj > 0 ? fy[mm] : fy[6 - mm];
+            oz[mm] = sk > 0 ? fz[mm] : fz[6 - mm];
+        }
+    } else {
+#pragma unroll
+        for (int mm = 0; mm < 7; ++mm) {
+            ox[mm] = T::lane_off(bc, cc, 0, si > 0, nj, nk, mm);
+            oy[mm] = T::lane_off(bc, cc, 1, sj > 0, nj, nk, mm);
+            oz[mm] = T::lane_off(bc, cc, 2, sk > 0, nj, nk, mm);
+        }
+    }
+#pragma unroll
+    for (int mm = 0; mm < 7; ++mm) asm volatile("" : "+v"(ox[mm]), "+v"(oy[mm]), "+v"(oz[mm]));
+}
+
 // One tile.  SC1 = false: every value this tile reads was written by an earlier launch (slot schedule).
 // SC1 = true: producers may have run in this launch on another XCD (persistent schedule): results are stored
 // write-through and drained before the caller publishes the tile, phi is loaded past the non-coherent caches
@@ -384,6 +440,35 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     auto ps_load = [&](int t) {
         return ps_t[(unsigned)(e_ps.x >> 2) + (unsigned)min(max(e_ps.y + (si > 0 ? t : -t), 0), nx)];
     };
+    // ---- per-lane constants ---------------------------------------------------------------------------------
+    const int gj = j_lo + (sj > 0 ? bc : nj - 1 - bc), gk = k_lo + (sk > 0 ? cc : nk - 1 - cc);
+    const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
+    const int fx0 = X0 - bc - cc;
+    double acc = 0.0;
+    // per-lane bit t: the cell of step t exists (0 <= fx0 + t < nxi) / takes the WENO branch (3 < gi < nx - 4)
+    auto step_mask = [](int lo_t, int hi_t) { // bits lo_t .. hi_t - 1 of 16
+        lo_t = min(max(lo_t, 0), TA), hi_t = min(max(hi_t, lo_t), TA);
+        return ((1u << hi_t) - 1u) & ~((1u << lo_t) - 1u);
+    };
+    const unsigned act_bits = row_ok ? step_mask(-fx0, nxi - fx0) : 0u;
+    // 3 < gi < nx - 4 with gi = 1 + fx (si > 0: 2 < fx < nx - 5) or gi = nx - 1 - fx (si < 0: 3 < fx < nx - 4)
+    const unsigned weno_bits = yz_weno ? step_mask((si > 0 ? 3 : 4) - fx0, (si > 0 ? nx - 5 : nx - 4) - fx0) : 0u;
+
+    // LDS offsets of a lane's stencil.  They used to be computed behind the barrier that ends the load phase: ~300 (three lanes per
+    // cell) / ~700 (one lane per cell) instructions between the arrival of the upstream tiles' values and the first marching step,
+    // on the critical path of every hand-off.  Now in front of the wait for the upstream tiles and pinned there -- one lane per cell:
+    // behind the first load stage, the loads in flight; three lanes per cell: in front of the loads (96 registers per lane leave no
+    // room for them beside the loads in flight: 832 bytes of scratch when tried).  Round 4, A/B/A/B on one box, ms per sweep:
+    // 128^3 FAST 0.308 -> 0.279, STRICT 0.498 -> 0.474; 256^3 0.637 -> 0.607, 1.036 -> 1.008; 512^3 unchanged (not bound by a chain).
+    [[maybe_unused]] bool yquirk = false;
+    [[maybe_unused]] int row_core = 0;
+    [[maybe_unused]] int off[7] = {0, 0, 0, 0, 0, 0, 0}; // three lanes per cell (sk_lane_offsets3)
+    [[maybe_unused]] int ox[7] = {0, 0, 0, 0, 0, 0, 0}, oy[7] = {0, 0, 0, 0, 0, 0, 0}, oz[7] = {0, 0, 0, 0, 0, 0, 0}; // one lane per cell (sk_lane_offsets1)
+    if constexpr (BY == 5) {
+        yquirk = axis == a.quirk_axis;
+        row_core = T::core_at(cc * NYT + bc) + 3;
+        sk_lane_offsets3<T>(axis, si, sj, sk, deep, pre, bc, cc, nj, nk, off);
+    }
     // Wide path: a deep tile (full, every row of its image an interior row) whose image also stays inside the grid along the
     // march axis -- entries 0 .. 22 of every row are interior cells -- needs no clamp, no interior test and no choice between
     // `in` and `out` per entry: its rows travel as 16-byte buffer loads (two entries per lane, 10 / 9 lanes per row; the pair is
@@ -431,6 +516,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         }
 #pragma unroll
         for (int t = 0; t < NPS; ++t) ps[t] = ps_load(t);
+        if constexpr (BY == 16) sk_lane_offsets1<T>(si, sj, sk, bc, cc, nj, nk, ox, oy, oz);
         if (!wait_upstream()) {
             loaded = false;
             return;
@@ -516,6 +602,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         }
 #pragma unroll
         for (int t = 0; t < NPS; ++t) ps[t] = ps_load(t);
+        if constexpr (BY == 16) sk_lane_offsets1<T>(si, sj, sk, bc, cc, nj, nk, ox, oy, oz);
         if (!wait_upstream()) {
             loaded = false;
             return;
@@ -572,35 +659,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     __syncthreads();
     LSF_PHASE(2);
 
-    // ---- per-lane constants ---------------------------------------------------------------------------------
-    const int gj = j_lo + (sj > 0 ? bc : nj - 1 - bc), gk = k_lo + (sk > 0 ? cc : nk - 1 - cc);
-    const bool yz_weno = gj > 3 && gj < ny - 4 && gk > 3 && gk < nz - 4;
-    const int fx0 = X0 - bc - cc;
-    double acc = 0.0;
-    // per-lane bit t: the cell of step t exists (0 <= fx0 + t < nxi) / takes the WENO branch (3 < gi < nx - 4)
-    auto step_mask = [](int lo_t, int hi_t) { // bits lo_t .. hi_t - 1 of 16
-        lo_t = min(max(lo_t, 0), TA), hi_t = min(max(hi_t, lo_t), TA);
-        return ((1u << hi_t) - 1u) & ~((1u << lo_t) - 1u);
-    };
-    const unsigned act_bits = row_ok ? step_mask(-fx0, nxi - fx0) : 0u;
-    // 3 < gi < nx - 4 with gi = 1 + fx (si > 0: 2 < fx < nx - 5) or gi = nx - 1 - fx (si < 0: 3 < fx < nx - 4)
-    const unsigned weno_bits = yz_weno ? step_mask((si > 0 ? 3 : 4) - fx0, (si > 0 ? nx - 5 : nx - 4) - fx0) : 0u;
-
     if constexpr (BY == 5) {
-        const bool yquirk = axis == a.quirk_axis;
-        const int row_core = T::core_at(cc * NYT + bc) + 3;
-        int off[7];
-        {
-            const bool pos = (axis == 0 ? si : (axis == 1 ? sj : sk)) > 0;
-            if (deep) { // one 16-byte load instead of ~25 vector instructions per offset
-                const uint4 pk = pos ? pre.off1 : pre.off0;
-                off[0] = (int)(pk.x & 0xffffu), off[1] = (int)(pk.x >> 16), off[2] = (int)(pk.y & 0xffffu), off[3] = (int)(pk.y >> 16);
-                off[4] = (int)(pk.z & 0xffffu), off[5] = (int)(pk.z >> 16), off[6] = (int)(pk.w & 0xffffu);
-            } else {
-#pragma unroll
-                for (int mm = 0; mm < 7; ++mm) off[mm] = T::lane_off(bc, cc, axis, pos, nj, nk, mm);
-            }
-        }
         // ---- march: TA steps, every lane busy; the wavefronts of a tile meet after every step -----------------
         // (one instance, fully unrolled: a second instance without step masks for tiles whose every cell takes the WENO branch,
         // -11 % vector instructions per step, was 5 % SLOWER -- the kernel grew from 44 to 52 KB --, the march as a loop of two
@@ -631,35 +690,6 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         }
     } else {
         // ---- one lane per cell: the lane evaluates the three axes of its cell; 19 LDS reads, one LDS write per cell ----
-        int ox[7], oy[7], oz[7]; // LDS index of the stencil value mm - 3 along x / y / z at step 0 (ox[3] = the cell itself)
-        if (nj == NYT && nk == NZT) {
-            // full tile: the 19 offsets in ~90 instructions instead of 19 calls of lane_off (~25 each): the row d places up or down
-            // the bundle is d rows (planes) further in the same row group, or in the halo group of that side
-            constexpr int RA_ = T::RA, RH_ = T::RH, PS_ = NYT * T::RA + T::PAD;
-            const int base = T::core_at(cc * NYT + bc) + 3; // the cell itself at step 0
-            const int yu = T::HB + (T::YU0 - T::NCORE + cc * 3 + 3 + bc) * RH_ + 3, yd = T::HB + (T::YD0 - T::NCORE + cc * 3 + bc - NYT) * RH_ - 1;
-            const int zu = T::HB + (T::ZU0 - T::NCORE + (cc + 3) * NYT + bc) * RH_ + 3, zd = T::HB + (T::ZD0 - T::NCORE + (cc - NZT) * NYT + bc) * RH_ - 1;
-            int fy[7], fz[7]; // by frame offset d + 3
-#pragma unroll
-            for (int d = -3; d <= 3; ++d) {
-                const int bq = bc + d, cq = cc + d;
-                fy[d + 3] = bq < 0 ? yu + d * (RH_ + 1) : (bq >= NYT ? yd + d * (RH_ + 1) : base + d * (RA_ + 1));
-                fz[d + 3] = cq < 0 ? zu + d * (NYT * RH_ + 1) : (cq >= NZT ? zd + d * (NYT * RH_ + 1) : base + d * (PS_ + 1));
-            }
-#pragma unroll
-            for (int mm = 0; mm < 7; ++mm) {
-                ox[mm] = base + (si > 0 ? mm - 3 : 3 - mm);
-                oy[mm] = sj > 0 ? fy[mm] : fy[6 - mm];
-                oz[mm] = sk > 0 ? fz[mm] : fz[6 - mm];
-            }
-        } else {
-#pragma unroll
-            for (int mm = 0; mm < 7; ++mm) {
-                ox[mm] = T::lane_off(bc, cc, 0, si > 0, nj, nk, mm);
-                oy[mm] = T::lane_off(bc, cc, 1, sj > 0, nj, nk, mm);
-                oz[mm] = T::lane_off(bc, cc, 2, sk > 0, nj, nk, mm);
-            }
-        }
         const bool quirk_x = a.quirk_axis == 0, quirk_y = a.quirk_axis == 1;
 #pragma unroll 1
         for (int t0 = 0; t0 < TA; t0 += CU) {
@@ -952,7 +982,7 @@ static __global__ __launch_bounds__(256) void k_build_order(uint2* __restrict__ 
 
 // Slot schedule: one launch per time slot, one block per tile of the slot (dependencies resolved by launch order).
 template <int TA, int WY, int WZ, int BY, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_skew(GsArgs a)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : 2) : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_skew(GsArgs a)
 {
     const int bx = (int)blockIdx.x;
     const int seg = (bx >= a.seg_end[0]) + (bx >= a.seg_end[1]) + (bx >= a.seg_end[2]);
@@ -975,7 +1005,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
 // time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
 // plane_cnt[s][P]; the last tile of a hyperplane publishes planes_done[s] = P + 1.
 template <int TA, int WY, int WZ, int BY, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? 2 : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_persist(GsArgs a)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : 2) : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_persist(GsArgs a)
 {
     using T = SkTile<TA, WY, WZ, BY>;
     __shared__ SkShared<T> sm;
