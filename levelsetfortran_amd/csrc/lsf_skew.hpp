@@ -738,6 +738,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
                            (fx_min <= 0 && fx_max >= 0) || (fx_min <= nxi - 1 && fx_max >= nxi - 1);
     if (widex) { // every cell of the tile exists and none touches a wall: 16-byte stores, two results per lane
         const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out_t, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no load is in flight (see the other branch)
 #pragma unroll
         for (int u = 0; u < (T::NCORE + 8 * W - 1) / (8 * W); ++u) {
             const int r = 8 * W * u + (tid >> 3), t = 2 * (tid & 7);
@@ -849,7 +850,12 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
             }
         }
     }
-    // 2. the cells: nothing waits between these stores
+    // 2. the cells: nothing waits between these stores -- and nothing behind them either: the compiler is told HERE (a wait it
+    //    understands, free for a tile away from the walls: nothing is outstanding) that no load is in flight any more.  Without it
+    //    the first reuse of a register behind the stores waited for ALL outstanding memory operations (a load of the wall-point
+    //    branch counted as possibly pending): the result stores drained before the tile's RMS sum was formed, and the store of that
+    //    sum drained again.  Worth 0.3-1 % on grids up to 256^3 (A/B/A/B, profiles/r04_hops.txt), nothing at 512^3.
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
 #pragma unroll
     for (int u = 0; u < NUW; ++u) {
         const WbRow w = wb_row(u);
