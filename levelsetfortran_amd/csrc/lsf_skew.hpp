@@ -782,13 +782,13 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         int2 e;
         bool mine;
     };
-    auto wb_row = [&](int u) {
+    auto wb_row_e = [&](int u, int2 e_) {
         WbRow w;
         const int r = 4 * W * u + (tid >> 4);
         w.cq = r / NYT;
         const int bq = r - NYT * w.cq;
         w.t = tid & 15;
-        w.e = rowtab[r];
+        w.e = e_;
         w.gi = w.e.y + (si > 0 ? w.t : -w.t);
         w.mine = bq < nj && w.cq < nk && (unsigned)(w.gi - 1) <= (unsigned)(nx - 2);
         w.gj2 = j_lo + (sj > 0 ? bq : nj - 1 - bq), w.gk2 = k_lo + (sk > 0 ? w.cq : nk - 1 - w.cq);
@@ -797,6 +797,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         w.ak = w.gk2 == 1 ? -1 : (w.gk2 == nz - 1 ? 1 : 0);
         return w;
     };
+    auto wb_row = [&](int u) { return wb_row_e(u, rowtab[4 * W * u + (tid >> 4)]); };
     auto sub_on = [](const WbRow& w, int sub) { return !(((sub & 1) && !w.ai) || ((sub & 2) && !w.aj) || ((sub & 4) && !w.ak)); };
     // 1. the wall points, chunk by chunk -- only loads are outstanding when a chunk waits for its old values, and a wavefront
     //    without wall points (most wavefronts of a tile at a wall) passes without waiting at all
@@ -856,10 +857,21 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     //    branch counted as possibly pending): the result stores drained before the tile's RMS sum was formed, and the store of that
     //    sum drained again.  Worth 0.3-1 % on grids up to 256^3 (A/B/A/B, profiles/r04_hops.txt), nothing at 512^3.
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    // (row-table entries and results of a lane's rows read in ONE batch: row by row, every store followed two dependent LDS reads of
+    // its own -- ten LDS round trips in a row between the end of the march and the last store)
+    int2 e_wb[NUW];
+    double v_wb[NUW];
 #pragma unroll
     for (int u = 0; u < NUW; ++u) {
-        const WbRow w = wb_row(u);
-        const double val0 = lds[T::core_at(4 * W * u + (tid >> 4)) + 3 + w.t];
+        e_wb[u] = rowtab[4 * W * u + (tid >> 4)];
+        v_wb[u] = lds[T::core_at(4 * W * u + (tid >> 4)) + 3 + (tid & 15)];
+    }
+#pragma unroll
+    for (int u = 0; u < NUW; ++u) asm volatile("" : "+v"(e_wb[u].x), "+v"(e_wb[u].y), "+v"(v_wb[u]));
+#pragma unroll
+    for (int u = 0; u < NUW; ++u) {
+        const WbRow w = wb_row_e(u, e_wb[u]);
+        const double val0 = v_wb[u];
         if (w.mine) stp(out_t + ((unsigned)(w.e.x >> 2) + (unsigned)w.gi), val0);
         if constexpr (PUSH) {
             if (w.mine && nb_lo && w.gk2 < k_push_lo) st_sys(nb_lo + org + ((unsigned)(w.e.x >> 2) + (unsigned)w.gi), val0);
