@@ -23,6 +23,38 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// The same butterfly, the same pairs in the same order -- hence the same bits -- without the LDS crossbar: gfx950's lane swaps
+// for the partners 32 and 16 lanes away, DPP row rotations and quad permutations for 8, 4, 2, 1.  Six ds_bpermute round trips
+// (~700 cycles when nothing else runs on the SIMD) become ~30 vector instructions; used where the sum sits between a tile's
+// last store and its flag (skew_tile).
+__device__ __forceinline__ double wave_sum_x(double v)
+{
+    auto join = [](int lo, int hi) { return __hiloint2double(hi, lo); };
+    {   // partner 32 lanes away: a = [v(0..31) | v(0..31)], b = [v(32..63) | v(32..63)]
+        const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = join(l[0], h[0]) + join(l[1], h[1]);
+    }
+    {   // 16 lanes away: a = rows [0, 0, 2, 2], b = rows [1, 1, 3, 3]
+        const auto l = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = join(l[0], h[0]) + join(l[1], h[1]);
+    }
+    // 8 lanes away: row_ror:8
+    v += join(__builtin_amdgcn_update_dpp(0, __double2loint(v), 0x128, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x128, 0xf, 0xf, false));
+    {   // 4 lanes away: lanes 0..3 and 8..11 of a row (banks 0, 2) read lane + 4 = row_ror:12, the others lane - 4 = row_ror:4
+        int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x12c, 0xf, 0x5, false);
+        lo = __builtin_amdgcn_update_dpp(lo, __double2loint(v), 0x124, 0xf, 0xa, false);
+        int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x12c, 0xf, 0x5, false);
+        hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(v), 0x124, 0xf, 0xa, false);
+        v += join(lo, hi);
+    }
+    // 2 and 1 lanes away: quad_perm [2,3,0,1] and [1,0,3,2]
+    v += join(__builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4e, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4e, 0xf, 0xf, false));
+    v += join(__builtin_amdgcn_update_dpp(0, __double2loint(v), 0xb1, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xb1, 0xf, 0xf, false));
+    return v;
+}
+
 // lane l receives the value of lane l - 1 of the wavefront (lane 0: undefined), DPP wave_shr:1
 __device__ __forceinline__ double dpp_shr1(double v)
 {

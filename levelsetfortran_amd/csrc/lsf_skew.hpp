@@ -879,7 +879,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         }
     }
     }
-    acc = wave_sum(acc);
+    acc = wave_sum_x(acc);
     if (W > 1) { // fixed-order sum over the wavefronts of the tile
         if (lane == 0) wsum[wave] = acc;
         __syncthreads();
@@ -1122,6 +1122,15 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
         const bool upstream_done = uni(sh_task[7]) != 0; // seen by thread 0 before the first load stage: nothing to wait for
         const int s = sP & (DF_BATCH - 1), P = (int)((unsigned)sP >> DF_SWEEP_BITS);
         if (go == 0) return;
+        // the tile's own flag: its address is formed HERE and kept (scalar registers) -- formed behind the drain of the tile's stores
+        // it cost two scalar loads of kernel arguments and their wait between the last barrier and the flag
+        typedef __attribute__((address_space(1))) int* GlobalIntPtr; // (a pointer that has been through an asm statement is a flat one otherwise)
+        GlobalIntPtr my_flag;
+        {
+            const int m_ = packed & 0x3ff, B_ = (packed >> 10) & 0x3ff, C_ = (packed >> 20) & 0x3ff;
+            my_flag = (GlobalIntPtr)(a.tile_done + s * per_sweep + m_ + (long)nM * (B_ + (long)a.nTj * C_));
+            asm volatile("" : "+s"(my_flag));
+        }
         const unsigned long long tsB = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
         // stage 2, called by skew_tile with its stage-1 loads in flight: condition (a) -- the upstream tiles of this sweep
         auto wait_upstream = [&]() -> bool {
@@ -1160,8 +1169,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
         }
         __syncthreads(); // every wave of the tile has drained its stores (and left the LDS image)
         if (tid == 0 && go == 1) {
-            const int m = packed & 0x3ff, B = (packed >> 10) & 0x3ff, C = (packed >> 20) & 0x3ff;
-            st_flag(a.tile_done + s * per_sweep + m + (long)nM * (B + (long)a.nTj * C), 1);
+            __hip_atomic_store(my_flag, 1, __ATOMIC_RELAXED, LSF_FLAG_ST_SCOPE);
             const int done = __hip_atomic_fetch_add(a.plane_cnt + s * np + P, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             if (done == a.plane_size[P]) {
                 // Hyperplanes may complete out of order now; planes_done[s] counts the LEADING complete ones.  Whoever
