@@ -47,6 +47,9 @@
 #ifndef LSF_STREAM_PRIO
 #define LSF_STREAM_PRIO 1
 #endif
+#ifndef LSF_STRICT22_WAVES
+#define LSF_STRICT22_WAVES 4
+#endif
 #ifndef LSF_POLL_SLEEP
 #define LSF_POLL_SLEEP 16 // 64-cycle units between two looks of a waiting tile at its flags
 #endif
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
 // time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
 // plane_cnt[s][P]; the last tile of a hyperplane publishes planes_done[s] = P + 1.
 template <int TA, int WY, int WZ, int BY, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : 2) : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_persist(GsArgs a)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : 2) : (WY == 2 && WZ == 2 ? (STRICT ? LSF_STRICT22_WAVES : 5) : 1)))) void k_reinit_gs_persist(GsArgs a)
 {
     using T = SkTile<TA, WY, WZ, BY>;
     __shared__ SkShared<T> sm;
