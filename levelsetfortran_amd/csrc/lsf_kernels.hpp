@@ -825,6 +825,12 @@ static __global__ __launch_bounds__(256) void k_phi0(double* __restrict__ phi, i
     const double gX = xlo0 + i * dx, gY = xlo1 + j * dx, gZ = xlo2 + k * dx; // gridX, set3d.f90:168-170
     double minD = 100000.;
     int fN = 0;
+    // The reference compares ROUNDED distances, `dis < minD` with dis = sqrt(d2) (set3d.f90:231-235), and keeps the first minimum.  The
+    // square root is monotone, so with m2 = the smallest d2 seen so far (minD = min(100000, sqrt(m2))) a triangle with d2 >= m2 cannot
+    // pass that test; only a triangle with d2 < m2 needs its square root taken and the reference's comparison made -- which may still
+    // say "not smaller" (two different d2 can round to the same distance: the first one stays, as in the reference).  A lane's running
+    // minimum improves ~ln(nElem) times, not nElem times: the correctly rounded fp64 square root (~25 instructions) leaves the loop.
+    double m2 = __builtin_inf();
     for (int base = 0; base < nElem; base += PHI0_CHUNK) {
         const int cnt = min(PHI0_CHUNK, nElem - base);
         __syncthreads();
@@ -832,10 +838,20 @@ static __global__ __launch_bounds__(256) void k_phi0(double* __restrict__ phi, i
         __syncthreads();
         for (int n = 0; n < cnt; ++n) {
             const double pX = sc[3 * n], pY = sc[3 * n + 1], pZ = sc[3 * n + 2];
-            const double dis = __builtin_sqrt((pX - gX) * (pX - gX) + (pY - gY) * (pY - gY) + (pZ - gZ) * (pZ - gZ));
-            if (dis < minD) {
-                minD = dis;
-                fN = base + n;
+            const double d2 = (pX - gX) * (pX - gX) + (pY - gY) * (pY - gY) + (pZ - gZ) * (pZ - gZ);
+            // (a wavefront-uniform branch and an argument the compiler cannot see through: otherwise it computes the square root for
+            // every triangle in front of the branch and selects.  Four triangles per branch: the same time.)
+            if (__builtin_amdgcn_ballot_w64(d2 < m2) != 0ull) {
+                double arg = d2;
+                asm volatile("" : "+v"(arg));
+                if (d2 < m2) {
+                    m2 = d2;
+                    const double dis = __builtin_sqrt(arg);
+                    if (dis < minD) {
+                        minD = dis;
+                        fN = base + n;
+                    }
+                }
             }
         }
     }
