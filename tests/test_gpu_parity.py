@@ -375,6 +375,42 @@ def test_phi0_matches_reference(lsf, cube40, twocube):
         assert np.array_equal(_host(t, phi.shape), gold["phi0"])
 
 
+def test_phi0_first_minimum_of_rounded_distances(lsf, oracle):
+    """The reference compares ROUNDED distances, `dis < minD` with dis = sqrt(d2), and keeps the first minimum (set3d.f90:231-235).
+    k_phi0 takes the square root only where d2 falls below the smallest d2 seen so far -- exact, because the square root is monotone --
+    and this surface is built to hit the seam of that argument: centroids on spheres of equal radius around grid points, in
+    directions that are permutations and sign flips of integer triples of equal norm, so that d2 = x^2 + y^2 + z^2 differs from
+    centroid to centroid in its last bits only (many different d2 with the same rounded distance, in every order)."""
+    import itertools
+
+    dirs = []
+    for tri, sc in (((1, 2, 2), 0.21), ((2, 3, 6), 0.09), ((1, 4, 8), 0.07), ((4, 4, 7), 0.07)):  # all of length 0.63
+        for perm in set(itertools.permutations(tri)):
+            for sg in itertools.product((1, -1), repeat=3):
+                dirs.append(tuple(sc * c * g for c, g in zip(perm, sg)))
+    rng = np.random.default_rng(12)
+    rng.shuffle(dirs)
+    dx = 0.1
+    centres = [(20 * dx, 20 * dx, 20 * dx), (23 * dx, 19 * dx, 21 * dx), (18 * dx, 22 * dx, 20 * dx)]  # grid points (xLo = 0)
+    nodes, elems = [], []
+    d = 0.015625  # a dyadic offset: the three vertices average to the centroid up to the division's rounding
+    for c in centres:
+        for u in dirs:
+            ctr = np.array(c) + np.array(u)
+            base = len(nodes)
+            nodes += [ctr + (d, 0, 0), ctr + (-d, d, 0), ctr + (0, -d, 0)]
+            elems.append((base + 1, base + 2, base + 3))
+    X, E = np.array(nodes, dtype=np.float64), np.array(elems, dtype=np.int32)
+    n = (34, 33, 35)  # the surface's bounding box and three cells around it lie inside the grid (the search box, set3d.f90:180-186)
+    xLo = np.zeros(3)
+    mn, mx = X.min(axis=0), X.max(axis=0)
+    want = oracle.phi0(n[0], n[1], n[2], dx, xLo, mn, mx, X, E)
+    got = np.ones(tuple(v + 1 for v in n), order="F")
+    lsf.phi0Init(got, n[0], n[1], n[2], dx, xLo, mn, mx, X, E)
+    assert np.array_equal(got, want)
+    assert len(dirs) == 144 and np.unique(want).size > 1000
+
+
 def test_minmax_tile_wavefront_path(lsf, oracle, cube40, monkeypatch):
     """The exact ordering has two implementations: fixed-point passes (default) and the tile-hyperplane
     wavefront (fallback when a fixed point is not certified).  Force the fallback and re-check parity."""
