@@ -21,6 +21,7 @@
 #include "lsf_boxtile.hpp"
 #include "lsf_skew.hpp"
 #include "lsf_f32.hpp"
+#include "lsf_minmax_band.hpp"
 
 using namespace lsf;
 
@@ -126,20 +127,6 @@ int gs_march()
     const char* e = getenv("LSF_GS_MARCH");
     return (e && (e[0] == 'x' || e[0] == 'X')) ? 0 : 1;
 }
-// dataflow launch: one block per tile (k_reinit_gs_persist, default) or resident blocks that carry on down a tile column
-// (k_reinit_gs_stream, LSF_GS_STREAM=1); LSF_GS_CONT selects when such a block continues
-int gs_stream()
-{
-    const char* e = getenv("LSF_GS_STREAM");
-    return e && atoi(e) != 0; // opt-in: measured slower than the one-block-per-tile launch
-}
-// 0 = never; 1 = when the two cross upstream tiles of the next tile are claimed (the block then waits for them); 2 (default) = only
-// when they are done already (the block never waits while it holds a column)
-int gs_cont()
-{
-    const char* e = getenv("LSF_GS_CONT");
-    return e ? std::max(0, std::min(2, atoi(e))) : 2;
-}
 int gs_nbuf()
 {
     const char* e = getenv("LSF_GS_NBUF");
@@ -175,7 +162,7 @@ struct BatchPlan {
     int nslots = 0;
 };
 
-enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_PLANECNT, S_DBG, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_PONG3, S_PONG4, S_SNAP, S_NSLOTS };
+enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_PLANECNT, S_DBG, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_PONG3, S_PONG4, S_SNAP, S_MB_CNT, S_MB_L, S_MB_NB6, S_MB_AOLD, S_MB_A0, S_MB_BAND, S_NSLOTS };
 
 // partial sums of the box calls issued on one stream; `deferred`: between lsf_sumsq_begin and lsf_sumsq_end the calls
 // append their partials instead of reducing them one by one
@@ -325,6 +312,7 @@ int get_tiles(int nA, int nB, int nC, TileList** out)
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Skewed tiles (lsf_skew.hpp): (m, fB, fC) with TA m <= Fx + Fy + Fz < TA m + TA for some cell of row bundle
 // (fB, fC); the m range assumes full bundles (NY x 4 rows), a superset for the partial bundles at the far walls

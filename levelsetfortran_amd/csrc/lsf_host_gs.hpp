@@ -71,8 +71,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     // launches on the box tiles of lsf_boxtile.hpp (`slots`): 256^3 0.97 / 1.24 / 1.75 ms, 512^3 3.25 / 4.61 / 6.83 ms,
     // 1024^3 24.7 / 25.2 / 38.0 ms.
     if (sched < 0) sched = 5;
-    bool persist = sched == 5; // k_reinit_gs_stream / k_reinit_gs_persist
-    const bool stream = gs_stream();
+    bool persist = sched == 5; // k_reinit_gs_persist
     if (persist) sched = 3;
     // skewed tiles need TA = 16, NY = 5 and at least two interior cells per axis
     const bool skew = sched == 3 && ta == 16 && nyc == 5 && nx >= 3 && ny >= 3 && nz >= 3;
@@ -291,18 +290,9 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         if (strict) hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, BY_, true>), grid, dim3(64 * WY_ * WZ_), 0, st, fa); \
         else hipLaunchKernelGGL((k_reinit_gs_persist<16, WY_, WZ_, BY_, false>), grid, dim3(64 * WY_ * WZ_), 0, st, fa);       \
     } while (0)
-            // Default: one block per tile (k_reinit_gs_persist).  LSF_GS_STREAM=1: the launch with column continuation
-            // (k_reinit_gs_stream: resident blocks that loop over tiles and carry on down a tile column; lsf_stream.hip);
-            // LSF_GS_CONT=0: that loop without continuation (every tile acquired from the list).
-            if (stream) {
-                fa.cont_on = gs_cont();
-                int cus = 0;
-                HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device));
-                const hipError_t le = (hipError_t)launch_gs_stream(wy, wz, by, strict, st, fa, cus, nullptr);
-                if (le != hipSuccess) return fail(LSF_ERR_HIP, std::string("k_reinit_gs_stream: ") + hipGetErrorString(le));
-            } else {
-                LSF_SK_SHAPES(LSF_LAUNCH_DF, wy, wz, by);
-            }
+            // one block per tile (the launch with column continuation of round 4, k_reinit_gs_stream, lives on the branch
+            // r04-column-continuation: bit-identical and 9-20 % slower, profiles/r04_stream_ab.txt)
+            LSF_SK_SHAPES(LSF_LAUNCH_DF, wy, wz, by);
 #undef LSF_LAUNCH_DF
             ++launches;
             if (g0 + BATCH < max_sweeps || d_dbg) { // stop flag between batches (later batches would exit at once anyway)
@@ -311,9 +301,6 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
                 if (d_dbg) {
                     unsigned long long hd[16];
                     HIPCHK(hipMemcpy(hd, d_dbg, sizeof hd, hipMemcpyDeviceToHost));
-                    if (stream)
-                        fprintf(stderr, "[lsf] column continuation: %llu of %llu tiles continued; not continued: end of column %llu, previous sweep not past %llu, "
-                                "cross tiles unclaimed %llu, claim lost %llu\n", hd[8], hd[2], hd[9], hd[10], hd[11], hd[12]);
 #ifdef LSF_EXPERIMENTS
                     if (hd[7])
                         fprintf(stderr, "[lsf] tile phases (us per tile): row table %.2f, load %.2f, march %.2f, write back %.2f\n",
@@ -335,7 +322,18 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         HIPCHK(hipMemsetAsync(fa.dbg, 0, 64, st));
     }
 #endif
+#ifdef LSF_EXPERIMENTS
+    int* stagger_tab = nullptr;
+    if (slots_loop && skew && getenv("LSF_PROBE_STAGGER")) { // k_reinit_gs_skew: the second block of every CU starts late (work-term probe)
+        if ((rc = ws(c.slot[S_PLANECNT], 2048 * sizeof(int)))) return rc;
+        stagger_tab = (int*)c.slot[S_PLANECNT].p;
+        fa.ticket = stagger_tab, fa.probe_us = atoi(getenv("LSF_PROBE_STAGGER"));
+    }
+#endif
     auto launch_tiles = [&](int grid, hipStream_t s_) {
+#ifdef LSF_EXPERIMENTS
+        if (stagger_tab) (void)hipMemsetAsync(stagger_tab, 0, 2048 * sizeof(int), s_);
+#endif
         if (skew) {
 #define LSF_LAUNCH_SKEW(WY_, WZ_, BY_)                                                                                     \
     do {                                                                                                                   \
@@ -409,6 +407,14 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
 #ifdef LSF_EXPERIMENTS
+    if (stagger_tab) { // did the probe tell the CUs apart?  (blocks of the LAST launch per CU)
+        std::vector<int> ht(2048);
+        HIPCHK(hipMemcpy(ht.data(), stagger_tab, 2048 * sizeof(int), hipMemcpyDeviceToHost));
+        int used = 0, mx = 0;
+        long tot = 0;
+        for (int v : ht) used += v != 0, mx = std::max(mx, v), tot += v;
+        fprintf(stderr, "[lsf] stagger probe: %d CU entries used, %ld blocks, most per CU %d\n", used, tot, mx);
+    }
     if (fa.dbg) {
         unsigned long long hd[8];
         HIPCHK(hipMemcpy(hd, fa.dbg, sizeof hd, hipMemcpyDeviceToHost));
@@ -425,7 +431,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         g_prof.bc_ms = g_prof.finish_ms = 0;
         g_prof.sweeps = nsw;
         g_prof.sweep_launches = launches;
-        if (skew) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "%s<16,%d,%d,%d,%s>", !slots_loop ? (stream ? "k_reinit_gs_stream" : "k_reinit_gs_persist") : "k_reinit_gs_skew",
+        if (skew) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "%s<16,%d,%d,%d,%s>", !slots_loop ? "k_reinit_gs_persist" : "k_reinit_gs_skew",
                            wy, wz, by, strict ? "true" : "false");
         else snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "k_reinit_gs_box<%d,%d,%s>", ta, nyc, strict ? "true" : "false");
         g_prof.kernel = g_prof.kernel_buf;

@@ -39,16 +39,19 @@
                            // ms, STRICT 512^3 equal -- once its refill was taken out from behind a run-time branch, see the march)
 #endif
 
-// k_reinit_gs_stream: the blocks of a CU live as long as the launch, and between wavefronts of equal priority the OLDER one
-// is served first -- one block of every CU would win every contest for the vector unit, the other would always lose.  With
-// this switch a wavefront raises its priority as its march proceeds (0..3) and drops it with the tile: the tile that is further
-// along wins, which is what the one-block-per-tile launch does by itself (its blocks age: the same scheme in THAT launch is
-// 0.5-2.5 % slower, profiles/r04_stream_ab.txt).
-#ifndef LSF_STREAM_PRIO
-#define LSF_STREAM_PRIO 1
-#endif
 #ifndef LSF_STRICT22_WAVES
 #define LSF_STRICT22_WAVES 4
+#endif
+// work-term probes of a smaller LDS image of the one-lane-per-cell tile (experiment builds; the field comes out wrong): row pitches
+// of the bundle / halo rows and the wavefronts per SIMD the kernels are compiled for (profiles/r05_ring_probe.txt)
+#ifndef LSF_PROBE_RA
+#define LSF_PROBE_RA 0
+#endif
+#ifndef LSF_PROBE_RH
+#define LSF_PROBE_RH 0
+#endif
+#ifndef LSF_WAVES16
+#define LSF_WAVES16 2
 #endif
 #ifndef LSF_POLL_SLEEP
 #define LSF_POLL_SLEEP 16 // 64-cycle units between two looks of a waiting tile at its flags
@@ -81,19 +84,19 @@ struct SkTile {
     static_assert(BY == 5 || BY == 16, "three lanes per cell (5 rows) or one lane per cell (16 rows)");
     static constexpr int BYW = BY;
     static constexpr int NYT = BY * WY, NZT = 4 * WZ; // rows of a tile in y and z
-    static constexpr int RA = TA + 6;
+    static constexpr int RA = (BY == 16 && LSF_PROBE_RA) ? LSF_PROBE_RA : TA + 6;
     // one lane per cell: the 32 lanes of an LDS access group are 16 b x 2 c; b steps by RA = 22 doubles (the 16 b cover the
     // even bank pairs), so an odd plane pitch puts the second c on the odd ones: conflict-free ds_read_b64 / ds_write_b64
     static constexpr int PAD = BY == 16 ? 1 : 0;
     static constexpr int HB = WY * BY * NZT * RA + NZT * PAD; // first halo entry
-    static constexpr int RH = TA + 2;         // entries kept of a halo row
+    static constexpr int RH = (BY == 16 && LSF_PROBE_RH) ? LSF_PROBE_RH : TA + 2; // entries kept of a halo row
     static constexpr int NCORE = NZT * NYT;
     static constexpr int YH = 3 * NZT;
     static constexpr int ZP = (3 * NYT + 3) / 4 * 4;
     static constexpr int YU0 = NCORE, ZU0 = YU0 + YH, YD0 = ZU0 + ZP, ZD0 = YD0 + YH;
     static constexpr int NR = (ZD0 + ZP + 4 * W - 1) / (4 * W) * (4 * W);
     static_assert(NCORE % (4 * W) == 0, "whole store instructions");
-    static constexpr int TOTAL = HB + (NR - NCORE) * RH;
+    static constexpr int TOTAL = HB + (NR - NCORE) * RH + (LSF_PROBE_RA || LSF_PROBE_RH ? 32 : 0);
     // LDS index of entry 0 of bundle row r
     __host__ __device__ static constexpr int core_at(int r) { return r * RA + (PAD ? (r / NYT) * PAD : 0); }
     // LDS index of entry k of row r (halo rows store entry 0 resp. 4 first)
@@ -212,15 +215,6 @@ __device__ __forceinline__ SkPre sk_prefetch(const GsArgs& a, int tid = threadId
 // would be dropped without a trace.  (Planes of 3 500^2 ... 4 650^2 points passed the old test, 4.0e9 bytes, and lay outside.)
 __host__ __device__ inline bool sk_wide_image_fits(long sxy, int nzt) { return (double)(nzt + 7) * (double)sxy * 8.0 <= (double)(0x7fffffff - 16); }
 
-// (LSF_STREAM_PRIO) priority of a wavefront at step u of its march
-__device__ __forceinline__ void sk_march_prio(int u)
-{
-    if (u == 0) __builtin_amdgcn_s_setprio(0);
-    else if (u == 4) __builtin_amdgcn_s_setprio(1);
-    else if (u == 8) __builtin_amdgcn_s_setprio(2);
-    else if (u == 12) __builtin_amdgcn_s_setprio(3);
-}
-
 // LDS of one tile: declared by the kernel (a kernel that runs several tiles one after the other, or two tile functions, has one)
 template <class T>
 struct SkShared {
@@ -302,12 +296,11 @@ __device__ __forceinline__ void sk_lane_offsets1(int si, int sj, int sk, int bc,
 // each with field buffers of its own.  Results within three planes of a cut are stored into the neighbour's buffer as well
 // (same address map), the column's running RMS sum into the colsum of the slab that runs this sweep's epilogue, and the
 // epilogue's verdict into every slab's control words; all of that and every load at system scope.
-template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, bool PUSH = false, bool STREAM = false, class WaitUp>
+template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, bool PUSH = false, class WaitUp>
 __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, const GsArgs& a, uint32_t packed, int g, int si, int sj,
-                                          int sk, const SkPre& pre, WaitUp&& wait_upstream, int cont_ = 0)
+                                          int sk, const SkPre& pre, WaitUp&& wait_upstream)
 {
     static_assert(TA == 16, "row-per-16-lanes loader");
-    const int cont = STREAM ? cont_ : 0; // continued column (k_reinit_gs_stream only)
     using T = SkTile<TA, WY, WZ, BY>;
     constexpr int NYT = T::NYT, NZT = T::NZT, W = T::W, NT = 64 * W;
     double* const lds = sm.lds;
@@ -372,26 +365,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     // deep tile: full, and every row of its LDS image (3 halo rows on each side included) is an interior row
     const bool deep = a.tables && nj == NYT && nk == NZT && j_lo >= 4 && j_lo + NYT + 2 <= ny - 1 && k_lo >= 4 && k_lo + NZT + 2 <= nz - 1;
     const int dir = (sj > 0 ? 2 : 0) + (sk > 0 ? 1 : 0);
-    // Continued column (cont != 0, k_reinit_gs_stream): the LDS image still holds tile m - 1 of this column, marched and written
-    // back by this block.  Entries 16..21 of its bundle rows are entries 0..5 of this tile's (0..2 this sweep's values, computed
-    // here; 3..5 old ones), 16, 17 of its upstream and 20, 21 of its downstream halo rows are entries 0, 1 resp. 4, 5: they move
-    // inside LDS, the rows' table entries advance by one tile length, and the loader fetches 16 instead of 22 (18) entries per row.
-    constexpr int NSHC = (6 * T::NCORE + NT - 1) / NT, NSHH = (2 * (T::NR - T::NCORE) + NT - 1) / NT;
-    double shc[NSHC], shh[NSHH];
-    if (cont) {
-        for (int r = tid; r < T::NR; r += NT) rowtab[r].y += si > 0 ? TA : -TA;
-#pragma unroll
-        for (int u = 0; u < NSHC; ++u) {
-            const int idx = min(tid + NT * u, 6 * T::NCORE - 1), r = idx / 6, k = idx - 6 * r;
-            shc[u] = lds[T::core_at(r) + TA + k];
-        }
-#pragma unroll
-        for (int u = 0; u < NSHH; ++u) {
-            const int idx = min(tid + NT * u, 2 * (T::NR - T::NCORE) - 1), r = T::NCORE + (idx >> 1), k = idx & 1;
-            shh[u] = lds[T::at(r, (r < T::YD0 ? TA : TA + 4) + k)];
-        }
-    }
-    for (int r = tid; r < T::NR && !cont; r += NT) {
+    for (int r = tid; r < T::NR; r += NT) {
         if (deep) {
             const uint32_t w = r == tid ? (dir == 0 ? pre.rel.x : (dir == 1 ? pre.rel.y : (dir == 2 ? pre.rel.z : pre.rel.w)))
                                         : a.tables[4 * r + dir];
@@ -408,18 +382,6 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         rowtab[r] = make_int2(o * 4 + (rin & up) + 2 * (rin & (up | core)), si > 0 ? gi0 - (bq + cq) : gi0 + (bq + cq));
     }
     __syncthreads();
-    if (cont) {
-#pragma unroll
-        for (int u = 0; u < NSHC; ++u) {
-            const int idx = min(tid + NT * u, 6 * T::NCORE - 1), r = idx / 6, k = idx - 6 * r;
-            lds[T::core_at(r) + k] = shc[u];
-        }
-#pragma unroll
-        for (int u = 0; u < NSHH; ++u) {
-            const int idx = min(tid + NT * u, 2 * (T::NR - T::NCORE) - 1), r = T::NCORE + (idx >> 1), k = idx & 1;
-            lds[T::at(r, (r < T::YD0 ? 0 : 4) + k)] = shh[u];
-        }
-    }
     LSF_PHASE(1);
 
     // ---- load: all global loads in flight before the first LDS write ------------------------------------
@@ -482,16 +444,13 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     constexpr int AUX_SC1 = SYS ? 17 : (SC1 ? 16 : 0); // cache policy of the buffer instructions: sc1 = bit 4, sc0 = bit 0 (system scope: both)
     const bool widex = (LSF_SKEW_WIDE == 2 || (LSF_SKEW_WIDE == 1 && BY == 16)) && deep && X0 - (NYT + NZT + 4) >= 0 && X0 + 22 <= nxi - 1 &&
                        sk_wide_image_fits(sxy, NZT);
-    // both loaders come in two instances: CT = false loads the whole image, CT = true what a continued column still needs
     bool loaded = true;
-    auto load_wide = [&](auto ct_tag) {
-        constexpr bool CT = decltype(ct_tag)::value;
+    auto load_wide = [&]() {
         const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(in_t), 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out_t, 0, 0x7fffffff, 0x00020000);
         constexpr int RPI = 4 * W;
-        // (continued: the 16 entries a bundle row still needs are 8 requests: 8 lanes per row, 8 W rows per instruction)
-        constexpr int NB = CT ? T::NCORE / (2 * RPI) : T::NCORE / RPI, NU = (T::YD0 - T::YU0 + RPI - 1) / RPI, ND = (T::NR - T::YD0 + RPI - 1) / RPI;
-        constexpr int XC = 3 * T::NCORE, NXC = CT ? 0 : (XC + NT - 1) / NT;
+        constexpr int NB = T::NCORE / RPI, NU = (T::YD0 - T::YU0 + RPI - 1) / RPI, ND = (T::NR - T::YD0 + RPI - 1) / RPI;
+        constexpr int XC = 3 * T::NCORE, NXC = (XC + NT - 1) / NT;
         u4_t w[NB + ND + NU];
         int dw[NB + ND + NU];
         double v3[NXC + 1];
@@ -503,17 +462,16 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
             const unsigned el = (unsigned)(e.x >> 2) + (unsigned)(e.y + (si > 0 ? k - 3 : 2 - k));
             return __builtin_amdgcn_raw_buffer_load_b128(rs, 8u * el, 0, AUX_SC1);
         };
-        // ---- stage 1: what the previous sweep left (bundle rows entries 3 .. 21 (+ 22, dropped), downstream halo 4 .. 21;
-        //      continued: 6 .. 21 of both)
+        // ---- stage 1: what the previous sweep left (bundle rows entries 3 .. 21 (+ 22, dropped), downstream halo 4 .. 21)
 #pragma unroll
         for (int u = 0; u < NB; ++u, ++n_) {
-            const int r = CT ? 2 * RPI * u + (tid >> 3) : RPI * u + rsub, k = CT ? 6 + 2 * (tid & 7) : 3 + 2 * min(xx, 9);
+            const int r = RPI * u + rsub, k = 3 + 2 * min(xx, 9);
             dw[n_] = T::core_at(r) + k;
             w[n_] = pair_at(r_in, rowtab[r], k);
         }
 #pragma unroll
         for (int u = 0; u < ND; ++u, ++n_) {
-            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = CT ? 6 + 2 * min(xx, 7) : 4 + 2 * min(xx, 8);
+            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = 4 + 2 * min(xx, 8);
             dw[n_] = T::HB + (r - T::NCORE) * T::RH + k - 4;
             w[n_] = pair_at(r_in, rowtab[r], k);
         }
@@ -525,11 +483,10 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
             return;
         }
         if (tid == 0 && m != (NYT * fB + NZT * fC) / TA) colsum_prev = ldp(a.colsum + (long)gb * ncol + (tj + (long)a.nTj * tk));
-        // ---- stage 2: what the upstream tiles of this sweep wrote (upstream halo 0 .. 17, bundle rows entries 0 .. 2;
-        //      continued: upstream halo 2 .. 17)
+        // ---- stage 2: what the upstream tiles of this sweep wrote (upstream halo 0 .. 17, bundle rows entries 0 .. 2)
 #pragma unroll
         for (int u = 0; u < NU; ++u, ++n_) {
-            const int r = min(T::YU0 + RPI * u + rsub, T::YD0 - 1), k = CT ? 2 + 2 * min(xx, 7) : 2 * min(xx, 8);
+            const int r = min(T::YU0 + RPI * u + rsub, T::YD0 - 1), k = 2 * min(xx, 8);
             dw[n_] = T::HB + (r - T::NCORE) * T::RH + k;
             w[n_] = pair_at(r_out, rowtab[r], k);
         }
@@ -545,26 +502,25 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         for (int u = 0; u < NB + ND + NU; ++u) {
             const double lo = __hiloint2double((int)w[u].y, (int)w[u].x), hi = __hiloint2double((int)w[u].w, (int)w[u].z);
             lds[dw[u]] = si > 0 ? lo : hi;                                    // entry k
-            if (CT || u >= NB || xx < 9) lds[dw[u] + 1] = si > 0 ? hi : lo;   // entry k + 1 (a bundle row has no entry 22)
+            if (u >= NB || xx < 9) lds[dw[u] + 1] = si > 0 ? hi : lo;         // entry k + 1 (a bundle row has no entry 22)
         }
 #pragma unroll
         for (int u = 0; u < NXC; ++u) lds[d3[u]] = v3[u];
     };
-    auto load_rows = [&](auto ct_tag) {
-        constexpr bool CT = decltype(ct_tag)::value;
+    auto load_rows = [&]() {
         // 16 entries of one row per 16 lanes, 4 W rows per load instruction.  Rows are taken CLASS BY CLASS (bundle /
         // upstream halo / downstream halo) so that everything that depends on the class -- first entry, where the row
         // lives in the LDS image, whether a value of this sweep has to be fetched from `out` -- is a compile-time
         // property of the instruction (the class boundaries are not multiples of 4 W rows: the last instruction of a
         // class re-loads its last row in the lanes that would overshoot, which rewrites the same LDS value).
         constexpr int RPI = 4 * W;                                        // rows per load instruction
-        constexpr int NB = T::NCORE / RPI;                                // bundle rows: entries 3..18 (continued: 6..21), old values
+        constexpr int NB = T::NCORE / RPI;                                // bundle rows: entries 3..18, old values
         constexpr int NU = (T::YD0 - T::YU0 + RPI - 1) / RPI;             // upstream halo: 2..17, this sweep's inside the interior
-        constexpr int ND = (T::NR - T::YD0 + RPI - 1) / RPI;              // downstream halo: 4..19 (continued: 6..21), old values
-        // the remaining entries (none in a continued column): 0..2 (this sweep's) and 19..21 (old) of the bundle rows, 0..1 of
+        constexpr int ND = (T::NR - T::YD0 + RPI - 1) / RPI;              // downstream halo: 4..19, old values
+        // the remaining entries: 0..2 (this sweep's) and 19..21 (old) of the bundle rows, 0..1 of
         // the upstream and 20..21 of the downstream halo rows
         constexpr int XC = 3 * T::NCORE, XHU = 2 * (T::YD0 - T::NCORE), XHD = 2 * (T::NR - T::YD0);
-        constexpr int NXC = CT ? 0 : (XC + NT - 1) / NT, NXHU = CT ? 0 : (XHU + NT - 1) / NT, NXHD = CT ? 0 : (XHD + NT - 1) / NT;
+        constexpr int NXC = (XC + NT - 1) / NT, NXHU = (XHU + NT - 1) / NT, NXHD = (XHD + NT - 1) / NT;
         constexpr int NV = NB + NU + ND + 2 * NXC + NXHU + NXHD;
         double v[NV];
         int dst[NV];
@@ -575,14 +531,14 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         // ---- stage 1: what the previous sweep left
 #pragma unroll
         for (int u = 0; u < NB; ++u, ++n_) {
-            const int r = RPI * u + rsub, k = (CT ? 6 : 3) + xx;
+            const int r = RPI * u + rsub, k = 3 + xx;
             const int2 e = rowtab[r];
             dst[n_] = T::core_at(r) + k;
             v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
         }
 #pragma unroll
         for (int u = 0; u < ND; ++u, ++n_) {
-            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = (CT ? 6 : 4) + xx;
+            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = 4 + xx;
             const int2 e = rowtab[r];
             dst[n_] = T::HB + (r - T::NCORE) * T::RH + k - 4;
             v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
@@ -646,18 +602,8 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
 #pragma unroll
         for (int u = 0; u < NV; ++u) lds[dst[u]] = v[u]; // duplicates (clamped indices) rewrite the same value
     };
-    if constexpr (STREAM) {
-        if (widex) {
-            if (cont) load_wide(std::true_type{});
-            else load_wide(std::false_type{});
-        } else {
-            if (cont) load_rows(std::true_type{});
-            else load_rows(std::false_type{});
-        }
-    } else {
-        if (widex) load_wide(std::false_type{});
-        else load_rows(std::false_type{});
-    }
+    if (widex) load_wide();
+    else load_rows();
     if (!loaded) return false;
     __syncthreads();
     LSF_PHASE(2);
@@ -670,7 +616,6 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         {
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
-                if constexpr (STREAM && LSF_STREAM_PRIO == 1) sk_march_prio(t);
                 const bool active = (bool)((act_bits >> t) & 1u) && axis == 0;
                 double q[7];
 #pragma unroll
@@ -701,8 +646,6 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
                 const int t = t0 + u;
                 const bool active = (act_bits >> t) & 1u;
                 const bool weno_ok = (weno_bits >> t) & 1u;
-                if constexpr (STREAM && LSF_STREAM_PRIO == 1) // the tile that is further along wins the vector unit (see stream_tile)
-                    sk_march_prio(u);
                 double qx[7], qy[7], qz[7];
 #pragma unroll
                 for (int mm = 0; mm < 7; ++mm) qx[mm] = lds[ox[mm] + t];
@@ -1003,12 +946,31 @@ static __global__ __launch_bounds__(256) void k_build_order(uint2* __restrict__ 
 
 // Slot schedule: one launch per time slot, one block per tile of the slot (dependencies resolved by launch order).
 template <int TA, int WY, int WZ, int BY, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : 2) : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_skew(GsArgs a)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : LSF_WAVES16) : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_skew(GsArgs a)
 {
     const int bx = (int)blockIdx.x;
     const int seg = (bx >= a.seg_end[0]) + (bx >= a.seg_end[1]) + (bx >= a.seg_end[2]);
     const uint32_t packed = a.seg_tiles[seg][bx - (seg ? a.seg_end[seg - 1] : 0)];
     if (ld_flag(a.ctl + 0) != 0) return; // converged or failed in an earlier launch
+#ifdef LSF_EXPERIMENTS
+    // work-term probe (profiles/r05_ring_probe.txt): the two tiles of a CU start every phase together when every tile of a sweep
+    // is in one launch; the SECOND block to arrive on a CU sleeps probe_us microseconds so that one loads while the other marches
+    if (a.ticket && a.probe_us > 0) {
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            const int ord = atomicAdd(a.ticket + ((xcc & 7u) * 256u + ((hw >> 8) & 255u)), 1);
+            if (ord == 1) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (__builtin_amdgcn_s_memrealtime() - t0 < 100ull * (unsigned)a.probe_us) __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        __syncthreads();
+    }
+#endif
+#if defined(LSF_EXPERIMENTS) && defined(LSF_PROBE_LDS_PAD)
+    __shared__ int lds_pad[LSF_PROBE_LDS_PAD / 4]; // work-term probe: one tile per CU (its phases when it has the CU to itself)
+    if (a.nx < 0) lds_pad[threadIdx.x] = a.ny, a.ctl[5] = lds_pad[threadIdx.x ^ 1];
+#endif
     const SkPre pre = sk_prefetch<TA, WY, WZ, BY>(a);
     __shared__ SkShared<SkTile<TA, WY, WZ, BY>> sm;
     skew_tile<TA, WY, WZ, BY, STRICT, false>(sm, a, packed, a.seg_g[seg], a.seg_sign[seg][0], a.seg_sign[seg][1], a.seg_sign[seg][2], pre,
@@ -1026,7 +988,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
 // time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
 // plane_cnt[s][P]; the last tile of a hyperplane publishes planes_done[s] = P + 1.
 template <int TA, int WY, int WZ, int BY, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : 2) : (WY == 2 && WZ == 2 ? (STRICT ? LSF_STRICT22_WAVES : 5) : 1)))) void k_reinit_gs_persist(GsArgs a)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : LSF_WAVES16) : (WY == 2 && WZ == 2 ? (STRICT ? LSF_STRICT22_WAVES : 5) : 1)))) void k_reinit_gs_persist(GsArgs a)
 {
     using T = SkTile<TA, WY, WZ, BY>;
     __shared__ SkShared<T> sm;
@@ -1201,9 +1163,6 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
     }
 }
 
-// host side (lsf_stream.hip): launches the instance of the tile shape with as many blocks as the device keeps resident
-int launch_gs_stream(int wy, int wz, int by, bool strict, hipStream_t st, const GsArgs& fa, int cus, int* blocks_out);
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Exact ordering across z slabs: the dataflow schedule above, one launch PER SLAB (one device each; several on one device
 // for the rehearsal), all working on the same tile graph.  A slab owns the tile columns tk_lo <= tk < tk_hi; its task list
@@ -1253,7 +1212,7 @@ static __global__ __launch_bounds__(256) void k_build_order_slab(uint2* __restri
 #define LSF_SLAB_WAVES 4
 #endif
 template <int TA, int WY, int WZ, int BY, bool STRICT, bool LOOP>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : 2) : (WY == 2 && WZ == 2 ? (LOOP ? LSF_SLAB_WAVES : 5) : 1)))) void k_reinit_gs_slab(GsArgs args_)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : LSF_WAVES16) : (WY == 2 && WZ == 2 ? (LOOP ? LSF_SLAB_WAVES : 5) : 1)))) void k_reinit_gs_slab(GsArgs args_)
 {
     using T = SkTile<TA, WY, WZ, BY>;
     __shared__ SkShared<T> sm;

@@ -124,8 +124,8 @@ for case in range(n_cases):
             assert cnt_o == k + 1
             for arith_ in ("strict", "fast"):
                 first = None
-                for ex in ("dataflow", "skew", "slots", "planes", "stream", "slabs"):
-                    for kk in ("LSF_GS_SCHEDULE", "LSF_GS_STREAM", "LSF_DF_BATCH", "LSF_GS_NBUF"):
+                for ex in ("dataflow", "skew", "slots", "planes", "slabs"):
+                    for kk in ("LSF_GS_SCHEDULE", "LSF_DF_BATCH", "LSF_GS_NBUF"):
                         os.environ.pop(kk, None)
                     if rng.random() < 0.5:
                         os.environ["LSF_DF_BATCH"] = "8"
@@ -133,8 +133,6 @@ for case in range(n_cases):
                         os.environ["LSF_GS_NBUF"] = "3"
                     if ex in ("skew", "slots", "planes"):
                         os.environ["LSF_GS_SCHEDULE"] = ex
-                    if ex == "stream":
-                        os.environ["LSF_GS_STREAM"] = "1"
                     g = phi0.copy(order="F")
                     try:
                         if ex == "slabs":
@@ -154,7 +152,7 @@ for case in range(n_cases):
                     elif not (rr.count == first[0] and np.array_equal(g, first[1]) and
                               (np.allclose(rr.rms, first[2], rtol=1e-12, atol=0) if ex in ("skew", "slots", "planes") else rr.rms == first[2])):  # (slot launches sum the RMS in another order)
                         msgs.append(f"stop fast {ex} differs from the dataflow launch")
-                for kk in ("LSF_GS_SCHEDULE", "LSF_GS_STREAM", "LSF_DF_BATCH", "LSF_GS_NBUF"):
+                for kk in ("LSF_GS_SCHEDULE", "LSF_DF_BATCH", "LSF_GS_NBUF"):
                     os.environ.pop(kk, None)
             tag.append(f"S=oracle@{cnt_o}")
     bad += bool(msgs)

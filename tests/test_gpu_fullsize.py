@@ -167,35 +167,3 @@ def test_dataflow_launch_equals_slot_launches_over_many_sweeps(arith, monkeypatc
     # the dataflow launch sums the squared changes by tile columns of the x <-> y transposed field, the slot launches by
     # tile columns of the field as it is: same values, different (fixed) orders of the additions
     assert np.allclose(res["dataflow"][2], res["skew"][2], rtol=1e-12, atol=0)
-
-
-@pytest.mark.parametrize("n,cont", [(256, "2"), (256, "1"), (512, "2")])
-def test_full_size_field_of_the_continuation_launch_equals_the_reference_itself(n, cont, monkeypatch):
-    """The same SHA-256 comparison for the opt-in dataflow launch with column continuation (LSF_GS_STREAM=1,
-    k_reinit_gs_stream): at BASELINE sizes deep tile columns exist, so continued tiles take the 16-byte loader and the exact
-    previous-sweep test (stream_prev_sweep_past).  STRICT arithmetic: the reference's field bit for bit."""
-    import hashlib
-    import os
-
-    import torch
-
-    import levelsetfortran_amd as lsf
-    from conftest import GOLDEN
-    from levelsetfortran_amd import fields
-
-    path = os.path.join(GOLDEN, "synth_big.npz")
-    if not os.path.exists(path):
-        pytest.skip("synth_big.npz not generated")
-    g = np.load(path)
-    monkeypatch.setenv("LSF_GS_STREAM", "1")
-    monkeypatch.setenv("LSF_GS_CONT", cont)
-    sweeps = int(g[f"n{n}_sweeps"])
-    phi0, dx = fields.two_sphere_phi0((n, n, n))
-    h = fields.reinit_step(dx)
-    for shape in ("c1x4", "2x2"):
-        monkeypatch.setenv("LSF_GS_SKEW_W", shape)
-        t = torch.from_numpy(phi0.reshape(-1, order="F")).cuda()
-        rep = lsf.reinit(t, None, None, n - 1, n - 1, n - 1, sweeps - 1, dx, h, arith="strict")
-        assert rep.count == sweeps
-        assert hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() == str(g[f"n{n}_sha"]), shape
-        assert np.allclose(rep.rms, g[f"n{n}_rms"], rtol=1e-7, atol=0)

@@ -567,57 +567,6 @@ def test_peer_selftest_on_one_device(lsf):
         pkg.peer_selftest(0, 99)
 
 
-@pytest.mark.parametrize("cont,waves", [("2", None), ("1", None), ("0", None), ("2", "c1x4"), ("1", "c1x4"), ("2", "c1x2"), ("1", "4x2"), ("2", "1"),
-                                        ("2", "c1x1"), ("1", "2x4")])
-def test_reinit_dataflow_launch_with_column_continuation(lsf, oracle, synth, cube40, monkeypatch, cont, waves):
-    """LSF_GS_STREAM=1: the dataflow launch as resident blocks that loop over tiles and carry on down a tile column
-    (k_reinit_gs_stream: the LDS image moves along by one tile length, 16 instead of 22 entries per row are loaded).
-    LSF_GS_CONT: 0 never continue (every tile taken from the list), 1 continue when the cross upstream tiles of the next
-    tile are claimed, 2 only when they are done.  Every tile shape of both lane maps; bit-identical to the reference,
-    including ragged grids (partial tiles, tiles along every wall) and the stop sweep."""
-    from levelsetfortran_amd import fields
-
-    monkeypatch.setenv("LSF_GS_STREAM", "1")
-    monkeypatch.setenv("LSF_GS_CONT", cont)
-    if waves:
-        monkeypatch.setenv("LSF_GS_SKEW_W", waves)
-    nx, ny, nz = _n(synth)
-    phi = F(synth["phi0"])
-    rep = lsf.reinit(phi, None, None, nx, ny, nz, 15, float(synth["dx"]), float(synth["h"]), arith="strict")
-    assert rep.count == 16 and np.array_equal(phi, synth["phi_16"])
-    assert np.allclose(rep.rms, synth["rms"], rtol=1e-11, atol=0)
-    for npts in ((6, 10, 8), (34, 13, 11), (10, 42, 14), (65, 8, 30), (23, 23, 5), (70, 21, 45), (96, 60, 75)):
-        phi0, dx = fields.two_sphere_phi0(npts)
-        nx, ny, nz = (v - 1 for v in npts)
-        h = fields.reinit_step(dx)
-        ref = phi0.copy(order="F")
-        _, n_ref, tr_ref = oracle.reinit(ref, nx, ny, nz, 10, dx, h, tol=0.0)
-        got = phi0.copy(order="F")
-        rep = lsf.reinit(got, None, None, nx, ny, nz, 10, dx, h, tol=0.0, arith="strict")
-        assert rep.count == n_ref == 11, npts
-        assert np.array_equal(got, ref), npts
-        assert np.allclose(rep.rms, tr_ref[:11], rtol=1e-9, atol=0), npts
-    nx, ny, nz = _n(cube40)
-    phi = F(cube40["phi0"])
-    rep = lsf.reinit(phi, None, None, nx, ny, nz, 63, float(cube40["dx"]), float(cube40["h"]), arith="strict")
-    assert rep.count == 64 and sha(phi) == str(cube40["re64_sha"])
-    # the stop sweep and its field, against the one-block-per-tile launch
-    phi = F(cube40["phi0"])
-    rep = lsf.reinit(phi, None, None, nx, ny, nz, 200, float(cube40["dx"]), float(cube40["h"]), tol=3.0e-3, arith="strict")
-    monkeypatch.delenv("LSF_GS_STREAM")
-    phi2 = F(cube40["phi0"])
-    rep2 = lsf.reinit(phi2, None, None, nx, ny, nz, 200, float(cube40["dx"]), float(cube40["h"]), tol=3.0e-3, arith="strict")
-    assert rep.count == rep2.count and 1 < rep.count < 200 and rep.converged and np.array_equal(phi, phi2)
-    # FAST arithmetic: the same bits from both launches (same tile code, same order of the RMS sums)
-    monkeypatch.setenv("LSF_GS_STREAM", "1")
-    a = F(cube40["phi0"])
-    ra = lsf.reinit(a, None, None, nx, ny, nz, 31, float(cube40["dx"]), float(cube40["h"]), tol=0.0, arith="fast")
-    monkeypatch.delenv("LSF_GS_STREAM")
-    b = F(cube40["phi0"])
-    rb = lsf.reinit(b, None, None, nx, ny, nz, 31, float(cube40["dx"]), float(cube40["h"]), tol=0.0, arith="fast")
-    assert np.array_equal(a, b) and ra.rms == rb.rms
-
-
 @pytest.mark.parametrize("march,nbuf", [("x", "3"), ("x", "4"), ("y", "3"), ("y", "4")])
 def test_dataflow_march_axis_and_buffer_count(lsf, oracle, synth, cube40, monkeypatch, march, nbuf):
     """The dataflow launch marches its tiles along the reference's y axis by default (the kernel runs on the x <-> y
