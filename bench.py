@@ -56,6 +56,19 @@ BYTES_PER_CELL_UPDATE = 24.0  # read phi, read phiS, write phi (SURVEY.md sectio
 # CPU baseline worker (separate process: the Fortran runtime of the reference prints one line per
 # sweep on stdout, which must not reach the JSON line)
 # ------------------------------------------------------------------------------------------------
+def kernel_sources_fingerprint():
+    """sha256 (16 hex digits) of the library's kernel sources as they lie in the tree: profiles/ships_summarize.py stamps the counters it
+    condenses with it, and the counters are attached to a bench line only while the sources are the ones they were measured on"""
+    import glob
+    import hashlib
+
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "levelsetfortran_amd", "csrc", "*.h*"))):
+        hsh.update(os.path.basename(f).encode())
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def _cpu_worker(out_path: str, n: int, slab: int, sweeps: int) -> None:
     import threading
 
@@ -150,6 +163,7 @@ def main() -> None:
                     help="f32 = single-precision Jacobi path (BASELINE configuration 5); implies --mode jacobi")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary-ordering measurement")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the 256^3 / 1024^3 entries of a 512^3 run")
     ap.add_argument("--no-decomposed", action="store_true",
                     help="N > 1, mode gs: skip the block-decomposed Jacobi sweep (RCCL halo exchange) that is otherwise "
                          "timed after the headline measurement and attached as \"decomposed\"")
@@ -309,19 +323,25 @@ def main() -> None:
         watchdog.daemon = True
     state["run_decomposed"] = watchdog is not None
 
-    def roofline(prof_, cells_per_sweep):
+    src_now = kernel_sources_fingerprint()
+
+    def roofline(prof_, cells_per_sweep, size=None):
         if not prof_ or not prof_.get("sweeps"):
             return None
         kernel = prof_["kernel"]  # the exact ordering picks box or skewed tiles by grid size
         per_sweep_s = prof_["sweep_ms"] * 1e-3 / prof_["sweeps"]
         ach = cells_per_sweep * bytes_per_cell / per_sweep_s / 1e9
         lps = prof_["launches"] / prof_["sweeps"]
-        # measured HBM bytes and issue counters of THIS kernel instance at THIS size (profiles/ships.sh -> profiles/traffic.json)
-        traffic, issue = None, None
+        # measured HBM bytes and issue counters of THIS kernel instance at THIS size (profiles/ships.sh -> profiles/traffic.json),
+        # attached only while the kernel sources are the ones the counters were collected on (the entry's stamp)
+        traffic, issue, stale = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                ent = json.load(open(tpath)).get(kernel, {}).get(str(N))
+                ent = json.load(open(tpath)).get(kernel, {}).get(str(size or N))
+                if isinstance(ent, dict) and ent.get("kernel_sources") != src_now:
+                    stale = {"counters_collected_on_sources": ent.get("kernel_sources"), "sources_now": src_now, "file": ent.get("source")}
+                    ent = None
                 if isinstance(ent, dict):
                     traffic = ent.get("hbm_bytes_per_sweep")
                     if "valu_lane_insts_per_cell" in ent:
@@ -341,6 +361,7 @@ def main() -> None:
             "avg_launch_us": per_sweep_s / lps * 1e6,
             "algorithmic_bytes_per_launch": cells_per_sweep * bytes_per_cell / lps,
             "traffic_per_sweep": traffic, "algorithmic_bytes_per_sweep": cells_per_sweep * bytes_per_cell, "issue": issue,
+            **({"counters_stale": stale} if stale else {}),
             "note": f"achieved = {bytes_per_cell:.0f} B x (N-2)^3 cells / HIP-event time of the sweep kernel launch(es) of one sweep; "
                     "traffic = measured HBM bytes per launch (per sweep / launches per sweep) from the rocprofv3 PMC "
                     "passes summarised in profiles/, null if not collected for this size",
@@ -459,6 +480,51 @@ def main() -> None:
                       "reference's bit for bit after any number of sweeps; `value` above is the FAST arithmetic (same "
                       "mathematics, ~1e-16 per sweep away: see fast_valid_sweeps for how long that stays inside 1e-10 RMS)")
         out["strict_arithmetic"] = st
+        if order == "gs":
+            # the number that carries the contract's parity on every BASELINE configuration (the drop-in's arithmetic), where it cannot
+            # be overlooked
+            out["value_strict"], out["ms_per_step_strict"] = st["gs"]["value"], st["gs"]["ms_per_step"]
+            out["roofline_strict_frac"] = (st["gs"]["roofline"] or {}).get("frac")
+
+    if world == 1 and not args.no_secondary and not f32 and order == "gs" and N == 512 and not args.no_sizes:
+        # north_star's other two sizes, in the driver's own line: the exact ordering, 16 sweeps after 16, FAST and STRICT
+        def at_size(G):
+            p0, dxg = fields.two_sphere_phi0_device((G, G, G), dev)
+            hg = fields.reinit_step(dxg)
+            pS, p = p0.clone(), p0.clone()
+            ent = {}
+            for ar in ("fast", "strict"):
+                p.copy_(p0)
+                lib.lsf_profile(0)
+                lsf.reinit(p, None, None, G - 1, G - 1, G - 1, 15, dxg, hg, tol=0.0, order="gs", arith=ar, phiS=pS)
+                barrier()
+                t0 = time.perf_counter()
+                lib.lsf_profile(1)
+                rep = lsf.reinit(p, None, None, G - 1, G - 1, G - 1, 15, dxg, hg, tol=0.0, order="gs", arith=ar, phiS=pS)
+                barrier()
+                dt = time.perf_counter() - t0
+                assert rep.count == 16
+                sw, bc, fin = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+                nl, ns = ctypes.c_longlong(), ctypes.c_int()
+                lib.lsf_profile_get(ctypes.byref(sw), ctypes.byref(bc), ctypes.byref(fin), ctypes.byref(nl), ctypes.byref(ns))
+                lib.lsf_profile(0)
+                pr = {"sweep_ms": sw.value, "bc_ms": bc.value, "finish_ms": fin.value, "launches": nl.value, "sweeps": ns.value,
+                      "kernel": (lib.lsf_profile_kernel() or b"").decode()}
+                cells = float(G - 2) ** 3 * 16
+                ent[ar] = {"value": cells / dt, "unit": "cell-updates/s", "ms_per_step": dt / 16 * 1e3, "steps": 16, "warmup": 16,
+                           "roofline": roofline(pr, cells / 16, size=G)}
+            del p0, pS, p
+            torch.cuda.empty_cache()
+            return ent
+
+        out["sizes"] = {"note": "exact Gauss-Seidel ordering at north_star's other sizes, same run, same box: 16 sweeps after 16, FAST "
+                                "and STRICT arithmetic, wall clock between barrier + synchronize pairs; `value` stays the 512^3 figure"}
+        for G in (256, 1024):
+            try:
+                out["sizes"][f"{G}^3"] = at_size(G)
+            except Exception as e:  # noqa: BLE001
+                out["sizes"][f"{G}^3"] = {"error": repr(e)[:200]}
+        lib.lsf_release_workspace()
 
     if world == 1 and not args.no_secondary:
         # min/max-flow sweep (set3d.f90:394-462) on the same grid: 16 B per grid point per iteration
@@ -473,24 +539,35 @@ def main() -> None:
         sdf = torch.from_numpy(np.asfortranarray(dmin).reshape(-1, order="F")).to(dev)
         del dmin, r
         mm = {}
-        KM = 10
+        KM, KM0 = 50, 10
         for order_ in ("gs", "jacobi"):
-            f = sdf.clone()
-            nb = torch.zeros(f.numel(), dtype=torch.int32, device=dev)
-            sb = torch.zeros_like(nb)
-            lsf.narrowBand(nx, ny, nz, dxm, f, nb, sb)
-            lsf.minmaxFlow(f, nb, sb, nx, ny, nz, 2, dxm, 0.1 * h, tol=0.0, order=order_)
-            barrier()
-            t0 = time.perf_counter()
-            lsf.minmaxFlow(f, nb, sb, nx, ny, nz, KM, dxm, 0.1 * h, tol=0.0, order=order_)
-            barrier()
-            dtm = time.perf_counter() - t0
-            mm[order_] = {"ms_per_iteration": dtm / KM * 1e3, "points_per_s": float(N) ** 3 * KM / dtm,
+            times = {}
+            for km in (KM0, KM):
+                f = sdf.clone()
+                nb = torch.zeros(f.numel(), dtype=torch.int32, device=dev)
+                sb = torch.zeros_like(nb)
+                lsf.narrowBand(nx, ny, nz, dxm, f, nb, sb)
+                band = float((nb == 1).sum().item()) / float(nb.numel())
+                lsf.minmaxFlow(f, nb, sb, nx, ny, nz, 2, dxm, 0.1 * h, tol=0.0, order=order_)
+                barrier()
+                t0 = time.perf_counter()
+                lsf.minmaxFlow(f, nb, sb, nx, ny, nz, km, dxm, 0.1 * h, tol=0.0, order=order_)
+                barrier()
+                times[km] = time.perf_counter() - t0
+                del f, nb, sb
+            dtm = times[KM]
+            slope = (times[KM] - times[KM0]) / (KM - KM0)
+            mm[order_] = {"ms_per_iteration": dtm / KM * 1e3, "iterations_per_call": KM, "points_per_s": float(N) ** 3 * KM / dtm,
                           "algorithmic_GBps": 16.0 * float(N) ** 3 * KM / dtm / 1e9,
-                          "frac_of_hbm_peak": 16.0 * float(N) ** 3 * KM / dtm / 1e9 / HBM_PEAK_GBS}
-            del f, nb, sb
-        mm["note"] = ("min/max-flow iteration at the same size, narrow band = |phi| < 4.1 dx of an exact two-sphere distance; "
-                      "gs = the reference's (+,+,+) raster order reproduced exactly, jacobi = double-buffered")
+                          "frac_of_hbm_peak": 16.0 * float(N) ** 3 * KM / dtm / 1e9 / HBM_PEAK_GBS,
+                          "ms_per_additional_iteration": slope * 1e3, "ms_per_call_overhead": (times[KM0] - KM0 * slope) * 1e3,
+                          "band_fraction": band}
+        mm["note"] = ("min/max-flow iteration at the same size (set3d.f90:394-462), narrow band = |phi| < 4.1 dx of an exact two-sphere "
+                      "distance; gs = the reference's (+,+,+) raster order reproduced exactly, jacobi = double-buffered.  Default executor: "
+                      "on the band only (list of band cells built once per call, compact arrays, the field written once at the end): the "
+                      "cost follows band_fraction, so algorithmic_GBps -- 16 B per GRID point per iteration, the dense accounting of "
+                      "SURVEY.md 8d -- can exceed the HBM peak; ms_per_iteration = one call of iterations_per_call iterations, list build "
+                      "and the final narrowBand pass included (ms_per_call_overhead), / iterations_per_call")
         out["minmax"] = mm
 
     failed = False
@@ -578,7 +655,18 @@ def main() -> None:
                                   "note": "N independent replicas of the exact Gauss-Seidel ordering: linear by construction, no communication"}
             out["metric"] = (f"cell-updates/s (WENO5 reinit, {N}^3 fp64 per GPU); N > 1: block-decomposed Jacobi ordering, 3-cell halos "
                              "over RCCL, weak scaling (N = 1: the reference's exact ordering on one GPU)")
+            # what was computed from the replicas' timing goes with the replicas; the VALU roofline of the headline is recomputed
+            # from the headline's own value with the Jacobi ordering's operation count
+            for k_ in ("step_breakdown_ms", "roofline_fp64_valu", "fast_valid_sweeps"):
+                if k_ in out:
+                    out["replicas_gs"][k_] = out.pop(k_)
             out["value"], out["ms_per_step"], out["roofline"] = weak["value"], weak["ms_per_step"], weak["roofline"]
+            per_gpu = weak["value"] / world
+            out["roofline_fp64_valu"] = {"bound": "fp64-valu", "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "achieved": 505.0 * per_gpu / 1e12, "frac": 505.0 * per_gpu / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                         "useful_ops_per_cell": 259.0, "achieved_useful_Tops": 259.0 * per_gpu / 1e12,
+                                         "note": "per GPU, from the headline's own value: 505 fp64 flop per cell as written in subs.f90; the "
+                                                 "Jacobi ordering needs 259 operations per cell in the cheapest form found (DESIGN.md 4.2)"}
             out["headline_path"] = "decomposed-jacobi-weak"
             out["config"]["workload"] = (f"WENO5 HJ reinit sweep (weno+Godunov+Euler, BC, RMS), global grid {weak['global_grid']} fp64 split "
                                          f"{weak['dims']}, local block {weak['local_block']} points, synthetic two-sphere phi0 (SURVEY.md 8d), HBM-resident")

@@ -162,7 +162,7 @@ struct BatchPlan {
     int nslots = 0;
 };
 
-enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_PLANECNT, S_DBG, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_PONG3, S_PONG4, S_SNAP, S_MB_CNT, S_MB_L, S_MB_NB6, S_MB_AOLD, S_MB_A0, S_MB_BAND, S_NSLOTS };
+enum Slot { S_PONG, S_PHIS, S_PART, S_CTL, S_TRACE, S_HPHI, S_HNB, S_HSB, S_CEN, S_VTX, S_BFLAG, S_CHG, S_BACKUP, S_PART2, S_PLANECNT, S_DBG, S_COLSUM, S_ORDER, S_GRAD, S_NODES, S_STAMP, S_PONG2, S_PONG3, S_PONG4, S_SNAP, S_MB_CNT, S_MB_L, S_MB_NB6, S_MB_AOLD, S_MB_A0, S_MB_BAND, S_MB_KEY, S_MB_TMP, S_NSLOTS };
 
 // partial sums of the box calls issued on one stream; `deferred`: between lsf_sumsq_begin and lsf_sumsq_end the calls
 // append their partials instead of reducing them one by one
@@ -1611,6 +1611,7 @@ int lsf_multi_upload_block(lsf_multi* M, int r, const void* d_block)
     HIPCHK(hipSetDevice(M->devs[r]));
     if (M->f32) HIPCHK(hipMemcpy(M->r32[r].buf[0], d_block, M->r32[r].g.npoints() * sizeof(float), hipMemcpyDeviceToDevice));
     else HIPCHK(hipMemcpy(M->r64[r].buf[0], d_block, M->r64[r].g.npoints() * sizeof(double), hipMemcpyDeviceToDevice));
+    HIPCHK(hipDeviceSynchronize()); // (a device-to-device hipMemcpy returns early; the run's streams are non-blocking: see lsfm::run)
     M->result_parity = 0;
     return LSF_OK;
 }

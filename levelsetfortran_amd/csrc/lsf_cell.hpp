@@ -59,41 +59,72 @@ __device__ __forceinline__ double div_by(double n, double d, double r)
 // either way (tests/test_gpu_parity.py, ..._at_the_ends_of_the_exponent_range).
 __device__ __forceinline__ double div_dx(double x, double dx, double rdx) { return div_by(x, dx, rdx); }
 
-__device__ __forceinline__ void weno_axis_strict(const double q[7], double dx, bool yquirk, double& dm,
-                                                 double& dp)
+// The second and first differences of an axis as subs.f90:509-513 / :525-530 write them.  Along an axis they are ONE formula at
+// several offsets: with X(j) = (phi(j+1) - 2 phi(j) + phi(j-1)) / dx and its mirror image Y(j) = (phi(j-1) - 2 phi(j) + phi(j+1)) / dx
+// (the reference starts the sum at the far point on either side), P(j) = (phi(j+1) - phi(j)) / dx:
+//     ap = X(i+2), bp = X(i+1), cp = cm = X(i), am = Y(i-2), bm = Y(i-1),   p0 .. p5 = P(i-3) .. P(i+2)
+// so a kernel that marches along the axis over frozen data (the Jacobi ordering) computes X(i+2), Y(i-1), P(i+2) and P(i+2)^2 per
+// cell and carries the rest -- the same doubles by construction (WenoDiffs; k_reinit_jacobi<true>).
+struct WenoDiffs {
+    double ap, am, bp, bm, cp;       // second differences
+    double p[6];                     // first differences p0 .. p5
+    double s[6];                     // their squares (the epsilons of subs.f90:533-534 take the largest of five each)
+    double t1p;                      // 13 (bp - cp)(bp - cp), which is 13 (ap - bp)(ap - bp) of the cell before
+};
+__device__ __forceinline__ double weno_X(double far, double mid, double near, double dx, double rdx)
 {
 #pragma clang fp contract(off)
-    const double rdx = recip_refined(dx); // loop invariant: hoisted out of every march
+    return div_dx(far - 2. * mid + near, dx, rdx); // (phi(j+1) - 2 phi(j) + phi(j-1)) / dx, or its mirror image
+}
+__device__ __forceinline__ double weno_P(double hi, double lo, double dx, double rdx)
+{
+#pragma clang fp contract(off)
+    return div_dx(hi - lo, dx, rdx);
+}
+__device__ __forceinline__ void weno_diffs_strict(const double q[7], double dx, double rdx, bool yquirk, WenoDiffs& d)
+{
+#pragma clang fp contract(off)
     const double m3 = q[0], m2 = q[1], m1 = q[2], c0 = q[3], r1 = q[4], r2 = q[5], r3 = q[6];
-    const double ap = div_dx(r3 - 2. * r2 + r1, dx, rdx);
-    const double am = div_dx(m3 - 2. * m2 + m1, dx, rdx);
-    const double bp = div_dx(r2 - 2. * r1 + c0, dx, rdx);
-    const double bm = div_dx(m2 - 2. * m1 + c0, dx, rdx);
-    const double cp = div_dx(r1 - 2. * c0 + m1, dx, rdx);
+    d.ap = weno_X(r3, r2, r1, dx, rdx);
+    d.am = weno_X(m3, m2, m1, dx, rdx);
+    d.bp = weno_X(r2, r1, c0, dx, rdx);
+    d.bm = weno_X(m2, m1, c0, dx, rdx);
+    d.cp = weno_X(r1, c0, m1, dx, rdx);
+    d.p[0] = weno_P(m2, m3, dx, rdx);
+    d.p[1] = weno_P(m1, m2, dx, rdx);
+    d.p[2] = weno_P(c0, m1, dx, rdx);
+    d.p[3] = weno_P(r1, c0, dx, rdx);
+    d.p[4] = weno_P(r2, r1, dx, rdx);
+    d.p[5] = yquirk ? weno_P(r3, r3, dx, rdx) : weno_P(r3, r2, dx, rdx);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d.s[k] = d.p[k] * d.p[k];
+    d.t1p = 13. * (d.bp - d.cp) * (d.bp - d.cp);
+}
+
+// Everything of an axis behind its differences (subs.f90:518-552).  t0p_out: 13 (ap - bp)(ap - bp), the t1p of the next cell along
+// the axis.
+__device__ __forceinline__ void weno_from_diffs_strict(const WenoDiffs& d, double& dm, double& dp, double& t0p_out)
+{
+#pragma clang fp contract(off)
+    const double ap = d.ap, am = d.am, bp = d.bp, bm = d.bm, cp = d.cp;
     const double cm = cp, dpp = bm, dmm = bp;
+    const double p1 = d.p[1], p2 = d.p[2], p3 = d.p[3], p4 = d.p[4];
 
     // 13.*(x)*(x) is ((13 x) x): the same double for x and -x, so the first term of IS2m (x = cm - dmm = cp - bp) is that
     // of IS1p (x = bp - cp), and the first term of IS2p (cp - dpp = cp - bm) that of IS1m (bm - cm = bm - cp): two of the
     // twelve quadratic terms of subs.f90:518-523 are evaluated once (the rest differ in value, not only in sign)
-    const double T1p = 13. * (bp - cp) * (bp - cp), T1m = 13. * (bm - cm) * (bm - cm);
-    const double IS0p = 13. * (ap - bp) * (ap - bp) + 3. * (ap - 3. * bp) * (ap - 3. * bp);
+    const double T1p = d.t1p, T1m = 13. * (bm - cm) * (bm - cm);
+    const double T0p = 13. * (ap - bp) * (ap - bp);
+    t0p_out = T0p;
+    const double IS0p = T0p + 3. * (ap - 3. * bp) * (ap - 3. * bp);
     const double IS0m = 13. * (am - bm) * (am - bm) + 3. * (am - 3. * bm) * (am - 3. * bm);
     const double IS1p = T1p + 3. * (bp + cp) * (bp + cp);
     const double IS1m = T1m + 3. * (bm + cm) * (bm + cm);
     const double IS2p = T1m + 3. * (3. * cp - dpp) * (3. * cp - dpp);
     const double IS2m = T1p + 3. * (3. * cm - dmm) * (3. * cm - dmm);
 
-    const double p0 = div_dx(m2 - m3, dx, rdx);
-    const double p1 = div_dx(m1 - m2, dx, rdx);
-    const double p2 = div_dx(c0 - m1, dx, rdx);
-    const double p3 = div_dx(r1 - c0, dx, rdx);
-    const double p4 = div_dx(r2 - r1, dx, rdx);
-    const double p5 = yquirk ? div_dx(r3 - r3, dx, rdx) : div_dx(r3 - r2, dx, rdx);
-
-    const double epsp =
-        (1.E-6) * smax(p1 * p1, smax(p2 * p2, smax(p3 * p3, smax(p4 * p4, p5 * p5)))) + 1.E-99;
-    const double epsm =
-        (1.E-6) * smax(p0 * p0, smax(p1 * p1, smax(p2 * p2, smax(p3 * p3, p4 * p4)))) + 1.E-99;
+    const double epsp = (1.E-6) * smax(d.s[1], smax(d.s[2], smax(d.s[3], smax(d.s[4], d.s[5])))) + 1.E-99;
+    const double epsm = (1.E-6) * smax(d.s[0], smax(d.s[1], smax(d.s[2], smax(d.s[3], d.s[4])))) + 1.E-99;
 
     const double x0p = (epsp + IS0p) * (epsp + IS0p), x0m = (epsm + IS0m) * (epsm + IS0m);
     const double x1p = (epsp + IS1p) * (epsp + IS1p), x1m = (epsm + IS1m) * (epsm + IS1m);
@@ -125,6 +156,17 @@ __device__ __forceinline__ void weno_axis_strict(const double q[7], double dx, b
 
     dm = 1. / 12. * (-p1 + 7. * p2 + 7. * p3 - p4) - PWm;
     dp = 1. / 12. * (-p1 + 7. * p2 + 7. * p3 - p4) + PWp;
+}
+
+__device__ __forceinline__ void weno_axis_strict(const double q[7], double dx, bool yquirk, double& dm,
+                                                 double& dp)
+{
+#pragma clang fp contract(off)
+    const double rdx = recip_refined(dx); // loop invariant: hoisted out of every march
+    WenoDiffs d;
+    weno_diffs_strict(q, dx, rdx, yquirk, d);
+    double t0p_;
+    weno_from_diffs_strict(d, dm, dp, t0p_);
 }
 
 // STRICT: Godunov switch + magnitude, subs.f90:667-702.

@@ -166,15 +166,14 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
 }
 
 // The min/max flow on the narrow band only (lsf_minmax_band.hpp): the list of cells that can ever be in the band is built once
-// per call, phi stays in place, every pass of an iteration runs over the list.  Both orderings (the Jacobi ordering is the start
-// pass and the RMS pass alone).  *dense = true: not run (band above a quarter of the grid, no band cell at all, or a field beyond
-// 32-bit point indices) -- the caller takes the dense executor; *inexact as in minmax_core_impl (the field is restored).
+// per call and the flow runs on compact arrays; the field is written once, at the end.  Both orderings (the Jacobi ordering is
+// the start pass and the RMS pass alone).  *dense = true: not run (band above a quarter of the grid, no band cell at all, a
+// field beyond 32-bit point indices, or an iteration that 32 fix passes did not certify -- never observed) and phi, the masks
+// untouched: the caller takes the dense executors.
 int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int nz, int iter, double dx, double h1, double tol,
-                     int mode, int* iters_done, double* rms_trace, int trace_cap, hipStream_t st, int exact_mode, bool* inexact,
-                     bool* dense)
+                     int mode, int* iters_done, double* rms_trace, int trace_cap, hipStream_t st, bool* dense)
 {
     *dense = true;
-    if (inexact) *inexact = false;
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
     if (n > (size_t)0x7fffffff) return LSF_OK;
     const bool gs = (mode & LSF_ORDER_MASK) == LSF_ORDER_GS;
@@ -187,119 +186,136 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     int* staging = (int*)c.slot[S_PONG].p;
     int* counts = (int*)c.slot[S_MB_CNT].p;
     int* offsets = counts + nblk;
-    const double t_build0 = getenv("LSF_TRACE") ? now_s() : 0.0;
+    const bool trace = getenv("LSF_TRACE") != nullptr;
+    const double t_build0 = trace ? now_s() : 0.0;
     hipLaunchKernelGGL(k_mb_collect, dim3((unsigned)nblk), dim3(256), 0, st, (const double*)d_phi, (const int32_t*)d_nb, nx, ny, nz, dx,
                        staging, counts);
     hipLaunchKernelGGL(k_mb_offsets, dim3(1), dim3(1024), 0, st, (const int*)counts, nblk, offsets);
     int nL = 0;
     HIPCHK(hipMemcpyAsync(&nL, offsets + nblk, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (nL <= 0 || (size_t)nL * 4 > n) return LSF_OK; // dense executor
-    *dense = false;
+    // a band above a quarter of the grid: the dense executor streams it as fast (LSF_MINMAX_BAND_MAX, per cent: test hook)
+    double band_max = 25.0;
+    if (const char* e = getenv("LSF_MINMAX_BAND_MAX")) band_max = std::min(100.0, std::max(0.0, atof(e)));
+    if (nL <= 0 || (double)nL * 100.0 > band_max * (double)n) return LSF_OK;
     const int nchunks = (nL + MB_CH - 1) / MB_CH;
     if ((rc = ws(c.slot[S_MB_L], (size_t)nL * sizeof(int)))) return rc;
     if ((rc = ws(c.slot[S_MB_NB6], (size_t)nL * 6 * sizeof(int)))) return rc;
     if ((rc = ws(c.slot[S_MB_AOLD], (size_t)nL * 2 * sizeof(double)))) return rc;
-    if ((rc = ws(c.slot[S_MB_A0], (size_t)nL * sizeof(double)))) return rc;
+    if ((rc = ws(c.slot[S_MB_A0], (size_t)nL * 4 * sizeof(double)))) return rc; // curvature | three downstream values
     if ((rc = ws(c.slot[S_MB_BAND], (size_t)nL))) return rc;
     if ((rc = ws(c.slot[S_BFLAG], (size_t)nchunks * sizeof(int)))) return rc;
     if ((rc = ws(c.slot[S_STAMP], (size_t)nchunks * sizeof(int)))) return rc;
     if ((rc = ws(c.slot[S_PART], (size_t)nchunks * sizeof(double)))) return rc;
     if ((rc = ws(c.slot[S_PART2], 256 * sizeof(double)))) return rc;
-    constexpr size_t CHG_BYTES = (MM_MAX_FIX + 1) * sizeof(int);
-    if ((rc = ws(c.slot[S_CHG], CHG_BYTES))) return rc;
+    if ((rc = ws(c.slot[S_CHG], 1024))) return rc;
     if ((rc = ws(c.slot[S_TRACE], (size_t)std::max(iter, 1) * sizeof(double)))) return rc;
     int* L = (int*)c.slot[S_MB_L].p;
-    int* nb6 = (int*)c.slot[S_MB_NB6].p;
-    double* aold[2] = {(double*)c.slot[S_MB_AOLD].p, (double*)c.slot[S_MB_AOLD].p + nL};
-    double* a0 = (double*)c.slot[S_MB_A0].p;
-    unsigned char* isband = (unsigned char*)c.slot[S_MB_BAND].p;
-    int* chunkflag = (int*)c.slot[S_BFLAG].p;
-    int* stamp = (int*)c.slot[S_STAMP].p;
+    double* V[2] = {(double*)c.slot[S_MB_AOLD].p, (double*)c.slot[S_MB_AOLD].p + nL};
     double* part = (double*)c.slot[S_PART].p;
     double* part2 = (double*)c.slot[S_PART2].p;
     int* chg = (int*)c.slot[S_CHG].p;
     int* ctl = (int*)c.slot[S_CTL].p;
     double* d_trace = (double*)c.slot[S_TRACE].p;
-    const int sx = nx + 1;
-    const long sxy = (long)(nx + 1) * (ny + 1);
-    const dim3 b256(256), gl((unsigned)nchunks);
-    hipLaunchKernelGGL(k_mb_gather, dim3((unsigned)nblk), b256, 0, st, (const int*)staging, (const int*)counts, (const int*)offsets,
-                       (const double*)d_phi, L, aold[0], a0);
-    hipLaunchKernelGGL(k_mb_links, gl, b256, 0, st, (const int*)L, nL, sx, (int)sxy, nb6);
+    MbArgs a;
+    a.F = d_phi, a.L = L, a.nb = (const int*)c.slot[S_MB_NB6].p, a.isband = (unsigned char*)c.slot[S_MB_BAND].p;
+    a.curv = (double*)c.slot[S_MB_A0].p, a.down = a.curv + nL;
+    a.nL = nL, a.sx = nx + 1, a.sxy = (long)(nx + 1) * (ny + 1), a.dx = dx, a.h1 = h1;
+    a.chunkflag = (int*)c.slot[S_BFLAG].p, a.stamp = (int*)c.slot[S_STAMP].p, a.nchunks = nchunks, a.partials = part, a.ctl = ctl;
+    const dim3 b256(256), gl((unsigned)nchunks), ge((unsigned)cdiv(nL, 256));
+    {
+        // the list in memory order and its brick keys -> sorted by key (both pairs of arrays live in the staging buffer's tail and in
+        // the slots of the list: the scan's segments are no longer needed once they have been gathered)
+        const int nbx = cdiv(nx + 1, 8), nby = cdiv(ny + 1, 8);
+        if ((double)nbx * nby * cdiv(nz + 1, 4) * 256.0 > 4.0e9) return LSF_OK; // keys beyond 32 bits: dense executor
+        if ((rc = ws(c.slot[S_MB_KEY], (size_t)nL * 3 * sizeof(int)))) return rc;
+        unsigned* key_in = (unsigned*)c.slot[S_MB_KEY].p;
+        unsigned* key = key_in + nL;
+        int* L_in = (int*)(key + nL);
+        hipLaunchKernelGGL(k_mb_gather, dim3((unsigned)((nblk + 3) / 4)), b256, 0, st, (const int*)staging, (const int*)counts,
+                           (const int*)offsets, nblk, nx + 1, ny + 1, nbx, nby, L_in, key_in);
+        size_t tmp_bytes = 0;
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in, key, L_in, L, (size_t)nL, 0, 32, st));
+        void* tmp = staging; // (free again: its segments have been gathered -- in stream order)
+        if (tmp_bytes > n * sizeof(int)) { // tiny grids
+            if ((rc = ws(c.slot[S_MB_TMP], tmp_bytes))) return rc;
+            tmp = c.slot[S_MB_TMP].p;
+        }
+        HIPCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, key_in, key, L_in, L, (size_t)nL, 0, 32, st));
+        hipLaunchKernelGGL(k_mb_links, ge, b256, 0, st, (const int*)L, (const unsigned*)key, nL, nx + 1, ny + 1, nbx, nby, (const double*)d_phi,
+                           (int*)c.slot[S_MB_NB6].p, V[0]);
+    }
     HIPCHK(hipMemsetAsync(ctl, 0, 64, st));
-    HIPCHK(hipMemsetAsync(stamp, 0, (size_t)nchunks * sizeof(int), st));
-    if (getenv("LSF_TRACE")) {
+    HIPCHK(hipMemsetAsync(a.stamp, 0, (size_t)nchunks * sizeof(int), st));
+    if (trace) {
         HIPCHK(hipStreamSynchronize(st));
         fprintf(stderr, "[lsf] min/max on the band: %d list cells (%.2f %% of the grid), %d chunks; list built in %.3f ms\n", nL,
                 100.0 * nL / (double)n, nchunks, (now_s() - t_build0) * 1e3);
     }
     const double den = rms_denominator(nx, ny, nz);
-    int host_ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int cap = !gs ? 0 : (exact_mode == MM_FP_FULL ? MM_MAX_FIX : MM_FIX_START);
-    if (const char* e = getenv("LSF_MINMAX_FIX_START")) // test hook: start with too few passes to exercise the rerun
-        if (gs && exact_mode == MM_FP_ADAPTIVE) cap = std::min(MM_MAX_FIX, std::max(1, atoi(e)));
-    const dim3 gwide((unsigned)std::min(cdiv(nchunks, 64), 4096)), gthin((unsigned)std::min(cdiv(nchunks, 64), 1024));
     const char* tfp = getenv("LSF_TRACE_MINMAX");
     const bool trace_fp = tfp && atoi(tfp) != 0;
+    auto args_of = [&](int it) {
+        MbArgs q = a;
+        q.A = V[it & 1], q.X = V[(it + 1) & 1], q.nbmask = it == 0 ? d_nb : nullptr;
+        return q;
+    };
+    // Exact ordering: the first fix pass as a wide launch over every band chunk, every further pass inside one small resident
+    // launch that loops until a pass changes nothing (k_minmax_band_tail).  Epochs of iteration it: it * MB_EPOCHS + 1 + pass.
+    constexpr int MB_EPOCHS = 64;
+    int tail_max = MB_EPOCHS - 2;
+    if (const char* e = getenv("LSF_MINMAX_TAIL_MAX")) tail_max = std::min(tail_max, std::max(1, atoi(e))); // test hook: too few passes
+    int* bar = chg + MB_EPOCHS; // barrier word of the tail launch, behind its per-pass change counts
+    int host_ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < iter; ++it) { // DO n = 1,iter (set3d.f90:394)
-        const double* A = aold[it & 1];
-        double* An = aold[(it + 1) & 1];
-        const int32_t* mask = it == 0 ? d_nb : nullptr;
-        const int epoch0 = it * (MM_MAX_FIX + 1) + 1; // stamps of this iteration: epoch0+1 .. epoch0+MM_MAX_FIX
-        if (cap > 0) HIPCHK(hipMemsetAsync(chg, 0, CHG_BYTES, st));
-        hipLaunchKernelGGL((k_minmax_band<0>), gl, b256, 0, st, d_phi, A, An, mask, (const int*)L, (const int*)nb6, isband, nL, sx, sxy, dx, h1,
-                           chunkflag, stamp, nchunks, 0, 0, (const int*)nullptr, (int*)nullptr, part, ctl);
-        for (int f = 0; f < cap; ++f)
-            hipLaunchKernelGGL((k_minmax_band<1>), f < 3 ? gwide : gthin, b256, 0, st, d_phi, A, An, mask, (const int*)L, (const int*)nb6, isband,
-                               nL, sx, sxy, dx, h1, chunkflag, stamp, nchunks, epoch0 + f, f == 0 ? 1 : 0,
-                               f == 0 ? (const int*)nullptr : (const int*)(chg + f - 1), chg + f, part, ctl);
-        hipLaunchKernelGGL((k_minmax_band<2>), gl, b256, 0, st, d_phi, A, An, mask, (const int*)L, (const int*)nb6, isband, nL, sx, sxy, dx, h1,
-                           chunkflag, stamp, nchunks, 0, cap, cap > 0 ? (const int*)(chg + cap - 1) : (const int*)nullptr, (int*)nullptr, part,
-                           ctl);
+        const MbArgs q = args_of(it);
+        hipLaunchKernelGGL((k_minmax_band<0>), gl, b256, 0, st, q);
+        if (gs) {
+            const int epoch0 = it * MB_EPOCHS + 1;
+            (void)hipMemsetAsync(chg, 0, (MB_EPOCHS + 1) * sizeof(int), st);
+            hipLaunchKernelGGL(k_minmax_band_fix, gl, b256, 0, st, q, epoch0, chg);
+            hipLaunchKernelGGL(k_minmax_band_tail, dim3(MB_TAIL_BLOCKS), b256, 0, st, q, epoch0 + 1, tail_max, (const int*)chg, chg + 1, bar,
+                               200000000ull);
+        }
+        hipLaunchKernelGGL((k_minmax_band<2>), gl, b256, 0, st, q);
         if (nchunks > 16384) {
             hipLaunchKernelGGL(k_reduce_slices, dim3(256), dim3(256), 0, st, (const double*)part, (long)nchunks, part2);
-            hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, (const double*)part2, 256L, den, tol, d_trace, std::max(iter, 1), ctl);
+            hipLaunchKernelGGL(k_mb_finish, dim3(1), dim3(RED_T), 0, st, (const double*)part2, 256L, den, tol, d_trace, std::max(iter, 1), ctl);
         } else {
-            hipLaunchKernelGGL(k_finish, dim3(1), dim3(RED_T), 0, st, (const double*)part, (long)nchunks, den, tol, d_trace, std::max(iter, 1),
+            hipLaunchKernelGGL(k_mb_finish, dim3(1), dim3(RED_T), 0, st, (const double*)part, (long)nchunks, den, tol, d_trace, std::max(iter, 1),
                                ctl);
         }
-        if (cap > 0 && trace_fp) {
-            int hc[MM_MAX_FIX + 1] = {0};
+        if (gs && trace_fp) {
+            int hc[MB_EPOCHS] = {0};
             HIPCHK(hipMemcpyAsync(hc, chg, sizeof hc, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             fprintf(stderr, "[lsf] min/max iteration %d (band): chunks changed per fix pass:", it + 1);
-            for (int f = 0; f < MM_MAX_FIX; ++f) fprintf(stderr, " %d", hc[f]);
+            for (int f = 0; f < MB_EPOCHS && (f == 0 || hc[f - 1]); ++f) fprintf(stderr, " %d", hc[f]);
             fprintf(stderr, "\n");
         }
-        const bool early = gs && exact_mode == MM_FP_ADAPTIVE && (it == 0 || it == 1 || it == 3);
-        if (((it + 1) % CHECK_EVERY == 0 || early) && it + 1 < iter) {
+        if ((it + 1) % CHECK_EVERY == 0 && it + 1 < iter) {
             HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             if (host_ctl[0] || host_ctl[3]) break;
-            if (gs && exact_mode == MM_FP_ADAPTIVE) cap = std::min(MM_MAX_FIX, std::max(8, 3 * host_ctl[4] + 4));
         }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (gs && getenv("LSF_TRACE"))
-        fprintf(stderr, "[lsf] min/max on the band: at most %d fix passes changed cells (%d enqueued at the end)%s\n", host_ctl[4], cap,
-                host_ctl[3] ? "; NOT certified -> rerun" : "");
-    const dim3 ge((unsigned)cdiv(nL, 256));
-    if (host_ctl[3]) { // the caller repeats the call: phi as it was on entry (the masks have not been touched)
-        hipLaunchKernelGGL(k_mb_restore, ge, b256, 0, st, (const int*)L, (const double*)a0, nL, d_phi);
-        HIPCHK(hipStreamSynchronize(st));
-        if (inexact) *inexact = true;
+    if (host_ctl[3]) { // an iteration the tail launch did not certify (never observed): phi and the masks have not been written
+        if (trace) fprintf(stderr, "[lsf] min/max on the band: iteration %d NOT certified -> dense executor\n", host_ctl[1] + 1);
         return LSF_OK;
     }
+    if (gs && trace) fprintf(stderr, "[lsf] min/max on the band: at most %d fix passes per iteration\n", host_ctl[4] + 1);
+    *dense = false;
     const int nit = host_ctl[1];
     const bool stopped_early = host_ctl[0] != 0; // converged or NaN: EXIT/STOP before narrowBand
+    if (nit >= 1) hipLaunchKernelGGL(k_mb_scatter, ge, b256, 0, st, (const int*)L, (const double*)V[nit & 1], nL, d_phi);
     // masks the host would hold now (set3d.f90:448-460): narrowBand of the final field, or -- when the loop was left by EXIT / STOP
     // -- of the field before the last iteration: the final field with the list cells as that iteration froze them
     if (nit >= 1 && (!stopped_early || nit >= 2)) {
         if ((rc = narrowband_core(d_phi, d_nb, d_sb, n, dx, st))) return rc;
-        if (stopped_early) hipLaunchKernelGGL(k_mb_patch_masks, ge, b256, 0, st, (const int*)L, (const double*)aold[(nit - 1) & 1], nL, dx, d_nb, d_sb);
+        if (stopped_early) hipLaunchKernelGGL(k_mb_patch_masks, ge, b256, 0, st, (const int*)L, (const double*)V[(nit - 1) & 1], nL, dx, d_nb, d_sb);
     }
     if (rms_trace && trace_cap > 0 && nit > 0)
         HIPCHK(hipMemcpyAsync(rms_trace, d_trace, sizeof(double) * (size_t)std::min(nit, trace_cap), hipMemcpyDeviceToHost, st));
@@ -324,13 +340,9 @@ int minmax_core(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int
     // grid or a field beyond 32-bit point indices: the dense executors below.
     const char* ed = getenv("LSF_MINMAX_DENSE");
     if (args_ok && !force_tiles && !(ed && atoi(ed) != 0)) {
-        for (int exact_mode : {MM_FP_ADAPTIVE, MM_FP_FULL}) {
-            bool inexact = false, dense = false;
-            const int rcb = minmax_band_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap, st,
-                                             exact_mode, &inexact, &dense);
-            if (dense) break;
-            if (rcb != LSF_OK || !inexact) return rcb;
-        }
+        bool dense = false;
+        const int rcb = minmax_band_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace, trace_cap, st, &dense);
+        if (rcb != LSF_OK || !dense) return rcb;
     }
     if (order != LSF_ORDER_GS || force_tiles || !args_ok)
         return minmax_core_impl(d_phi, d_nb, d_sb, nx, ny, nz, iter, dx, h1, tol, mode, iters_done, rms_trace,

@@ -126,12 +126,36 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi
         };
 #pragma unroll
         for (int m = 0; m < 6; ++m) qz[m + 1] = ldz(k0 - 3 + m);
+        // STRICT: the differences of the march axis carried from plane to plane (lsf_cell.hpp, WenoDiffs): per cell one new X, one
+        // new Y, one new P and its square instead of five second differences, six first differences and six squares -- the same
+        // doubles, the formulas being the same at every offset.  (The data are frozen in this ordering; the exact ordering
+        // cannot do this: there the centre value differs between a cell's two uses.)
+        [[maybe_unused]] WenoDiffs dz;
+        [[maybe_unused]] double t0p_prev = 0.0;
+        [[maybe_unused]] bool prev_weno = false;
+        [[maybe_unused]] const double rdx = recip_refined(dx);
         for (int k = k0; k < k1; ++k) {
 #pragma unroll
             for (int m = 0; m < 6; ++m) qz[m] = qz[m + 1];
             qz[6] = ldz(k + 3);
             const int gk = k + bx.gz0;
             const bool weno_ok = ij_weno && gk > 3 && gk < bx.nz - 4;
+            if constexpr (STRICT) {
+                if (k == k0) {
+                    weno_diffs_strict(qz, dx, rdx, false, dz);
+                } else {
+                    dz.cp = dz.bp, dz.bp = dz.ap, dz.am = dz.bm;
+                    dz.ap = weno_X(qz[6], qz[5], qz[4], dx, rdx);
+                    dz.bm = weno_X(qz[1], qz[2], qz[3], dx, rdx);
+#pragma unroll
+                    for (int m = 0; m < 5; ++m) dz.p[m] = dz.p[m + 1], dz.s[m] = dz.s[m + 1];
+                    dz.p[5] = weno_P(qz[6], qz[5], dx, rdx);
+                    {
+#pragma clang fp contract(off)
+                        dz.s[5] = dz.p[5] * dz.p[5];
+                    }
+                }
+            }
             const auto P = desc(A + sxy * k, 3); // (x+m, y+n) of this cell: col + 8*(m+3) + n*rowb
             double qx[7], qy[7];
             if (weno_ok) {
@@ -148,7 +172,28 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi
             }
             const auto PS = desc(phiS + sxy * k, 0);
             const auto PB = desc(Bout + sxy * k, 0);
-            const double newv = cell_update<STRICT>(qx, qy, qz, weno_ok, at(PS, col), dx, inv_dx, floor2, h);
+            double newv;
+            if constexpr (STRICT) {
+#pragma clang fp contract(off)
+                const double phic = qz[3], pS = at(PS, col);
+                double a, b, c, d, e, f;
+                if (weno_ok) {
+                    // 13 (bp - cp)^2 of this cell is 13 (ap - bp)^2 of the cell before, if that cell was evaluated
+                    dz.t1p = prev_weno ? t0p_prev : 13. * (dz.bp - dz.cp) * (dz.bp - dz.cp);
+                    weno_axis_strict(qx, dx, false, a, b);
+                    weno_axis_strict(qy, dx, true, c, d);
+                    weno_from_diffs_strict(dz, e, f, t0p_prev);
+                } else {
+                    a = div_dx(phic - qx[2], dx, rdx), b = div_dx(qx[4] - phic, dx, rdx);
+                    c = div_dx(phic - qy[2], dx, rdx), d = div_dx(qy[4] - phic, dx, rdx);
+                    e = div_dx(phic - qz[2], dx, rdx), f = div_dx(qz[4] - phic, dx, rdx);
+                }
+                prev_weno = weno_ok;
+                newv = finish_update<true>(phic, axis_godunov<true>(phic, a, b), axis_godunov<true>(phic, c, d), axis_godunov<true>(phic, e, f),
+                                           pS, dx, 0.0, h);
+            } else {
+                newv = cell_update<STRICT>(qx, qy, qz, weno_ok, at(PS, col), dx, inv_dx, floor2, h);
+            }
             {
                 typedef unsigned u2 __attribute__((ext_vector_type(2)));
                 u2 w;

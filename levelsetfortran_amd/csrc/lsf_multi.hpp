@@ -730,8 +730,12 @@ int run(lsf_multi* M, std::vector<RankState<T>>& ranks, int iter, double dx, dou
     S.vals.assign((size_t)nr * MAX_CHECK, 0.0);
     S.seq0 = M->posted[0].load();
     for (auto& R : ranks) { // phiS = phi on entry (subs.f90:731)
+        // ON THE BLOCK'S COMPUTE STREAM: a device-to-device hipMemcpy returns before the copy has run, on the null stream, and the
+        // block's streams are non-blocking -- nothing ordered the first sweep behind it.  Found in round 5 by the at-size
+        // rehearsal of BASELINE configuration 5 (tests/test_gpu_configs45.py): with blocks of >= 1 GB the first workgroups of the
+        // first sweep read a sign field that had not arrived (NaN); blocks of a few hundred MB had always won the race.
         if (hipSetDevice(R.dev) != hipSuccess ||
-            hipMemcpy(R.phiS, R.buf[0], R.g.npoints() * sizeof(T), hipMemcpyDeviceToDevice) != hipSuccess) {
+            hipMemcpyAsync(R.phiS, R.buf[0], R.g.npoints() * sizeof(T), hipMemcpyDeviceToDevice, R.compute) != hipSuccess) {
             *err = "copying the sign field failed";
             return LSF_ERR_HIP;
         }

@@ -15,6 +15,10 @@ import sys
 
 out, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(here))
+from bench import kernel_sources_fingerprint  # noqa: E402
+
+SRC = kernel_sources_fingerprint()  # bench.py attaches the counters to a line only while the kernel sources are these
 
 
 def norm(name):
@@ -78,6 +82,27 @@ for line in open(os.path.join(out, "configs.txt")):
         e["hbm_bytes_per_sweep"] = fb + wb
         e["algorithmic_bytes_per_sweep"] = 24.0 * float(N - 2) ** 3
         e["traffic_over_algorithmic"] = (fb + wb) / e["algorithmic_bytes_per_sweep"]
+        # the same from the L2s' request counters resolved by size (rocprofv3 on gfx950: TCC_EA0_RDREQ with _32B / _64B / _128B,
+        # TCC_EA0_WRREQ with _64B): bytes really asked of the fabric; FETCH_SIZE x 2 above is exact only where every request is
+        # a 128-byte one
+        rq = counters(os.path.join(d, "RDREQ"), want).get(k, {})
+        wq = counters(os.path.join(d, "WRREQ"), want).get(k, {})
+        if rq.get("TCC_EA0_RDREQ_sum"):
+            n_all, n32, n64, n128 = (rq.get(c, 0.0) for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"))
+            other = max(n_all - n32 - n64 - n128, 0.0)
+            e["read_requests_per_sweep"] = {"all": n_all / sweeps, "32B": n32 / sweeps, "64B": n64 / sweeps, "128B": n128 / sweeps}
+            e["fetch_bytes_per_sweep_by_request_size"] = (32.0 * n32 + 64.0 * n64 + 128.0 * n128 + 64.0 * other) / sweeps
+        if wq.get("TCC_EA0_WRREQ_sum"):
+            w_all, w64 = wq.get("TCC_EA0_WRREQ_sum", 0.0), wq.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+            e["write_requests_per_sweep"] = {"all": w_all / sweeps, "64B": w64 / sweeps}
+            e["write_bytes_per_sweep_by_request_size"] = (64.0 * w64 + 32.0 * max(w_all - w64, 0.0)) / sweeps
+            e["dram_requests_per_sweep"] = {"read": wq.get("TCC_EA0_RDREQ_DRAM_sum", 0.0) / sweeps, "write": wq.get("TCC_EA0_WRREQ_DRAM_sum", 0.0) / sweeps}
+        if "fetch_bytes_per_sweep_by_request_size" in e and "write_bytes_per_sweep_by_request_size" in e:
+            e["hbm_bytes_per_sweep_upper_bound"] = e["hbm_bytes_per_sweep"]
+            e["hbm_bytes_per_sweep"] = e["fetch_bytes_per_sweep_by_request_size"] + e["write_bytes_per_sweep_by_request_size"]
+            e["traffic_over_algorithmic_upper_bound"] = e["traffic_over_algorithmic"]
+            e["traffic_over_algorithmic"] = e["hbm_bytes_per_sweep"] / e["algorithmic_bytes_per_sweep"]
+            e["traffic_method"] = "TCC_EA0_RDREQ / _WRREQ by request size"
         s = sq.get(k, {})
         if s.get("SQ_WAVES"):
             e["sq"] = {c: v for c, v in s.items()}
@@ -92,9 +117,10 @@ for line in open(os.path.join(out, "configs.txt")):
                 # flight: how full the SIMD's vector issue is (<= 1; the exact-ordering launch keeps its slots occupied)
                 e["valu_busy_share"] = min(1.0, e["valu_active_over_wave_cycles"] * oc["waves_per_simd"])
         res[f"{N} {arith} {mode} {k}"] = e
-        traffic.setdefault(k, {})[str(N)] = {q: e[q] for q in ("hbm_bytes_per_sweep", "traffic_over_algorithmic", "valu_lane_insts_per_cell",
+        traffic.setdefault(k, {})[str(N)] = {q: e[q] for q in ("hbm_bytes_per_sweep", "traffic_over_algorithmic", "traffic_method", "traffic_over_algorithmic_upper_bound", "valu_lane_insts_per_cell",
                                                                  "valu_active_over_wave_cycles", "waves_per_simd", "valu_busy_share") if q in e}
         traffic[k][str(N)]["source"] = f"profiles/{tag}_ships.json"
+        traffic[k][str(N)]["kernel_sources"] = SRC
 json.dump(res, open(os.path.join(here, f"{tag}_ships.json"), "w"), indent=1)
 json.dump(traffic, open(tp, "w"), indent=1)
 for k, e in res.items():

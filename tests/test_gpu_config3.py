@@ -65,9 +65,11 @@ def test_config3_cubic_512_stage_by_stage_on_the_device(sweeps, monkeypatch):
     sb = torch.zeros(npts, dtype=torch.int32, device="cuda")
     lsf.narrowBand(nx, ny, nz, dx, phi, nb, sb)
     assert _sha_t(nb) == str(g["NB0_sha"]) and _sha_t(sb) == str(g["SB0_sha"])
-    # min/max flow, 200 iterations: fixed-point executor (default) and tile-hyperplane executor
-    for tiles in (False, True):
-        if tiles:
+    # min/max flow, 200 iterations: the three exact executors -- on the band (default), dense fixed point, tile hyperplanes
+    for tiles in ("band", "dense", "tiles"):
+        if tiles == "dense":
+            monkeypatch.setenv("LSF_MINMAX_DENSE", "1")
+        if tiles == "tiles":
             monkeypatch.setenv("LSF_MINMAX_TILES", "1")
         p2, nb2, sb2 = phi.clone(), nb.clone(), sb.clone()
         rm = lsf.minmaxFlow(p2, nb2, sb2, nx, ny, nz, 200, dx, float(g["h1"]))

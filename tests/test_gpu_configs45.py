@@ -88,3 +88,81 @@ def test_config5_1536_fp32_two_spheres_block_tracks_oracle(oracle):
     assert np.array_equal(np.signbit(got[a:b, a:b, a:b][far]), np.signbit(ref[a:b, a:b, a:b][far]))
     assert bool(torch.isfinite(phi).all())
     lsf._lib.load().lsf_release_workspace()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The jobs' OWN decompositions at their full size, rehearsed with every block on the one GPU of the test box (VERDICT r4
+# item 6): pack / unpack offsets, 32-bit index paths and the core | rims split at BASELINE block sizes (1024 x 512 x 512 and
+# 512 x 512 x 1024 points fp64, 768^3 fp32).  lsf_reinit_multi scatters the host field into blocks with 3 ghost layers, runs
+# the decomposed Jacobi sweeps (peer copies between the blocks, which here share the device) and gathers the result: it must
+# be the single-domain Jacobi field bit for bit (SHA-256 of the whole field).
+# ---------------------------------------------------------------------------------------------------------------------
+def _sha_host(a):
+    import hashlib
+
+    h = hashlib.sha256()
+    flat = a.reshape(-1, order="F")
+    step = 1 << 26
+    for o in range(0, flat.size, step):
+        h.update(flat[o:o + step].tobytes())
+    return h.hexdigest()
+
+
+def _as_host_field(t):
+    """the [k][j][i] device tensor as an (i, j, k) Fortran-ordered host array (no second host copy)"""
+    a = t.cpu().numpy().transpose(2, 1, 0)
+    assert a.flags.f_contiguous
+    return a
+
+
+@pytest.mark.parametrize("dims", [(1, 2, 2), (2, 2, 1)])
+def test_config4_1024_fp64_own_decomposition_on_one_device(dims):
+    """BASELINE configuration 4: 1024^3 fp64, four blocks.  (1, 2, 2) is the split bench.py runs on four ranks (x, the unit-stride
+    axis, uncut); (2, 2, 1) is BASELINE.json's literal "2x2x1" read as (x, y, z)."""
+    import time
+
+    import levelsetfortran_amd as lsf
+    from levelsetfortran_amd import fields
+
+    N, s = 1024, 4
+    phi, dx = _build(N, ((0.0, 0.0, 0.0),), 1.0, torch.float64)
+    h = fields.reinit_step(dx)
+    host = _as_host_field(phi)
+    t0 = time.time()
+    rep1 = lsf.reinit(phi.reshape(-1), None, None, N - 1, N - 1, N - 1, s - 1, dx, h, tol=0.0, order="jacobi", arith="strict")
+    want = _sha_host(_as_host_field(phi))
+    del phi
+    torch.cuda.empty_cache()
+    lsf._lib.load().lsf_release_workspace()
+    rep = lsf.reinit_multi(host, N - 1, N - 1, N - 1, s - 1, dx, h, [0] * 4, dims=dims, tol=0.0, arith="strict")
+    assert rep.count == rep1.count == s
+    assert _sha_host(host) == want, dims
+    assert np.allclose(rep.rms, rep1.rms, rtol=1e-12, atol=0)
+    print(f"config 4 split {dims}: {time.time() - t0:.1f} s")
+    lsf._lib.load().lsf_release_workspace()
+
+
+def test_config5_1536_fp32_own_decomposition_on_one_device():
+    """BASELINE configuration 5: 1536^3 fp32, eight blocks 2 x 2 x 2 of 768^3 points: the fp32 decomposed sweep == the fp32
+    single-domain sweep, bit for bit."""
+    import time
+
+    import levelsetfortran_amd as lsf
+    from levelsetfortran_amd import fields
+
+    N, s = 1536, 4
+    phi, dx = _build(N, ((-0.6, 0.0, 0.0), (0.6, 0.0, 0.0)), 0.5, torch.float32)
+    h = fields.reinit_step(dx)
+    host = _as_host_field(phi)
+    assert host.dtype == np.float32
+    t0 = time.time()
+    rep1 = lsf.reinit(phi.reshape(-1), None, None, N - 1, N - 1, N - 1, s - 1, dx, h, tol=0.0, order="jacobi")
+    want = _sha_host(_as_host_field(phi))
+    del phi
+    torch.cuda.empty_cache()
+    lsf._lib.load().lsf_release_workspace()
+    rep = lsf.reinit_multi(host, N - 1, N - 1, N - 1, s - 1, dx, h, [0] * 8, dims=(2, 2, 2), tol=0.0)
+    assert rep.count == rep1.count == s
+    assert _sha_host(host) == want
+    print(f"config 5 split (2, 2, 2): {time.time() - t0:.1f} s")
+    lsf._lib.load().lsf_release_workspace()

@@ -296,15 +296,24 @@ def test_narrowband(lsf, cube40):
     assert np.array_equal(nb, cube40["NB0"]) and np.array_equal(sb, cube40["SB0"])
 
 
+@pytest.fixture(params=["default", "band"])
+def mm_executor(request, monkeypatch):
+    """cube40 as shipped has 32 % of its 62^3 points in the narrow band: by default the dense executor takes it (bands above a quarter
+    of the grid); "band" makes the band executor take any band, so that both run every cube40 case."""
+    if request.param == "band":
+        monkeypatch.setenv("LSF_MINMAX_BAND_MAX", "100")
+    return request.param
+
+
 @pytest.mark.parametrize("its", [1, 2, 10, 200])
-def test_minmax_cube40_intermediate(lsf, cube40, its):
+def test_minmax_cube40_intermediate(lsf, cube40, its, mm_executor):
     nx, ny, nz = _n(cube40)
     phi, nb, sb = F(cube40["phi_reinit"]), F(cube40["NB0"].astype(np.int32)), F(cube40["SB0"].astype(np.int32))
     rep = lsf.minmaxFlow(phi, nb, sb, nx, ny, nz, its, float(cube40["dx"]), float(cube40["h1"]))
     assert rep.count == its and sha(phi) == str(cube40[f"mm{its}_sha"])
 
 
-def test_minmax_cube40_to_convergence(lsf, cube40):
+def test_minmax_cube40_to_convergence(lsf, cube40, mm_executor):
     nx, ny, nz = _n(cube40)
     for seam in ("host", "device"):
         phi, nb, sb = F(cube40["phi_reinit"]), F(cube40["NB0"].astype(np.int32)), F(cube40["SB0"].astype(np.int32))
@@ -423,19 +432,72 @@ def test_minmax_tile_wavefront_path(lsf, oracle, cube40, monkeypatch):
     test_minmax_vs_oracle_other_shapes(lsf, oracle)
 
 
-def test_minmax_uncertified_fixed_point_is_repeated(lsf, oracle, cube40, monkeypatch, capfd):
-    """The fixed-point passes are enqueued without a host round trip; when an iteration needs more passes than were
-    enqueued, the call starts over with the full count.  One pass is never enough here (the first fix pass always
-    changes cells), so this runs the second rung of the ladder; the result must not change."""
-    monkeypatch.setenv("LSF_MINMAX_FIX_START", "1")
+def test_minmax_uncertified_iteration_falls_back_to_the_dense_executor(lsf, oracle, cube40, monkeypatch, capfd):
+    """The band executor runs every fix pass after the first inside one resident launch that loops until a pass changes nothing (up
+    to 62 passes).  LSF_MINMAX_TAIL_MAX=1 leaves it one pass: an iteration it cannot certify ends the attempt with nothing written,
+    and the call is run by the dense executor; the result must not change."""
+    monkeypatch.setenv("LSF_MINMAX_TAIL_MAX", "1")
+    monkeypatch.setenv("LSF_MINMAX_BAND_MAX", "100")
     monkeypatch.setenv("LSF_TRACE", "1")
     nx, ny, nz = _n(cube40)
+    phi, nb, sb = F(cube40["phi_reinit"]), F(cube40["NB0"].astype(np.int32)), F(cube40["SB0"].astype(np.int32))
+    rep = lsf.minmaxFlow(phi, nb, sb, nx, ny, nz, 200, float(cube40["dx"]), float(cube40["h1"]))
+    assert rep.count == 200 and sha(phi) == str(cube40["mm200_sha"])
+    assert "NOT certified -> dense executor" in capfd.readouterr().err
+    monkeypatch.delenv("LSF_TRACE")
+    monkeypatch.delenv("LSF_MINMAX_TAIL_MAX")
+    test_minmax_vs_oracle_other_shapes(lsf, oracle)
+
+
+def test_minmax_dense_executor(lsf, oracle, cube40, monkeypatch, capfd):
+    """LSF_MINMAX_DENSE=1: the executor that streams the whole grid every iteration (the path of bands above a quarter of the grid
+    and of fields beyond 32-bit point indices): cube40 to its stop, the other shapes, and its own ladder -- an uncertified
+    iteration there repeats the call with the full pass count."""
+    monkeypatch.setenv("LSF_MINMAX_DENSE", "1")
+    nx, ny, nz = _n(cube40)
+    phi, nb, sb = F(cube40["phi_reinit"]), F(cube40["NB0"].astype(np.int32)), F(cube40["SB0"].astype(np.int32))
+    rep = lsf.minmaxFlow(phi, nb, sb, nx, ny, nz, 10000, float(cube40["dx"]), float(cube40["h1"]))
+    assert rep.count == 406 and rep.converged and np.array_equal(phi, cube40["phi_minmax"])
+    assert np.array_equal(nb, cube40["NBfinal"]) and np.array_equal(sb, cube40["SBfinal"])
+    assert np.allclose(rep.rms[:-1], cube40["rms_minmax"], rtol=1e-9, atol=0)
+    test_minmax_vs_oracle_other_shapes(lsf, oracle)
+    monkeypatch.setenv("LSF_MINMAX_FIX_START", "1")
+    monkeypatch.setenv("LSF_TRACE", "1")
     phi, nb, sb = F(cube40["phi_reinit"]), F(cube40["NB0"].astype(np.int32)), F(cube40["SB0"].astype(np.int32))
     rep = lsf.minmaxFlow(phi, nb, sb, nx, ny, nz, 10, float(cube40["dx"]), float(cube40["h1"]))
     assert rep.count == 10 and sha(phi) == str(cube40["mm10_sha"])
     assert "NOT certified -> rerun" in capfd.readouterr().err
-    monkeypatch.delenv("LSF_TRACE")
-    test_minmax_vs_oracle_other_shapes(lsf, oracle)
+
+
+def test_minmax_band_executor_with_a_mask_that_is_not_the_band(lsf, oracle, monkeypatch):
+    """The C ABI takes ANY mask for the first iteration (set3d.f90:399 reads phiNB as the host left it).  The band executor's list is
+    mask == 1 OR |phi| < 4.1 dx: a mask with cells far outside the band (they move in iteration 1 only) and WITHOUT some band cells
+    (they start to move in iteration 2) -- against the oracle, both orderings, and against the dense executor."""
+    from levelsetfortran_amd import fields
+
+    npts = (36, 30, 41)
+    nx, ny, nz = (v - 1 for v in npts)
+    x, y, z, dx = fields.grid_axes(npts, -1.0, 1.0)
+    d = np.sqrt(x[:, None, None] ** 2 + y[None, :, None] ** 2 + (z[None, None, :] + 0.1) ** 2) - 0.45
+    phi0 = np.asfortranarray(d + 0.02 * np.sin(9 * x)[:, None, None] * np.cos(7 * y)[None, :, None])
+    nb, sb = oracle.narrowband(nx, ny, nz, dx, phi0)
+    rng = np.random.default_rng(5)
+    odd = nb.copy(order="F")
+    odd[rng.random(odd.shape) < 0.02] = 1          # cells anywhere in the grid, walls included (never updated there)
+    odd[(rng.random(odd.shape) < 0.3) & (nb == 1)] = 0  # band cells the first iteration must skip
+    odd[rng.random(odd.shape) < 0.01] = 7          # neither 0 nor 1: not in the band
+    for order in ("gs", "jacobi"):
+        a, na, sa = phi0.copy(order="F"), odd.copy(order="F"), sb.copy(order="F")
+        oracle.minmax(a, na, sa, nx, ny, nz, 9, dx, 1e-4, tol=0.0, order=oracle.GS_LEX if order == "gs" else oracle.JACOBI)
+        res = {}
+        for dense in ("0", "1"):
+            monkeypatch.setenv("LSF_MINMAX_DENSE", dense)
+            b, nb2, sb2 = phi0.copy(order="F"), odd.copy(order="F"), sb.copy(order="F")
+            rep = lsf.minmaxFlow(b, nb2, sb2, nx, ny, nz, 9, dx, 1e-4, tol=0.0, order=order)
+            assert rep.count == 9
+            assert np.array_equal(a, b) and np.array_equal(na, nb2) and np.array_equal(sa, sb2), (order, dense)
+            res[dense] = np.array(rep.rms)
+        assert np.allclose(res["0"], res["1"], rtol=1e-11, atol=0)
 
 
 @pytest.mark.parametrize("geometry", [("4", "16"), ("5", "32"), ("4", "32")])
