@@ -99,6 +99,22 @@ void gs_skew_w(int ny, int nz, bool strict, int* wy, int* wz, int* by)
     for (auto& s : ok)
         if (s[0] == y && s[1] == z) *wy = y, *wz = z;
 }
+// marching steps of a skewed tile: 16.  Tiles of 32 steps (three lanes per cell, 2 x 2 wavefronts; skew_tile and the host code
+// below are written for both) were built in round 5 for grids below 384 cells across, where a sweep costs its chain of dependent
+// tiles: consecutive sweeps are spaced by n / TA time slots (+ the tiles across where a cross-section axis flips), so a tile twice
+// as long was expected to trade 34.5 hand-offs per 256^3 sweep for 24.5 slightly longer ones.  Measured (profiles/r05_ta32_ab.txt,
+// one box, bit-identical): SLOWER at every size from 64^3 to 512^3 -- 256^3 0.591 -> 0.673 ms per sweep FAST, 0.928 -> 1.176
+// STRICT -- a hand-off carries the tile's whole load and write back, which double with the tile.  Experiment builds only
+// (LSF_GS_SKEW_TA=32): the product library holds no such kernel.
+int gs_skew_ta(int cells_across, int wy, int wz, int by)
+{
+#ifdef LSF_EXPERIMENTS
+    if (by == 5 && wy == 2 && wz == 2)
+        if (const char* e = getenv("LSF_GS_SKEW_TA")) return atoi(e) == 32 ? 32 : 16;
+#endif
+    (void)cells_across, (void)wy, (void)wz, (void)by;
+    return 16;
+}
 // dispatch on the tile shape: CALL(WY, WZ, BY) with compile-time arguments
 #define LSF_SK_SHAPES(CALL, wy_, wz_, by_)               \
     do {                                                 \
@@ -321,7 +337,7 @@ int get_skew_tiles(int nxi, int nTj, int nTk, int ta, int nyc, int nzc, TileList
 {
     const int m_max = (nxi - 1 + nyc * nTj - 1 + nzc * nTk - 1) / ta;
     if (m_max > 1023 || nTj > 1023 || nTk > 1023) return fail(LSF_ERR_INVALID, "grid too large for tile index packing");
-    const uint64_t key = ((uint64_t)nxi << 44) | ((uint64_t)nTj << 28) | ((uint64_t)nTk << 12) | (uint64_t)(nyc << 6 | nzc);
+    const uint64_t key = ((uint64_t)nxi << 44) | ((uint64_t)nTj << 28) | ((uint64_t)nTk << 12) | (uint64_t)(nyc << 6 | nzc) | (ta == 32 ? 1u << 11 : 0u);
     Ctx& c = ctx();
     auto it = c.skew_tiles.find(key);
     if (it == c.skew_tiles.end()) {

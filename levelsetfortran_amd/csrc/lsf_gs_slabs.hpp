@@ -211,7 +211,7 @@ int reinit_gs_slabs(double* phi, int nx, int ny, int nz, int iter, double dx, do
         if ((rc = slab_alloc(b, (void**)&b.colsum, (size_t)4 * ncol * sizeof(double), fine))) return rc;
         HIPCHK(hipMemset(b.colsum, 0, (size_t)4 * ncol * sizeof(double)));
         if ((rc = slab_alloc(b, (void**)&b.trace, (size_t)max_sweeps * sizeof(double), fine))) return rc;
-        if ((rc = get_sk_tables(wy, wz, by, &b.tables))) return rc;
+        if ((rc = get_sk_tables(16, wy, wz, by, &b.tables))) return rc;
         // this slab's tiles per hyperplane: frame C runs along z in sweeps with sk > 0 (C = tk), against it otherwise
         long ntiles = 0;
         for (int v = 0; v < 2; ++v) {

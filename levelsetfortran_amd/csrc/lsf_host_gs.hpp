@@ -4,10 +4,10 @@
 #pragma once
 
 // lookup tables of a skewed tile shape (lsf_skew.hpp: sk_fill_tables), built once per shape and device
-int get_sk_tables(int wy, int wz, int by, const uint32_t** out)
+int get_sk_tables(int ta, int wy, int wz, int by, const uint32_t** out)
 {
     Ctx& c = ctx();
-    const int key = by * 256 + wy * 16 + wz;
+    const int key = by * 256 + wy * 16 + wz + (ta == 32 ? 1 << 16 : 0);
     auto it = c.sk_tables.find(key);
     if (it == c.sk_tables.end()) {
         std::vector<uint32_t> h;
@@ -17,7 +17,16 @@ int get_sk_tables(int wy, int wz, int by, const uint32_t** out)
         h.assign((size_t)T_::REL_WORDS + T_::OFF_WORDS, 0u);                                 \
         sk_fill_tables<16, WY_, WZ_, BY_>(h.data());                                         \
     } while (0)
-        LSF_SK_SHAPES(LSF_SK_TAB, wy, wz, by);
+#ifdef LSF_EXPERIMENTS
+        if (ta == 32) {
+            using T_ = SkTile<32, 2, 2, 5>;
+            h.assign((size_t)T_::REL_WORDS + T_::OFF_WORDS, 0u);
+            sk_fill_tables<32, 2, 2, 5>(h.data());
+        } else
+#endif
+        {
+            LSF_SK_SHAPES(LSF_SK_TAB, wy, wz, by);
+        }
 #undef LSF_SK_TAB
         uint32_t* d = nullptr;
         HIPCHK(hipMalloc((void**)&d, h.size() * sizeof(uint32_t)));
@@ -63,7 +72,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     Ctx& c = ctx();
     const size_t n = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
     const int max_sweeps = iter + 1;
-    const int ta = gs_ta();
+    int ta = gs_ta();
     int nyc = gs_ny();
     int sched = gs_schedule();
     // Default: skewed tiles (lsf_skew.hpp), 2 x 2 wavefronts each, dependencies resolved in the kernel (`dataflow`,
@@ -80,6 +89,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     if (skew) {
         gs_skew_w(std::min(nx, ny), nz, strict, &wy, &wz, &by); // (the dataflow launch may swap x and y)
         nyc = by * wy, nzc = 4 * wz; // rows of a tile in y and z
+        ta = gs_skew_ta(std::min(std::min(nx, ny), nz) - 1, wy, wz, by);
     }
     // Dataflow launch: the kernel marches along ITS x axis; run it on the x <-> y transposed field so that the march axis
     // is the reference's y, the axis the raster cycle flips in six of its eight transitions (a flip of the march axis
@@ -157,7 +167,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     fa.ctl = ctl;
     fa.nTiles = (long)nTi * nTj * nTk;
     fa.last_packed = tl->last;
-    if (skew && !getenv("LSF_GS_NO_TABLES") && (rc = get_sk_tables(wy, wz, by, &fa.tables))) return rc;
+    if (skew && !getenv("LSF_GS_NO_TABLES") && (rc = get_sk_tables(ta, wy, wz, by, &fa.tables))) return rc;
 
     // start slot of sweep g, generated on demand (slot schedules; never transposed)
     std::vector<long> start{0};
@@ -219,7 +229,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         }
         for (int g0 = 0; g0 < max_sweeps; g0 += BATCH) {
             const int ns = std::min(BATCH, max_sweeps - g0), phase = (first_raster + g0) & 7;
-            const std::array<int, 6> key{knx, kny, nz, phase, ns, wy * 16 + wz + 256 * (int)tr + 1024 * nbuf + 8192 * by};
+            const std::array<int, 6> key{knx, kny, nz, phase, ns, wy * 16 + wz + 256 * (int)tr + 1024 * nbuf + 8192 * by + (ta == 32 ? 1 << 20 : 0)};
             auto it = c.plans.find(key);
             if (it == c.plans.end()) {
                 BatchPlan bp;
@@ -292,7 +302,15 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
     } while (0)
             // one block per tile (the launch with column continuation of round 4, k_reinit_gs_stream, lives on the branch
             // r04-column-continuation: bit-identical and 9-20 % slower, profiles/r04_stream_ab.txt)
-            LSF_SK_SHAPES(LSF_LAUNCH_DF, wy, wz, by);
+#ifdef LSF_EXPERIMENTS
+            if (ta == 32) {
+                if (strict) hipLaunchKernelGGL((k_reinit_gs_persist<32, 2, 2, 5, true>), grid, dim3(256), 0, st, fa);
+                else hipLaunchKernelGGL((k_reinit_gs_persist<32, 2, 2, 5, false>), grid, dim3(256), 0, st, fa);
+            } else
+#endif
+            {
+                LSF_SK_SHAPES(LSF_LAUNCH_DF, wy, wz, by);
+            }
 #undef LSF_LAUNCH_DF
             ++launches;
             if (g0 + BATCH < max_sweeps || d_dbg) { // stop flag between batches (later batches would exit at once anyway)
@@ -342,7 +360,15 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         else                                                                                                               \
             hipLaunchKernelGGL((k_reinit_gs_skew<16, WY_, WZ_, BY_, false>), dim3(grid), dim3(64 * WY_ * WZ_), 0, s_, fa); \
     } while (0)
-            LSF_SK_SHAPES(LSF_LAUNCH_SKEW, wy, wz, by);
+#ifdef LSF_EXPERIMENTS
+            if (ta == 32) {
+                if (strict) hipLaunchKernelGGL((k_reinit_gs_skew<32, 2, 2, 5, true>), dim3(grid), dim3(256), 0, s_, fa);
+                else hipLaunchKernelGGL((k_reinit_gs_skew<32, 2, 2, 5, false>), dim3(grid), dim3(256), 0, s_, fa);
+            } else
+#endif
+            {
+                LSF_SK_SHAPES(LSF_LAUNCH_SKEW, wy, wz, by);
+            }
 #undef LSF_LAUNCH_SKEW
             return;
         }
@@ -431,8 +457,8 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         g_prof.bc_ms = g_prof.finish_ms = 0;
         g_prof.sweeps = nsw;
         g_prof.sweep_launches = launches;
-        if (skew) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "%s<16,%d,%d,%d,%s>", !slots_loop ? "k_reinit_gs_persist" : "k_reinit_gs_skew",
-                           wy, wz, by, strict ? "true" : "false");
+        if (skew) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "%s<%d,%d,%d,%d,%s>", !slots_loop ? "k_reinit_gs_persist" : "k_reinit_gs_skew",
+                           ta, wy, wz, by, strict ? "true" : "false");
         else snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "k_reinit_gs_box<%d,%d,%s>", ta, nyc, strict ? "true" : "false");
         g_prof.kernel = g_prof.kernel_buf;
     }

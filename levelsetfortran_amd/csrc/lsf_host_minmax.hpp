@@ -264,7 +264,7 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     // launch that loops until a pass changes nothing (k_minmax_band_tail).  Epochs of iteration it: it * MB_EPOCHS + 1 + pass.
     constexpr int MB_EPOCHS = 64;
     int tail_max = MB_EPOCHS - 2;
-    if (const char* e = getenv("LSF_MINMAX_TAIL_MAX")) tail_max = std::min(tail_max, std::max(1, atoi(e))); // test hook: too few passes
+    if (const char* e = getenv("LSF_MINMAX_TAIL_MAX")) tail_max = std::min(tail_max, std::max(0, atoi(e))); // test hook: too few passes (0: no certifying pass at all)
     int* bar = chg + MB_EPOCHS; // barrier word of the tail launch, behind its per-pass change counts
     int host_ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < iter; ++it) { // DO n = 1,iter (set3d.f90:394)

@@ -38,6 +38,7 @@ static __global__ __launch_bounds__(256) void k_peer_litmus(PeerArgs a)
 {
     __shared__ int sh_ok;
     const int tid = threadIdx.x;
+    if (a.side < 0) return; // warm-up launch: the code object is loaded on this device before the paired launch (lsf_peer_selftest)
     int status = 0, where = 0;
     // ---- (1) + (2) + (4): message passing, both directions at once -------------------------------------------------
     for (int r = 0; r < PT_ROUNDS && status == 0; ++r) {
@@ -164,6 +165,14 @@ extern "C" int lsf_peer_selftest(int devA, int devB, int* violated)
             return fail(LSF_ERR_HIP, std::string("lsf_peer_selftest: set-up failed: ") + hipGetErrorString(hipGetLastError()));
         }
     }
+    // both devices load the kernel BEFORE the paired launch: the first launch on a device can take longer than the 2 s the other
+    // side waits, which would read as assumption (4) on a healthy pair
+    for (Side& s : S) {
+        PeerArgs w{};
+        w.side = -1;
+        (void)hipSetDevice(s.dev);
+        hipLaunchKernelGGL(k_peer_litmus, dim3(1), dim3(256), 0, s.st, w);
+    }
     for (Side& s : S) (void)hipSetDevice(s.dev), (void)hipDeviceSynchronize();
     // two kernels that wait for each other, launched one after the other by this thread on two streams (two devices)
     for (int q = 0; q < 2; ++q) {
@@ -174,7 +183,8 @@ extern "C" int lsf_peer_selftest(int devA, int devB, int* violated)
         a.result = S[q].flags + 48;
         a.side = q;
         a.timeout_ticks = 200000000ull; // 2 s of the 100 MHz clock
-        if (const char* e = getenv("LSF_GS_TIMEOUT_TICKS")) a.timeout_ticks = strtoull(e, nullptr, 10); // test hook
+        if (const char* e = getenv("LSF_PEER_TIMEOUT_TICKS")) a.timeout_ticks = strtoull(e, nullptr, 10); // test hook (its own:
+                                                                     // LSF_GS_TIMEOUT_TICKS must reach the slab launches behind this test)
         (void)hipSetDevice(S[q].dev);
         hipLaunchKernelGGL(k_peer_litmus, dim3(1), dim3(256), 0, S[q].st, a);
     }
@@ -188,7 +198,10 @@ extern "C" int lsf_peer_selftest(int devA, int devB, int* violated)
     if (rc == LSF_OK && hipMemcpy(&amax, S[0].flags + 32, sizeof amax, hipMemcpyDeviceToHost) != hipSuccess) rc = LSF_ERR_HIP;
     cleanup();
     if (rc != LSF_OK) return fail(LSF_ERR_HIP, std::string("lsf_peer_selftest: ") + hipGetErrorString(hipGetLastError()));
-    int bad = res[0][0] ? res[0][0] : res[1][0];
+    // a side that finds a violated assumption leaves, and the other side then times out: report the finding, not the time-out
+    int bad = 0, bad_at = 0;
+    for (int q = 0; q < 2; ++q)
+        if (res[q][0] && (!bad || (bad == 4 && res[q][0] != 4))) bad = res[q][0], bad_at = res[q][1];
     if (!bad && amax != 2 * (PT_AMAX - 1) + 2) bad = 3; // the final maximum is B's last value
     if (violated) *violated = bad;
     if (bad) {
@@ -196,8 +209,7 @@ extern "C" int lsf_peer_selftest(int devA, int devB, int* violated)
                                       "(2)", "(3): a system-scope atomic max on peer memory lost an update or went back",
                                       "(4): the two kernels did not run at the same time (one never saw the other's flag)"};
         char buf[512];
-        snprintf(buf, sizeof buf, "peer self-test between devices %d and %d: assumption %s (DESIGN.md section 6.1); at round / value %d", devA, devB, what[bad],
-                 res[0][0] ? res[0][1] : res[1][1]);
+        snprintf(buf, sizeof buf, "peer self-test between devices %d and %d: assumption %s (DESIGN.md section 6.1); at round / value %d", devA, devB, what[bad], bad_at);
         return fail(LSF_ERR_HIP, buf);
     }
     return LSF_OK;

@@ -300,7 +300,8 @@ template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, bool PUSH = fal
 __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, const GsArgs& a, uint32_t packed, int g, int si, int sj,
                                           int sk, const SkPre& pre, WaitUp&& wait_upstream)
 {
-    static_assert(TA == 16, "row-per-16-lanes loader");
+    static_assert(TA == 16 || (TA == 32 && BY == 5 && !PUSH), "tiles of 32 marching steps: three lanes per cell, single launch only");
+    constexpr int CPN = TA / 16; // the loaders and the write back handle a row 16 entries at a time
     using T = SkTile<TA, WY, WZ, BY>;
     constexpr int NYT = T::NYT, NZT = T::NZT, W = T::W, NT = 64 * W;
     double* const lds = sm.lds;
@@ -413,7 +414,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     // per-lane bit t: the cell of step t exists (0 <= fx0 + t < nxi) / takes the WENO branch (3 < gi < nx - 4)
     auto step_mask = [](int lo_t, int hi_t) { // bits lo_t .. hi_t - 1 of 16
         lo_t = min(max(lo_t, 0), TA), hi_t = min(max(hi_t, lo_t), TA);
-        return ((1u << hi_t) - 1u) & ~((1u << lo_t) - 1u);
+        return (unsigned)(((1ull << hi_t) - 1ull) & ~((1ull << lo_t) - 1ull));
     };
     const unsigned act_bits = row_ok ? step_mask(-fx0, nxi - fx0) : 0u;
     // 3 < gi < nx - 4 with gi = 1 + fx (si > 0: 2 < fx < nx - 5) or gi = nx - 1 - fx (si < 0: 3 < fx < nx - 4)
@@ -442,7 +443,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     // odd entries per bundle row no longer cost separate scattered requests.
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));
     constexpr int AUX_SC1 = SYS ? 17 : (SC1 ? 16 : 0); // cache policy of the buffer instructions: sc1 = bit 4, sc0 = bit 0 (system scope: both)
-    const bool widex = (LSF_SKEW_WIDE == 2 || (LSF_SKEW_WIDE == 1 && BY == 16)) && deep && X0 - (NYT + NZT + 4) >= 0 && X0 + 22 <= nxi - 1 &&
+    const bool widex = TA == 16 && (LSF_SKEW_WIDE == 2 || (LSF_SKEW_WIDE == 1 && BY == 16)) && deep && X0 - (NYT + NZT + 4) >= 0 && X0 + 22 <= nxi - 1 &&
                        sk_wide_image_fits(sxy, NZT);
     bool loaded = true;
     auto load_wide = [&]() {
@@ -514,9 +515,10 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         // property of the instruction (the class boundaries are not multiples of 4 W rows: the last instruction of a
         // class re-loads its last row in the lanes that would overshoot, which rewrites the same LDS value).
         constexpr int RPI = 4 * W;                                        // rows per load instruction
-        constexpr int NB = T::NCORE / RPI;                                // bundle rows: entries 3..18, old values
-        constexpr int NU = (T::YD0 - T::YU0 + RPI - 1) / RPI;             // upstream halo: 2..17, this sweep's inside the interior
-        constexpr int ND = (T::NR - T::YD0 + RPI - 1) / RPI;              // downstream halo: 4..19, old values
+        // (TA = 32: every class twice, the second time 16 entries further -- u counts (row group, 16-entry piece) pairs)
+        constexpr int NB = T::NCORE / RPI * CPN;                          // bundle rows: entries 3..18, old values
+        constexpr int NU = (T::YD0 - T::YU0 + RPI - 1) / RPI * CPN;       // upstream halo: 2..17, this sweep's inside the interior
+        constexpr int ND = (T::NR - T::YD0 + RPI - 1) / RPI * CPN;        // downstream halo: 4..19, old values
         // the remaining entries: 0..2 (this sweep's) and 19..21 (old) of the bundle rows, 0..1 of
         // the upstream and 20..21 of the downstream halo rows
         constexpr int XC = 3 * T::NCORE, XHU = 2 * (T::YD0 - T::NCORE), XHD = 2 * (T::NR - T::YD0);
@@ -531,14 +533,14 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         // ---- stage 1: what the previous sweep left
 #pragma unroll
         for (int u = 0; u < NB; ++u, ++n_) {
-            const int r = RPI * u + rsub, k = 3 + xx;
+            const int r = RPI * (u / CPN) + rsub, k = 3 + xx + 16 * (u % CPN);
             const int2 e = rowtab[r];
             dst[n_] = T::core_at(r) + k;
             v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
         }
 #pragma unroll
         for (int u = 0; u < ND; ++u, ++n_) {
-            const int r = min(T::YD0 + RPI * u + rsub, T::NR - 1), k = 4 + xx;
+            const int r = min(T::YD0 + RPI * (u / CPN) + rsub, T::NR - 1), k = 4 + xx + 16 * (u % CPN);
             const int2 e = rowtab[r];
             dst[n_] = T::HB + (r - T::NCORE) * T::RH + k - 4;
             v[n_] = ldp(in_t + off_of(e, gi_of(e, k)));
@@ -572,7 +574,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         // ---- stage 2: what the upstream tiles of this sweep wrote (rows or entries outside the interior: the walls, from `in`)
 #pragma unroll
         for (int u = 0; u < NU; ++u, ++n_) {
-            const int r = min(T::YU0 + RPI * u + rsub, T::YD0 - 1), k = 2 + xx;
+            const int r = min(T::YU0 + RPI * (u / CPN) + rsub, T::YD0 - 1), k = 2 + xx + 16 * (u % CPN);
             const int2 e = rowtab[r];
             const int gi_r = gi_of(e, k);
             const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 1);
@@ -714,7 +716,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     // tiles along the walls are the first of every hyperplane.  Now: wall points first (chunks of rows, all old values of a chunk
     // in flight together, wavefronts without wall points skip), then the cells.  At 256^3, where a sweep is bound by the latency
     // of its dependency chains: 0.725 -> 0.65 ms per sweep; the summation order of the RMS is unchanged.
-    constexpr int NUW = T::NCORE / (4 * W);        // row iterations of a lane
+    constexpr int NUW = T::NCORE / (4 * W) * CPN;  // (row group, 16-entry piece) pairs of a lane
 #ifndef LSF_WB_CHUNK
 #define LSF_WB_CHUNK 3
 #endif
@@ -730,10 +732,10 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     };
     auto wb_row_e = [&](int u, int2 e_) {
         WbRow w;
-        const int r = 4 * W * u + (tid >> 4);
+        const int r = 4 * W * (u / CPN) + (tid >> 4);
         w.cq = r / NYT;
         const int bq = r - NYT * w.cq;
-        w.t = tid & 15;
+        w.t = (tid & 15) + 16 * (u % CPN);
         w.e = e_;
         w.gi = w.e.y + (si > 0 ? w.t : -w.t);
         w.mine = bq < nj && w.cq < nk && (unsigned)(w.gi - 1) <= (unsigned)(nx - 2);
@@ -743,7 +745,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         w.ak = w.gk2 == 1 ? -1 : (w.gk2 == nz - 1 ? 1 : 0);
         return w;
     };
-    auto wb_row = [&](int u) { return wb_row_e(u, rowtab[4 * W * u + (tid >> 4)]); };
+    auto wb_row = [&](int u) { return wb_row_e(u, rowtab[4 * W * (u / CPN) + (tid >> 4)]); };
     auto sub_on = [](const WbRow& w, int sub) { return !(((sub & 1) && !w.ai) || ((sub & 2) && !w.aj) || ((sub & 4) && !w.ak)); };
     // 1. the wall points, chunk by chunk -- only loads are outstanding when a chunk waits for its old values, and a wavefront
     //    without wall points (most wavefronts of a tile at a wall) passes without waiting at all
@@ -772,7 +774,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
                 if (u >= NUW) break;
                 const WbRow w = wb_row(u);
                 if (!(w.mine && (w.ai | w.aj | w.ak))) continue;
-                const double val0 = lds[T::core_at(4 * W * u + (tid >> 4)) + 3 + w.t];
+                const double val0 = lds[T::core_at(4 * W * (u / CPN) + (tid >> 4)) + 3 + w.t];
 #pragma unroll
                 for (int sub = 1; sub < 8; ++sub) {
                     if (!sub_on(w, sub)) continue;
@@ -809,8 +811,8 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     double v_wb[NUW];
 #pragma unroll
     for (int u = 0; u < NUW; ++u) {
-        e_wb[u] = rowtab[4 * W * u + (tid >> 4)];
-        v_wb[u] = lds[T::core_at(4 * W * u + (tid >> 4)) + 3 + (tid & 15)];
+        e_wb[u] = rowtab[4 * W * (u / CPN) + (tid >> 4)];
+        v_wb[u] = lds[T::core_at(4 * W * (u / CPN) + (tid >> 4)) + 3 + (tid & 15) + 16 * (u % CPN)];
     }
 #pragma unroll
     for (int u = 0; u < NUW; ++u) asm volatile("" : "+v"(e_wb[u].x), "+v"(e_wb[u].y), "+v"(v_wb[u]));
@@ -946,7 +948,7 @@ static __global__ __launch_bounds__(256) void k_build_order(uint2* __restrict__ 
 
 // Slot schedule: one launch per time slot, one block per tile of the slot (dependencies resolved by launch order).
 template <int TA, int WY, int WZ, int BY, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : LSF_WAVES16) : (WY == 2 && WZ == 2 ? 5 : 1)))) void k_reinit_gs_skew(GsArgs a)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : LSF_WAVES16) : (WY == 2 && WZ == 2 ? (TA == 32 ? 2 : 5) : 1)))) void k_reinit_gs_skew(GsArgs a)
 {
     const int bx = (int)blockIdx.x;
     const int seg = (bx >= a.seg_end[0]) + (bx >= a.seg_end[1]) + (bx >= a.seg_end[2]);
@@ -988,7 +990,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
 // time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
 // plane_cnt[s][P]; the last tile of a hyperplane publishes planes_done[s] = P + 1.
 template <int TA, int WY, int WZ, int BY, bool STRICT>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : LSF_WAVES16) : (WY == 2 && WZ == 2 ? (STRICT ? LSF_STRICT22_WAVES : 5) : 1)))) void k_reinit_gs_persist(GsArgs a)
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : LSF_WAVES16) : (WY == 2 && WZ == 2 ? (TA == 32 ? 2 : (STRICT ? LSF_STRICT22_WAVES : 5)) : 1)))) void k_reinit_gs_persist(GsArgs a)
 {
     using T = SkTile<TA, WY, WZ, BY>;
     __shared__ SkShared<T> sm;

@@ -42,8 +42,9 @@
 !                               ! 'fast' (same mathematics restructured for the GPU, 2 x faster, ~1e-16 per sweep away;
 !                               !   see DESIGN.md section 2 for what that becomes over thousands of sweeps)
 !     devices = 0, 1, 2, 3      ! reinit runs on these GPUs (lsf_reinit_multi; a device may be listed more than once):
-!                               !   order = 'jacobi': block-decomposed, one block each; order = 'gs': ONE GPU (the first
-!                               !   listed) unless `slabs = 1`; unset: one GPU
+!                               !   order = 'jacobi': block-decomposed, one block each; order = 'gs': ONE GPU -- the process'
+!                               !   current device, where the other seams keep their arrays, not the first listed --
+!                               !   unless `slabs = 1`; unset: one GPU
 !     slabs = 0                 ! 1: with order = 'gs', the reference's ordering over one z slab per listed device, the
 !                               !   field of one GPU bit for bit (lsf_reinit_multi with LSF_ORDER_GS).  Opt-in: the path
 !                               !   has not run on two real devices yet; on first use every pair of neighbouring devices

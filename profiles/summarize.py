@@ -57,7 +57,7 @@ def jacobi_kernel_name(mode="jacobi"):
     return plain
 
 
-for mode, kern in (("gs", gs_kernel_name()), ("jacobi", jacobi_kernel_name()), ("f32", jacobi_kernel_name("f32")), ("mm", "k_minmax_fp")):
+for mode, kern in (("gs", gs_kernel_name()), ("jacobi", jacobi_kernel_name()), ("f32", jacobi_kernel_name("f32")), ("mm", "k_minmax_")):  # every kernel of a min/max iteration: band executor since round 5 (k_minmax_band*), dense k_minmax_fp<*> before
     entry = {}
     bytes_per_cell = 12.0 if mode == "f32" else 24.0
     sweeps = 17.0 if mode == "mm" else SWEEPS  # mm_time.py: 1 + 16 iterations

@@ -434,9 +434,9 @@ def test_minmax_tile_wavefront_path(lsf, oracle, cube40, monkeypatch):
 
 def test_minmax_uncertified_iteration_falls_back_to_the_dense_executor(lsf, oracle, cube40, monkeypatch, capfd):
     """The band executor runs every fix pass after the first inside one resident launch that loops until a pass changes nothing (up
-    to 62 passes).  LSF_MINMAX_TAIL_MAX=1 leaves it one pass: an iteration it cannot certify ends the attempt with nothing written,
+    to 62 passes).  LSF_MINMAX_TAIL_MAX=0 leaves it none: an iteration it cannot certify ends the attempt with nothing written,
     and the call is run by the dense executor; the result must not change."""
-    monkeypatch.setenv("LSF_MINMAX_TAIL_MAX", "1")
+    monkeypatch.setenv("LSF_MINMAX_TAIL_MAX", "0")
     monkeypatch.setenv("LSF_MINMAX_BAND_MAX", "100")
     monkeypatch.setenv("LSF_TRACE", "1")
     nx, ny, nz = _n(cube40)
@@ -627,6 +627,18 @@ def test_peer_selftest_on_one_device(lsf):
     assert pkg.peer_selftest(0, 0) == 0
     with pytest.raises(pkg.LsfError, match="out of range"):
         pkg.peer_selftest(0, 99)
+
+
+def test_peer_selftest_time_out_names_assumption_4(lsf, monkeypatch):
+    """its spins are bounded by a hook of their own (LSF_PEER_TIMEOUT_TICKS): with 0 ticks neither side sees the other in time and the
+    call ends with LSF_ERR_HIP naming assumption (4) -- not a hang, and the next call works"""
+    import levelsetfortran_amd as pkg
+
+    monkeypatch.setenv("LSF_PEER_TIMEOUT_TICKS", "0")
+    with pytest.raises(pkg.LsfError, match=r"\(4\)"):
+        pkg.peer_selftest(0, 0)
+    monkeypatch.delenv("LSF_PEER_TIMEOUT_TICKS")
+    assert pkg.peer_selftest(0, 0) == 0
 
 
 @pytest.mark.parametrize("march,nbuf", [("x", "3"), ("x", "4"), ("y", "3"), ("y", "4")])
