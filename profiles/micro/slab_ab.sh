@@ -1,6 +1,6 @@
 #!/bin/bash
 # one box: the slab launch (profiles/micro/slab_bench.py) with experiment builds build/exp/liblsf_<name>.so against the product
-# library.  How the write back of the wall tiles was found: with -DLSF_EXPERIMENTS builds that
+# library.  How the write back of the wall tiles was found (DESIGN_HISTORY.md section 4.1 item 6): with -DLSF_EXPERIMENTS builds that
 # launched k_reinit_gs_persist around skew_tile<PUSH> on the one-slab launch's buffers and switched the parts of PUSH off one at
 # a time (commits 6d97f0c..fadb6da carry those switches; they are gone from the sources now).
 for L in ${LIBS:-prod}; do
