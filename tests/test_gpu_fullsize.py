@@ -167,3 +167,46 @@ def test_dataflow_launch_equals_slot_launches_over_many_sweeps(arith, monkeypatc
     # the dataflow launch sums the squared changes by tile columns of the x <-> y transposed field, the slot launches by
     # tile columns of the field as it is: same values, different (fixed) orders of the additions
     assert np.allclose(res["dataflow"][2], res["skew"][2], rtol=1e-12, atol=0)
+
+
+def test_minmax_band_executor_equals_the_dense_executor_at_1024_cubed(monkeypatch):
+    """The min/max flow on the narrow band (compact arrays, 32-bit point indices and brick keys, a list of ~6 M cells) against the
+    dense executor on a 1024^3 field -- 2^30 points, the largest cubic grid whose indices the band executor's 32-bit lists hold with
+    room to spare: field and both masks bit for bit after 6 iterations of the exact ordering and of the Jacobi ordering."""
+    import torch
+
+    import levelsetfortran_amd as lsf
+    from levelsetfortran_amd import fields
+
+    N = 1024
+    dev = torch.device("cuda", 0)
+    x, y, z, dx = fields.grid_axes((N, N, N))
+    ax = torch.from_numpy(x).to(dev)
+    sdf = torch.empty((N, N, N), dtype=torch.float64, device=dev)  # [k][j][i]
+    for k0 in range(0, N, 64):
+        zz = ax[k0:k0 + 64]
+        d = None
+        for c in ((-0.6, 0.0, 0.0), (0.6, 0.0, 0.0)):
+            r = ((zz[:, None, None] - c[2]) ** 2 + (ax[None, :, None] - c[1]) ** 2 + (ax[None, None, :] - c[0]) ** 2).sqrt_().sub_(0.5)
+            d = r if d is None else torch.minimum(d, r)
+        sdf[k0:k0 + 64] = d
+    del d, r
+    sdf = sdf.reshape(-1)
+    h1 = 0.1 * fields.reinit_step(dx)
+    for order in ("gs", "jacobi"):
+        res = {}
+        for dense in ("0", "1"):
+            monkeypatch.setenv("LSF_MINMAX_DENSE", dense)
+            f = sdf.clone()
+            nb = torch.zeros(f.numel(), dtype=torch.int32, device=dev)
+            sb = torch.zeros_like(nb)
+            lsf.narrowBand(N - 1, N - 1, N - 1, dx, f, nb, sb)
+            rep = lsf.minmaxFlow(f, nb, sb, N - 1, N - 1, N - 1, 6, dx, h1, tol=0.0, order=order)
+            assert rep.count == 6
+            res[dense] = (f, nb, sb, np.array(rep.rms))
+        for q in range(3):
+            assert torch.equal(res["0"][q], res["1"][q]), (order, q)
+        assert np.allclose(res["0"][3], res["1"][3], rtol=1e-9, atol=0)
+        del res
+        torch.cuda.empty_cache()
+    lsf._lib.load().lsf_release_workspace()
