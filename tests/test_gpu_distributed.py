@@ -120,6 +120,11 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     cells_rep = 2 * 4 * 94.0 ** 3
     assert abs(rep["value"] * rep["ms_per_step"] * 1e-3 * 4 - cells_rep) < 1e-6 * cells_rep and "replicas" in rep["note"]
     assert d["same_path_one_gpu"]["value"] > 0
+    # what was computed from the replicas' timing sits with the replicas; the headline's VALU roofline is its own:
+    # per GPU, from the decomposed Jacobi value, with the Jacobi ordering's operation count
+    v = d["roofline_fp64_valu"]
+    assert v["useful_ops_per_cell"] == 259.0 and abs(v["achieved"] - 505.0 * d["value"] / 2 / 1e12) < 1e-9 * v["achieved"]
+    assert rep["roofline_fp64_valu"]["useful_ops_per_cell"] == 313.0 and "step_breakdown_ms" in rep and "step_breakdown_ms" not in d
     strong = [e for e in ent if e["scaling"] == "strong"]
     assert len(weak) == 1 and weak[0]["value"] > 0 and weak[0]["global_grid"] == [96, 96, 192] and weak[0]["dims"] == [1, 1, 2]
     # fixed global grid split over the ranks: non-cubic local blocks (48 owned + 3 ghost points along z, the axis two
