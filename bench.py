@@ -56,16 +56,19 @@ BYTES_PER_CELL_UPDATE = 24.0  # read phi, read phiS, write phi (SURVEY.md sectio
 # CPU baseline worker (separate process: the Fortran runtime of the reference prints one line per
 # sweep on stdout, which must not reach the JSON line)
 # ------------------------------------------------------------------------------------------------
+# the device code of the sweep kernels whose counters profiles/traffic.json holds (host-side files do not change a kernel instance)
+KERNEL_SOURCES = ("lsf_cell.hpp", "lsf_kernels.hpp", "lsf_boxtile.hpp", "lsf_skew.hpp", "lsf_f32.hpp")
+
+
 def kernel_sources_fingerprint():
-    """sha256 (16 hex digits) of the library's kernel sources as they lie in the tree: profiles/ships_summarize.py stamps the counters it
-    condenses with it, and the counters are attached to a bench line only while the sources are the ones they were measured on"""
-    import glob
+    """sha256 (16 hex digits) of the sweep kernels' sources as they lie in the tree: profiles/ships_summarize.py stamps the counters it
+    condenses with it, and the counters are attached to a bench line only while those sources are the ones they were measured on"""
     import hashlib
 
     hsh = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "levelsetfortran_amd", "csrc", "*.h*"))):
-        hsh.update(os.path.basename(f).encode())
-        hsh.update(open(f, "rb").read())
+    for name in KERNEL_SOURCES:
+        hsh.update(name.encode())
+        hsh.update(open(os.path.join(ROOT, "levelsetfortran_amd", "csrc", name), "rb").read())
     return hsh.hexdigest()[:16]
 
 

@@ -168,7 +168,7 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
 // The min/max flow on the narrow band only (lsf_minmax_band.hpp): the list of cells that can ever be in the band is built once
 // per call and the flow runs on compact arrays; the field is written once, at the end.  Both orderings (the Jacobi ordering is
 // the start pass and the RMS pass alone).  *dense = true: not run (band above a quarter of the grid, no band cell at all, a
-// field beyond 32-bit point indices, or an iteration that 32 fix passes did not certify -- never observed) and phi, the masks
+// field beyond 32-bit point indices or brick keys, or an iteration that 62 fix passes did not certify -- never observed) and phi, the masks
 // untouched: the caller takes the dense executors.
 int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int nz, int iter, double dx, double h1, double tol,
                      int mode, int* iters_done, double* rms_trace, int trace_cap, hipStream_t st, bool* dense)
