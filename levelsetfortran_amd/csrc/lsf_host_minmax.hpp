@@ -222,6 +222,7 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     a.curv = (double*)c.slot[S_MB_A0].p, a.down = a.curv + nL;
     a.nL = nL, a.sx = nx + 1, a.sxy = (long)(nx + 1) * (ny + 1), a.dx = dx, a.h1 = h1;
     a.chunkflag = (int*)c.slot[S_BFLAG].p, a.stamp = (int*)c.slot[S_STAMP].p, a.nchunks = nchunks, a.partials = part, a.ctl = ctl;
+    a.chg = chg;
     const dim3 b256(256), gl((unsigned)nchunks), ge((unsigned)cdiv(nL, 256));
     {
         // the list in memory order and its brick keys -> sorted by key (both pairs of arrays live in the staging buffer's tail and in
@@ -262,7 +263,6 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     };
     // Exact ordering: the first fix pass as a wide launch over every band chunk, every further pass inside one small resident
     // launch that loops until a pass changes nothing (k_minmax_band_tail).  Epochs of iteration it: it * MB_EPOCHS + 1 + pass.
-    constexpr int MB_EPOCHS = 64;
     int tail_max = MB_EPOCHS - 2;
     if (const char* e = getenv("LSF_MINMAX_TAIL_MAX")) tail_max = std::min(tail_max, std::max(0, atoi(e))); // test hook: too few passes (0: no certifying pass at all)
     int* bar = chg + MB_EPOCHS; // barrier word of the tail launch, behind its per-pass change counts
@@ -272,7 +272,6 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
         hipLaunchKernelGGL((k_minmax_band<0>), gl, b256, 0, st, q);
         if (gs) {
             const int epoch0 = it * MB_EPOCHS + 1;
-            (void)hipMemsetAsync(chg, 0, (MB_EPOCHS + 1) * sizeof(int), st);
             hipLaunchKernelGGL(k_minmax_band_fix, gl, b256, 0, st, q, epoch0, chg);
             hipLaunchKernelGGL(k_minmax_band_tail, dim3(MB_TAIL_BLOCKS), b256, 0, st, q, epoch0 + 1, tail_max, (const int*)chg, chg + 1, bar,
                                200000000ull);

@@ -188,7 +188,9 @@ struct MbArgs {
     int nchunks;
     double* partials;      // [nchunks]
     int* ctl;              // [0] stop, [1] iterations done, [2] NaN, [3] an iteration was not certified, [4] most fix passes that changed cells
+    int* chg;              // [64] chunks changed per fix pass of the iteration | [64] barrier word of the looping launch
 };
+constexpr int MB_EPOCHS = 64; // fix passes an iteration can take (epochs of iteration it: it * MB_EPOCHS + 1 + pass)
 
 // PASS 0: Jacobi start, band test, per-chunk band flags, the frozen data of the fix passes (one chunk per block).
 // PASS 2: RMS partials per chunk (one chunk per block).
@@ -197,6 +199,10 @@ __global__ __launch_bounds__(256) void k_minmax_band(MbArgs a)
 {
     __shared__ double red[4];
     if (a.ctl[0] | a.ctl[3]) return;
+    // (pass 0 also zeroes the iteration's change counts and barrier word: no memset command between the launches.  The block that
+    // finishes pass 2 last could add the partials and apply the stop test as well -- built and measured: 5 800 blocks counting
+    // themselves on ONE word cost 60 us per iteration on this chip, three times what the separate launch of k_mb_finish costs)
+    if (PASS == 0 && blockIdx.x == 0 && threadIdx.x <= MB_EPOCHS) a.chg[threadIdx.x] = 0;
     const int chunk = blockIdx.x, e = chunk * MB_CH + threadIdx.x;
     const int nL = a.nL;
     double acc = 0.0;
