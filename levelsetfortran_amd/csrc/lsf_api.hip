@@ -439,13 +439,14 @@ int check_dims(int nx, int ny, int nz)
 
 // ---------------------------------------------------------------------------------------------
 // One fp64 Jacobi sweep over the cells [lo, hi) of a box: picks the kernel and its launch geometry.
-//   STRICT            k_reinit_jacobi<true>  (per-cell arithmetic of the reference)
+//   STRICT            k_reinit_jacobi_strict_sh (the reference's arithmetic, every difference evaluated once per point);
+//                     k_reinit_jacobi<true> (per cell) with LSF_JAC_SH = 0
 //   FAST              k_reinit_jacobi_sh<WX, BY> (WENO interfaces shared along x and z); WX = wavefronts a block
 //                     spans along x, chosen so that the 64 WX - 1 cells of a block tile the row with the fewest wavefronts
 //   3-cell x rims     k_reinit_jacobi<., true> (lanes along y)
 // LSF_JAC_SH = 0 forces the per-cell kernel, "WXxBY" a block shape (measurement aids; all FAST choices are bit-identical).
 struct JacPlan {
-    int kind = 0; // 0 per-cell kernel, 1 per-cell THINX, 2 shared-interface kernel
+    int kind = 0; // 0 per-cell kernel, 1 per-cell THINX, 2 shared-interface kernel (FAST), 3 shared-difference kernel (STRICT)
     dim3 grid;
     int wx = 1, by = 4, nbx = 0, nby = 0, nbz = 0;
     int kc = JAC_KC; // planes a block marches: JAC_KC, halved while a thin region (a rim of a decomposed sweep) would leave CUs idle
@@ -468,6 +469,14 @@ JacPlan jacobi_plan(const int lo[3], const int hi[3], bool strict)
     int fwx = 0, fby = 0;
     const bool off = env && env[0] == '0' && env[1] == 0;
     if (env && !off && sscanf(env, "%dx%d", &fwx, &fby) != 2) fwx = fby = 0;
+    if (strict && !thinx && !off) {
+        p.kind = 3;
+        const int gx = cdiv(cx, JSS_PX * JSS_WX), gy = cdiv(cy, JSS_PY * JSS_WY);
+        p.kc = jacobi_kc((long)gx * gy, cz);
+        p.grid = dim3(gx, gy, cdiv(cz, p.kc));
+        p.nparts = (long)p.grid.x * p.grid.y * p.grid.z;
+        return p;
+    }
     if (strict || thinx || off) {
         p.kind = thinx ? 1 : 0;
         const long cols = thinx ? (long)cdiv(cy, JAC_BX) * cdiv(cx, JAC_BY) : (long)cdiv(cx, JAC_BX) * cdiv(cy, JAC_BY);
@@ -502,7 +511,10 @@ void jacobi_launch(const JacPlan& p, bool strict, const double* A, double* B, co
 #define LSF_JAC_SH(WX_, BY_)                                                                                                   \
     hipLaunchKernelGGL((k_reinit_jacobi_sh<WX_, BY_>), p.grid, dim3(64 * WX_ * BY_), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], \
                        hi[0], hi[1], hi[2], dx, h, part, done, p.nbx, p.nby, p.nbz, p.kc)
-    if (p.kind == 2) {
+    if (p.kind == 3) {
+        hipLaunchKernelGGL(k_reinit_jacobi_strict_sh, p.grid, dim3(64 * JSS_WX * JSS_WY), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], hi[0],
+                           hi[1], hi[2], dx, h, part, done, p.kc);
+    } else if (p.kind == 2) {
         const int sh = p.wx * 16 + p.by;
         if (sh == 0x14) LSF_JAC_SH(1, 4);
         else if (sh == 0x22) LSF_JAC_SH(2, 2);
@@ -651,6 +663,7 @@ int jacobi_loop(T* d_phi, const T* d_phiS_in, int nx, int ny, int nz, int iter, 
     g_prof.sweep_launches = g_prof.sweeps;
     if (jp.kind == 2 && F32) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "k_reinit_jacobi_f32_sh<%d>", jp.wx);
     else if (jp.kind == 2) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "k_reinit_jacobi_sh<%d,%d>", jp.wx, jp.by);
+    else if (jp.kind == 3) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "k_reinit_jacobi_strict_sh");
     else snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, F32 ? "k_reinit_jacobi_f32<%s>" : (strict ? "k_reinit_jacobi<true,%s>" : "k_reinit_jacobi<false,%s>"), jp.kind == 1 ? "true" : "false");
     g_prof.kernel = g_prof.kernel_buf;
     if (bufs[nsw & 1] != d_phi)

@@ -123,8 +123,11 @@ __device__ __forceinline__ void weno_from_diffs_strict(const WenoDiffs& d, doubl
     const double IS2p = T1m + 3. * (3. * cp - dpp) * (3. * cp - dpp);
     const double IS2m = T1p + 3. * (3. * cm - dmm) * (3. * cm - dmm);
 
-    const double epsp = (1.E-6) * smax(d.s[1], smax(d.s[2], smax(d.s[3], smax(d.s[4], d.s[5])))) + 1.E-99;
-    const double epsm = (1.E-6) * smax(d.s[0], smax(d.s[1], smax(d.s[2], smax(d.s[3], d.s[4])))) + 1.E-99;
+    // the largest of five squares on either side (subs.f90:533-534): four of them are common to the two sides, and the largest
+    // element of a set does not depend on the order it is searched in -- five maxima instead of eight
+    const double smid = smax(smax(d.s[1], d.s[2]), smax(d.s[3], d.s[4]));
+    const double epsp = (1.E-6) * smax(smid, d.s[5]) + 1.E-99;
+    const double epsm = (1.E-6) * smax(d.s[0], smid) + 1.E-99;
 
     const double x0p = (epsp + IS0p) * (epsp + IS0p), x0m = (epsm + IS0m) * (epsm + IS0m);
     const double x1p = (epsp + IS1p) * (epsp + IS1p), x1m = (epsm + IS1m) * (epsm + IS1m);

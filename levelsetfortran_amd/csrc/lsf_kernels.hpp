@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "lsf_cell.hpp"
 
@@ -212,6 +213,253 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi
     if (tid == 0) {
         double t = 0.0;
         for (int w = 0; w < JAC_BX * JAC_BY / 64; ++w) t += red[w];
+        partials[blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)] = t;
+    }
+}
+
+// =============================================================================================
+// Reinit, Jacobi ordering, STRICT arithmetic, every difference of subs.f90:509-513 / :525-530 evaluated ONCE per point.
+// Along an axis the five second and six first differences of a cell are one formula at several offsets (lsf_cell.hpp,
+// WenoDiffs): X(j), its mirror image Y(j) and P(j).  In the Jacobi ordering all inputs are the previous sweep's, so the
+// value a neighbour computes IS the double this cell would compute -- sharing keeps the bits.
+//   z (march axis): carried in registers; the march loop is unrolled six times so that the windows (6 field values, 6 P, 6 P^2,
+//                   3 X, 2 Y) rotate by renaming, without a move.  Per cell: one X, one Y, one P, one square.
+//   x, y:           a wavefront owns a patch of 16 x 4 columns.  Every lane evaluates X, Y, P, P^2 of its own point along x and
+//                   along y and puts them into the wavefront's part of LDS; the points the patch's cells reach beyond its edge
+//                   (x: 9 per row, y: 8 per column -- 164 values) are evaluated by three "edge jobs", one value per lane and job
+//                   (operands by their own loads).  Then every lane reads the 14 + 12 differences of its neighbours.  LDS
+//                   is private to a wavefront here: its LDS operations complete in order, no barrier.
+// (p5 = 0 of the y axis, subs.f90:576, is the constant it evaluates to.)
+// 189 -> 78 instructions per cell for the differences; the rest of a cell (weno_from_diffs_strict, Godunov, Euler) is
+// k_reinit_jacobi<true>'s, hence the same doubles.  The per-cell kernel stays for the 3-cell x rims (THINX).
+// =============================================================================================
+constexpr int JSS_PX = 16, JSS_PY = 4;            // a wavefront's patch of columns
+constexpr int JSS_WX = 2, JSS_WY = 2;             // patches of a block: 32 x 8 columns, 256 threads
+constexpr int JSS_XP = JSS_PX + 5;                // x arrays: points i0-3 .. i0+17 of a row
+constexpr int JSS_XN = JSS_XP * JSS_PY;
+constexpr int JSS_YR = JSS_PY + 5;                // y arrays: rows j0-3 .. j0+5
+constexpr int JSS_YN = JSS_YR * JSS_PX;
+constexpr int JSS_WAVE = 4 * JSS_XN + 4 * JSS_YN; // doubles of LDS per wavefront: P, P^2, X, Y along x, then along y
+__global__ __launch_bounds__(64 * JSS_WX * JSS_WY) void k_reinit_jacobi_strict_sh(const double* __restrict__ A, double* __restrict__ Bout,
+                                                                                 const double* __restrict__ phiS, Box bx, int lo0, int lo1,
+                                                                                 int lo2, int hi0, int hi1, int hi2, double dx, double h,
+                                                                                 double* __restrict__ partials, const int* __restrict__ done,
+                                                                                 int kc)
+{
+#pragma clang fp contract(off)
+    __shared__ double red[JSS_WX * JSS_WY];
+    __shared__ double lds[JSS_WX * JSS_WY * JSS_WAVE];
+    if (done && *done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lx = lane & (JSS_PX - 1), ly = lane / JSS_PX;
+    const int i0 = lo0 + ((int)blockIdx.x * JSS_WX + (wave % JSS_WX)) * JSS_PX; // the patch's first column
+    const int j0 = lo1 + ((int)blockIdx.y * JSS_WY + (wave / JSS_WX)) * JSS_PY;
+    const int li = i0 + lx, lj = j0 + ly;
+    const int k0 = lo2 + blockIdx.z * kc, k1 = min(k0 + kc, hi2);
+    const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
+    const bool cell = li < hi0 && lj < hi1; // lanes beyond the region still evaluate the differences their neighbours read (hi <= l - 1)
+    const int gi = li + bx.gx0, gj = lj + bx.gy0;
+    const bool ij_weno = gi > 3 && gi < bx.nx - 4 && gj > 3 && gj < bx.ny - 4;
+    const double rdx = recip_refined(dx);
+    // addressing as in k_reinit_jacobi: one buffer descriptor per k-plane, starting 3 doubles early, + 32-bit byte offsets; what
+    // lies outside a plane reads as zero, and only differences no cell of the launch consumes are made of such values (a
+    // cell reaches 3 points when it takes the WENO branch, 1 otherwise, and those exist)
+    // Every offset handed to a load is INSIDE its plane by construction (the descriptor's range check is a second line only): a
+    // lane or an edge job whose operands are not all points of the array reads around point (1, 1) instead.
+    const unsigned plane_bytes = 8u * (unsigned)sxy, rowb = 8u * (unsigned)sx;
+    const unsigned safe = 24u + 8u + rowb;
+    auto inside = [&](int x, int y) { return x >= 1 && x <= bx.lx - 2 && y >= 1 && y <= bx.ly - 2; }; // the point and its four neighbours exist
+    const unsigned col = inside(li, lj) ? 24u + 8u * (unsigned)(li + sx * lj) : safe;
+    auto desc = [&](const double* base) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base) - 3, 0, (int)(plane_bytes + 48u), 0x00020000);
+    };
+    auto at = [](__amdgpu_buffer_rsrc_t r, unsigned boff) -> double {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, boff, 0, 0);
+        return __hiloint2double((int)v.y, (int)v.x);
+    };
+    auto ldz = [&](int k) -> double {
+        const int kk = k < 0 ? 0 : (k > bx.lz - 1 ? bx.lz - 1 : k);
+        return at(desc(A + sxy * kk), col);
+    };
+    double* const w = lds + wave * JSS_WAVE;
+    double* const wxo = w + ly * JSS_XP + lx + 3;              // the lane's own entry of an x array (arrays JSS_XN apart)
+    double* const wyo = w + 4 * JSS_XN + (ly + 3) * JSS_PX + lx; // ... of a y array (JSS_YN apart)
+
+    // edge jobs: kind 0 = P, 1 = X, 2 = Y; mid point offset, far = mid + s, near = mid + q; destination in LDS
+    // (a P reads two points: its third operand is loaded from the middle one and dropped)
+    auto job_mid = [&](int x, int y, long far, long near) {
+        const long m = 24 + 8 * ((long)x + sx * (long)y), lo = m + (far < near ? far : near), hi = m + (far < near ? near : far);
+        return lo >= 0 && hi <= (long)plane_bytes + 40 ? (unsigned)m : safe;
+    };
+    unsigned jm[3], js[3], jq[3];
+    double* jd[3];
+    bool jp[3], jon[3];
+    {
+        // x edges, 9 per row: P(-3) P(-2) P(-1) P(16) P(17) X(16) X(17) Y(-2) Y(-1)
+        const int r = lane / 9, e = lane % 9;
+        const int ex = e < 3 ? e - 3 : (e < 5 ? e + 13 : (e < 7 ? e + 11 : e - 9));
+        const int kind = e < 5 ? 0 : (e < 7 ? 1 : 2);
+        jon[0] = lane < 9 * JSS_PY;
+        jp[0] = kind == 0;
+        js[0] = kind == 2 ? 0u - 8u : 8u;
+        jq[0] = kind == 0 ? 0u : 0u - js[0];
+        jm[0] = job_mid(i0 + ex, j0 + r, (int)js[0], (int)jq[0]);
+        jd[0] = w + (kind == 0 ? 0 : kind + 1) * JSS_XN + (jon[0] ? r : 0) * JSS_XP + ex + 3;
+    }
+#pragma unroll
+    for (int t = 1; t < 3; ++t) {
+        // y edges, 8 per column: P(-3) P(-2) P(-1) P(4) X(4) X(5) Y(-2) Y(-1)
+        const int id = (t - 1) * 64 + lane, c = id & (JSS_PX - 1), e = id / JSS_PX;
+        const int ey = e < 3 ? e - 3 : (e == 3 ? 4 : (e < 6 ? e : e - 8));
+        const int kind = e < 4 ? 0 : (e < 6 ? 1 : 2);
+        jon[t] = true;
+        jp[t] = kind == 0;
+        js[t] = kind == 2 ? 0u - rowb : rowb;
+        jq[t] = kind == 0 ? 0u : 0u - js[t];
+        jm[t] = job_mid(i0 + c, j0 + ey, (int)js[t], (int)jq[t]);
+        jd[t] = w + 4 * JSS_XN + (kind == 0 ? 0 : kind + 1) * JSS_YN + (ey + 3) * JSS_PX + c;
+    }
+
+    // march-axis windows; slot of an entry = its plane index relative to k0, modulo the window length
+    double W[6], Pz[6], Sz[6], Xz[3], Yz[2], Tz;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) W[m] = ldz(k0 + (m < 3 ? m : m - 6)); // planes k0-3 .. k0+2; slot 3 = plane k0-3 until step 0 loads k0+3
+#pragma unroll
+    for (int m = 0; m < 5; ++m) { // P(k0-3) .. P(k0+1) -> slots 0 .. 4
+        Pz[m] = weno_P(W[(m + 4) % 6], W[(m + 3) % 6], dx, rdx);
+        Sz[m] = Pz[m] * Pz[m];
+    }
+    Pz[5] = Sz[5] = 0.0;
+    Xz[0] = weno_X(W[1], W[0], W[5], dx, rdx); // X(k0), X(k0+1)
+    Xz[1] = weno_X(W[2], W[1], W[0], dx, rdx);
+    Xz[2] = 0.0;
+    Yz[0] = weno_X(W[3], W[4], W[5], dx, rdx); // Y(k0-2); slot 1 = Y(k0-1) comes with step 0
+    Yz[1] = 0.0;
+    Tz = 13. * (Xz[1] - Xz[0]) * (Xz[1] - Xz[0]);
+
+    double acc = 0.0;
+    double qnext = ldz(k0 + 3); // the march-axis value one step ahead of its use
+    auto step = [&](auto phc, int k) __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+        constexpr int PH = decltype(phc)::value;
+        const auto PA = desc(A + sxy * k);
+        // loads of this step; the z axis, which needs none of them, is evaluated while they are in flight
+        const double qn = qnext;
+        qnext = ldz(k + 4);
+        const double xm = at(PA, col - 8u), xp = at(PA, col + 8u), ym = at(PA, col - rowb), yp = at(PA, col + rowb);
+        double jf[3], jmid[3], jn[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            jf[t] = at(PA, jm[t] + js[t]);
+            jmid[t] = at(PA, jm[t]);
+            jn[t] = at(PA, jm[t] + jq[t]);
+        }
+        const double pS = at(desc(phiS + sxy * k), col);
+        W[(PH + 3) % 6] = qn;
+        const double c0 = W[PH % 6], zm1 = W[(PH + 5) % 6], zm2 = W[(PH + 4) % 6], zp1 = W[(PH + 1) % 6], zp2 = W[(PH + 2) % 6];
+        const int gk = k + bx.gz0;
+        const bool weno_ok = ij_weno && gk > 3 && gk < bx.nz - 4;
+        double a, b, c, d, e, f;
+        // z: P(k+2), X(k+2), Y(k-1) are new
+        Pz[(PH + 5) % 6] = weno_P(qn, zp2, dx, rdx);
+        Sz[(PH + 5) % 6] = Pz[(PH + 5) % 6] * Pz[(PH + 5) % 6];
+        Xz[(PH + 2) % 3] = weno_X(qn, zp2, zp1, dx, rdx);
+        Yz[(PH + 1) % 2] = weno_X(zm2, zm1, c0, dx, rdx);
+        if (weno_ok) {
+            WenoDiffs D;
+            double t0;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) D.p[m] = Pz[(PH + m) % 6], D.s[m] = Sz[(PH + m) % 6];
+            D.cp = Xz[PH % 3], D.bp = Xz[(PH + 1) % 3], D.ap = Xz[(PH + 2) % 3];
+            D.am = Yz[PH % 2], D.bm = Yz[(PH + 1) % 2];
+            D.t1p = Tz;
+            weno_from_diffs_strict(D, e, f, t0);
+        } else {
+            e = Pz[(PH + 2) % 6], f = Pz[(PH + 3) % 6]; // subs.f90:661-662: P(k-1), P(k)
+        }
+        // 13 (ap - bp)^2 of this cell is 13 (bp - cp)^2 of the next one along z
+        Tz = 13. * (Xz[(PH + 2) % 3] - Xz[(PH + 1) % 3]) * (Xz[(PH + 2) % 3] - Xz[(PH + 1) % 3]);
+        const double gZ = axis_godunov<true>(c0, e, f);
+        // x and y: the lane's own point
+        {
+            const double P = weno_P(xp, c0, dx, rdx);
+            wxo[0] = P, wxo[JSS_XN] = P * P;
+            wxo[2 * JSS_XN] = weno_X(xp, c0, xm, dx, rdx);
+            wxo[3 * JSS_XN] = weno_X(xm, c0, xp, dx, rdx);
+        }
+        {
+            const double P = weno_P(yp, c0, dx, rdx);
+            wyo[0] = P, wyo[JSS_YN] = P * P;
+            wyo[2 * JSS_YN] = weno_X(yp, c0, ym, dx, rdx);
+            wyo[3 * JSS_YN] = weno_X(ym, c0, yp, dx, rdx);
+        }
+        // the points beyond the patch
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (jon[t]) {
+                if (jp[t]) {
+                    const double P = weno_P(jf[t], jmid[t], dx, rdx);
+                    jd[t][0] = P;
+                    jd[t][t == 0 ? JSS_XN : JSS_YN] = P * P;
+                } else {
+                    jd[t][0] = weno_X(jf[t], jmid[t], jn[t], dx, rdx);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (weno_ok) {
+            WenoDiffs D;
+            double t0;
+            // x
+#pragma unroll
+            for (int m = 0; m < 6; ++m) D.p[m] = wxo[m - 3], D.s[m] = wxo[JSS_XN + m - 3];
+            D.cp = wxo[2 * JSS_XN], D.bp = wxo[2 * JSS_XN + 1], D.ap = wxo[2 * JSS_XN + 2];
+            D.bm = wxo[3 * JSS_XN - 1], D.am = wxo[3 * JSS_XN - 2];
+            D.t1p = 13. * (D.bp - D.cp) * (D.bp - D.cp);
+            weno_from_diffs_strict(D, a, b, t0);
+            // y (p5 = 0, subs.f90:576)
+#pragma unroll
+            for (int m = 0; m < 5; ++m) D.p[m] = wyo[(m - 3) * JSS_PX], D.s[m] = wyo[JSS_YN + (m - 3) * JSS_PX];
+            D.p[5] = 0.0, D.s[5] = 0.0;
+            D.cp = wyo[2 * JSS_YN], D.bp = wyo[2 * JSS_YN + JSS_PX], D.ap = wyo[2 * JSS_YN + 2 * JSS_PX];
+            D.bm = wyo[3 * JSS_YN - JSS_PX], D.am = wyo[3 * JSS_YN - 2 * JSS_PX];
+            D.t1p = 13. * (D.bp - D.cp) * (D.bp - D.cp);
+            weno_from_diffs_strict(D, c, d, t0);
+        } else {
+            a = wxo[-1], b = wxo[0], c = wyo[-JSS_PX], d = wyo[0]; // subs.f90:657-660: P(i-1), P(i)
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double newv = finish_update<true>(c0, axis_godunov<true>(c0, a, b), axis_godunov<true>(c0, c, d), gZ, pS, dx, 0.0, h);
+        if (cell) {
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            u2 wv;
+            wv.x = (unsigned)__double2loint(newv);
+            wv.y = (unsigned)__double2hiint(newv);
+            __builtin_amdgcn_raw_buffer_store_b64(wv, desc(Bout + sxy * k), col, 0, 0);
+            const double dlt = newv - c0;
+            acc = acc + dlt * dlt;
+        }
+    };
+    for (int k = k0; k < k1; k += 6) {
+        step(std::integral_constant<int, 0>{}, k);
+        if (k + 1 >= k1) break;
+        step(std::integral_constant<int, 1>{}, k + 1);
+        if (k + 2 >= k1) break;
+        step(std::integral_constant<int, 2>{}, k + 2);
+        if (k + 3 >= k1) break;
+        step(std::integral_constant<int, 3>{}, k + 3);
+        if (k + 4 >= k1) break;
+        step(std::integral_constant<int, 4>{}, k + 4);
+        if (k + 5 >= k1) break;
+        step(std::integral_constant<int, 5>{}, k + 5);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int q = 0; q < JSS_WX * JSS_WY; ++q) t += red[q];
         partials[blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)] = t;
     }
 }

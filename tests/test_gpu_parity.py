@@ -220,6 +220,32 @@ def test_jacobi_shared_interface_kernel_equals_per_cell_kernel(lsf, oracle, monk
         assert _rms(_host(t, phi0.shape), ref) < FAST_RMS_TOL, (shape, npts)
 
 
+def test_jacobi_strict_shared_difference_kernel_equals_per_cell_kernel_and_oracle(lsf, oracle, monkeypatch):
+    """STRICT Jacobi sweeps run k_reinit_jacobi_strict_sh: the first and second differences of subs.f90:509-513 / :525-530
+    evaluated once per point (carried along z, exchanged inside a wavefront's 16 x 4 patch of columns along x and y, the
+    points beyond the patch by edge jobs).  Bits of the per-cell kernel (LSF_JAC_SH=0) and of the oracle's Jacobi sweep on
+    grids with partial patches in x and y, rows shorter than a patch, fewer rows than a patch, z chunks that are not a
+    multiple of the march loop's six-fold unrolling, and grids where every cell takes the first-order branch."""
+    from levelsetfortran_amd import fields
+
+    for npts in ((24, 24, 24), (66, 21, 37), (130, 11, 9), (19, 70, 40), (9, 8, 50), (8, 9, 7), (35, 37, 71), (49, 6, 13)):
+        phi0, dx = fields.two_sphere_phi0(npts)
+        nx, ny, nz = (v - 1 for v in npts)
+        h = fields.reinit_step(dx)
+        monkeypatch.setenv("LSF_JAC_SH", "0")
+        base = _dev(phi0)
+        r0 = lsf.reinit(base, None, None, nx, ny, nz, 5, dx, h, tol=0.0, order="jacobi", arith="strict")
+        monkeypatch.delenv("LSF_JAC_SH")
+        t = _dev(phi0)
+        r1 = lsf.reinit(t, None, None, nx, ny, nz, 5, dx, h, tol=0.0, order="jacobi", arith="strict")
+        assert r0.count == r1.count == 6
+        assert bool((t == base).all()), (npts, float((t - base).abs().max()))
+        assert np.allclose(r0.rms, r1.rms, rtol=1e-12, atol=0)
+        ref = phi0.copy(order="F")
+        oracle.reinit(ref, nx, ny, nz, 5, dx, h, tol=0.0, order=oracle.JACOBI)
+        assert np.array_equal(_host(t, phi0.shape), ref), npts
+
+
 def test_jacobi_fast_decomposed_equals_single_domain_bitwise(lsf, monkeypatch):
     """The block-decomposed sweep (core through the shared-interface kernel, 3-cell x rims through the per-cell THINX
     kernel, y and z rims as thin shared-interface launches) returns the bits of the single-domain FAST sweep."""
