@@ -293,6 +293,7 @@ __global__ __launch_bounds__(64 * JSS_WX * JSS_WY) void k_reinit_jacobi_strict_s
         return lo >= 0 && hi <= (long)plane_bytes + 40 ? (unsigned)m : safe;
     };
     unsigned jm[3], js[3], jq[3];
+    double jw[3];
     double* jd[3];
     bool jp[3], jon[3];
     {
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(64 * JSS_WX * JSS_WY) void k_reinit_jacobi_strict_s
         jp[0] = kind == 0;
         js[0] = kind == 2 ? 0u - 8u : 8u;
         jq[0] = kind == 0 ? 0u : 0u - js[0];
+        jw[0] = kind == 0 ? 1. : 2.;
         jm[0] = job_mid(i0 + ex, j0 + r, (int)js[0], (int)jq[0]);
         jd[0] = w + (kind == 0 ? 0 : kind + 1) * JSS_XN + (jon[0] ? r : 0) * JSS_XP + ex + 3;
     }
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(64 * JSS_WX * JSS_WY) void k_reinit_jacobi_strict_s
         jp[t] = kind == 0;
         js[t] = kind == 2 ? 0u - rowb : rowb;
         jq[t] = kind == 0 ? 0u : 0u - js[t];
+        jw[t] = kind == 0 ? 1. : 2.;
         jm[t] = job_mid(i0 + c, j0 + ey, (int)js[t], (int)jq[t]);
         jd[t] = w + 4 * JSS_XN + (kind == 0 ? 0 : kind + 1) * JSS_YN + (ey + 3) * JSS_PX + c;
     }
@@ -374,12 +377,11 @@ __global__ __launch_bounds__(64 * JSS_WX * JSS_WY) void k_reinit_jacobi_strict_s
             D.cp = Xz[PH % 3], D.bp = Xz[(PH + 1) % 3], D.ap = Xz[(PH + 2) % 3];
             D.am = Yz[PH % 2], D.bm = Yz[(PH + 1) % 2];
             D.t1p = Tz;
-            weno_from_diffs_strict(D, e, f, t0);
+            weno_from_diffs_strict(D, e, f, Tz); // 13 (ap - bp)^2 of this cell is 13 (bp - cp)^2 of the next one along z
         } else {
             e = Pz[(PH + 2) % 6], f = Pz[(PH + 3) % 6]; // subs.f90:661-662: P(k-1), P(k)
+            Tz = 13. * (Xz[(PH + 2) % 3] - Xz[(PH + 1) % 3]) * (Xz[(PH + 2) % 3] - Xz[(PH + 1) % 3]);
         }
-        // 13 (ap - bp)^2 of this cell is 13 (bp - cp)^2 of the next one along z
-        Tz = 13. * (Xz[(PH + 2) % 3] - Xz[(PH + 1) % 3]) * (Xz[(PH + 2) % 3] - Xz[(PH + 1) % 3]);
         const double gZ = axis_godunov<true>(c0, e, f);
         // x and y: the lane's own point
         {
@@ -398,13 +400,11 @@ __global__ __launch_bounds__(64 * JSS_WX * JSS_WY) void k_reinit_jacobi_strict_s
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             if (jon[t]) {
-                if (jp[t]) {
-                    const double P = weno_P(jf[t], jmid[t], dx, rdx);
-                    jd[t][0] = P;
-                    jd[t][t == 0 ? JSS_XN : JSS_YN] = P * P;
-                } else {
-                    jd[t][0] = weno_X(jf[t], jmid[t], jn[t], dx, rdx);
-                }
+                // one instruction stream for the three kinds: far - 1 mid is far - mid, (far - 2 mid) + near the second differences
+                const double u = jf[t] - jw[t] * jmid[t];
+                const double v = div_dx(jp[t] ? u : u + jn[t], dx, rdx);
+                jd[t][0] = v;
+                if (jp[t]) jd[t][t == 0 ? JSS_XN : JSS_YN] = v * v;
             }
         }
         __builtin_amdgcn_wave_barrier();
