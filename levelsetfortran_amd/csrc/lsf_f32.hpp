@@ -175,8 +175,9 @@ __global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const floa
     __shared__ double red[F32_BX * F32_BY / 64];
     if (done && *done) return;
     // THINX (x rim of a decomposed sweep, a few cells wide): lanes along the pair index instead of x
-    const int li = THINX ? lo0 + (int)(blockIdx.y * F32_BY + threadIdx.y) : lo0 + (int)(blockIdx.x * F32_BX + threadIdx.x);
-    const int lj = THINX ? lo1 + 2 * (int)(blockIdx.x * F32_BX + threadIdx.x)
+    // (a wavefront: 4 cells in x by 16 pairs -- four x neighbours share a cache line; a block covers 4 x 64 pairs either way)
+    const int li = THINX ? lo0 + (int)(blockIdx.y * F32_BY + (threadIdx.x & 3)) : lo0 + (int)(blockIdx.x * F32_BX + threadIdx.x);
+    const int lj = THINX ? lo1 + 2 * (int)(blockIdx.x * F32_BX + threadIdx.y * 16 + (threadIdx.x >> 2))
                          : lo1 + 2 * (int)(blockIdx.y * F32_BY + threadIdx.y);
     const int k0 = lo2 + blockIdx.z * kc;
     const int k1 = min(k0 + kc, hi2);

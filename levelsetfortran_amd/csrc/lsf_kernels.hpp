@@ -80,7 +80,7 @@ constexpr int JAC_BX = 64, JAC_BY = LSF_JAC_BY, JAC_KC = LSF_JAC_KC;
 #define LSF_JAC_WAVES 1
 #endif
 // THINX: for regions only a few cells wide in x (the x rim of a block-decomposed sweep, 3 cells) the lanes of a
-// wavefront run along y instead (blockIdx.y picks the x cell): strided loads, but 64 busy lanes instead of 3.
+// wavefront cover 4 cells in x by 16 in y (blockIdx.y picks the group of four x cells): 48 busy lanes instead of 3.
 template <bool STRICT, bool THINX = false>
 __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi(const double* __restrict__ A,
                                                                    double* __restrict__ Bout,
@@ -92,8 +92,10 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi
 {
     __shared__ double red[JAC_BX * JAC_BY / 64];
     if (done && *done) return;
-    const int li = THINX ? lo0 + (int)(blockIdx.y * JAC_BY + threadIdx.y) : lo0 + (int)(blockIdx.x * JAC_BX + threadIdx.x);
-    const int lj = THINX ? lo1 + (int)(blockIdx.x * JAC_BX + threadIdx.x) : lo1 + (int)(blockIdx.y * JAC_BY + threadIdx.y);
+    // THINX: a wavefront is 4 cells in x by 16 in y (four x neighbours share a cache line: a quarter of the lines a column of 64
+    // cells touches per load); a block covers 4 x 64 cells either way
+    const int li = THINX ? lo0 + (int)(blockIdx.y * JAC_BY + (threadIdx.x & 3)) : lo0 + (int)(blockIdx.x * JAC_BX + threadIdx.x);
+    const int lj = THINX ? lo1 + (int)(blockIdx.x * JAC_BX + threadIdx.y * 16 + (threadIdx.x >> 2)) : lo1 + (int)(blockIdx.y * JAC_BY + threadIdx.y);
     const int k0 = lo2 + blockIdx.z * kc; // kc: planes a block marches (JacPlan: JAC_KC, fewer for thin regions)
     const int k1 = min(k0 + kc, hi2);
     const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
@@ -517,10 +519,10 @@ __global__ __launch_bounds__(64 * WX * BY) __attribute__((amdgpu_waves_per_eu(5)
         const double inv_dx = 1.0 / dx, floor2 = 1.E-99 * dx * dx / 13.0;
         // Addressing: one buffer descriptor per k-plane (rebuilt on the scalar unit every step, base = the plane) + 32-bit
         // byte offsets inside the plane that do not change along the march.  No load of the loop sits behind a branch:
-        //   x: the six points li-2 .. li+3 are `colx` + immediates; the offset may leave the row or wrap below zero near a
-        //      wall -- the range check of the descriptor then returns 0 (below the plane / beyond it) or the value of a
-        //      neighbouring row, and neither is used: a WENO cell has all six points in its row, a first-order cell reads
-        //      li +- 1 only, which always exist;
+        //   x: the six points li-2 .. li+3 are `colx` + immediates; the offset may leave the row or the end of the plane near
+        //      a wall -- the load then returns the value of a neighbouring row or, past the plane, the descriptor's 0 -- and
+        //      neither is used: a WENO cell has all six points in its row, a first-order cell reads li +- 1 only, which always
+        //      exist.  (It never wraps below zero: lj >= 1, so col >= one row.  A wrapped offset is NOT safe: k_reinit_jacobi_strict_sh);
         //   y: six offsets with the row clamped into the plane (same argument).
         const unsigned plane_bytes = 8u * (unsigned)sxy;
         const int lic = min(li, bx.lx - 1), ljc = min(lj, bx.ly - 1);
