@@ -13,9 +13,9 @@ for dtype in ('f64', 'f32'):
     dr = lsd.DistributedReinit(be, b, dx, h)
     def fake_exchange(f):  # pack + unpack on the comm stream, no transport
         be.wait(be.comm, be.compute)
-        with be.stream_ctx(be.comm):
-            for (peer, s_box, _r, _a, _s), sb in zip(dr.plan, dr.send_bufs): be.pack(f, b, s_box, sb, be.comm)
-            for (peer, _s, r_box, _a, _sd), rb in zip(dr.plan, dr.recv_bufs): be.unpack(f, b, r_box, rb, be.comm)
+        with be.stream_ctx(be.comm):  # as DistributedReinit.exchange does: all face slabs in one launch each way
+            be.pack_all(f, b, [p[1] for p in dr.plan], dr.send_bufs, be.comm)
+            be.unpack_all(f, b, [p[2] for p in dr.plan], dr.recv_bufs, be.comm)
     dr.exchange = fake_exchange
     n = b.npoints_local()
     # the bench's own field (smooth two-sphere distance), not noise: these kernels run power-limited, and a field of random
