@@ -266,6 +266,8 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     int tail_max = MB_EPOCHS - 2;
     if (const char* e = getenv("LSF_MINMAX_TAIL_MAX")) tail_max = std::min(tail_max, std::max(0, atoi(e))); // test hook: too few passes (0: no certifying pass at all)
     int* bar = chg + MB_EPOCHS; // barrier word of the tail launch, behind its per-pass change counts
+    int tail_blocks = MB_TAIL_BLOCKS;
+    if (const char* e = getenv("LSF_MINMAX_TAIL_BLOCKS")) tail_blocks = std::min(512, std::max(8, atoi(e))); // measurement aid (all resident: <= 2 per CU)
     int host_ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < iter; ++it) { // DO n = 1,iter (set3d.f90:394)
         const MbArgs q = args_of(it);
@@ -273,7 +275,7 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
         if (gs) {
             const int epoch0 = it * MB_EPOCHS + 1;
             hipLaunchKernelGGL(k_minmax_band_fix, gl, b256, 0, st, q, epoch0, chg);
-            hipLaunchKernelGGL(k_minmax_band_tail, dim3(MB_TAIL_BLOCKS), b256, 0, st, q, epoch0 + 1, tail_max, (const int*)chg, chg + 1, bar,
+            hipLaunchKernelGGL(k_minmax_band_tail, dim3(tail_blocks), b256, 0, st, q, epoch0 + 1, tail_max, (const int*)chg, chg + 1, bar,
                                200000000ull);
         }
         hipLaunchKernelGGL((k_minmax_band<2>), gl, b256, 0, st, q);

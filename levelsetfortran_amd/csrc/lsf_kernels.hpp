@@ -373,7 +373,6 @@ __global__ __launch_bounds__(64 * JSS_WX * JSS_WY) void k_reinit_jacobi_strict_s
         Yz[(PH + 1) % 2] = weno_X(zm2, zm1, c0, dx, rdx);
         if (weno_ok) {
             WenoDiffs D;
-            double t0;
 #pragma unroll
             for (int m = 0; m < 6; ++m) D.p[m] = Pz[(PH + m) % 6], D.s[m] = Sz[(PH + m) % 6];
             D.cp = Xz[PH % 3], D.bp = Xz[(PH + 1) % 3], D.ap = Xz[(PH + 2) % 3];
