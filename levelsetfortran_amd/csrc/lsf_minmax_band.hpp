@@ -251,7 +251,10 @@ __global__ __launch_bounds__(256) void k_minmax_band(MbArgs a)
 // rows of a plane follow each other -- is then resolved by one visit instead of one pass per link.  Evolving values are read and
 // written past the vector L1 (sc1: the block re-reads what its own threads and other blocks have just stored).  Returns (to every
 // thread) whether the visit changed a cell.
-constexpr int MB_REPS = 8;
+#ifndef LSF_MB_REPS
+#define LSF_MB_REPS 8
+#endif
+constexpr int MB_REPS = LSF_MB_REPS;
 __device__ __forceinline__ bool mb_visit_chunk(const MbArgs& a, int chunk, int epoch)
 {
     const int nL = a.nL;
