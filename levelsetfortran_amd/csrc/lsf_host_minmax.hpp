@@ -181,11 +181,11 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     int rc;
     const long nblk = (long)((n + MB_SCAN - 1) / MB_SCAN);
     if ((rc = ws(c.slot[S_PONG], n * sizeof(int)))) return rc; // staging of the list build (the band executor has no second field)
-    if ((rc = ws(c.slot[S_MB_CNT], (size_t)(2 * nblk + 2) * sizeof(int)))) return rc;
+    if ((rc = ws(c.slot[S_MB_CNT], (size_t)(2 * nblk + 8) * sizeof(int)))) return rc;
     if ((rc = ws(c.slot[S_CTL], 64))) return rc;
     int* staging = (int*)c.slot[S_PONG].p;
     int* counts = (int*)c.slot[S_MB_CNT].p;
-    int* offsets = counts + nblk;
+    int* offsets = counts + ((nblk + 3) & ~3L); // 16-byte aligned like counts (k_mb_offsets moves vectors)
     const bool trace = getenv("LSF_TRACE") != nullptr;
     const double t_build0 = trace ? now_s() : 0.0;
     hipLaunchKernelGGL(k_mb_collect, dim3((unsigned)nblk), dim3(256), 0, st, (const double*)d_phi, (const int32_t*)d_nb, nx, ny, nz, dx,

@@ -87,13 +87,29 @@ static __global__ __launch_bounds__(256) void k_mb_collect(const double* __restr
     if (threadIdx.x == 0) counts[blockIdx.x] = run;
 }
 
-// List build, pass 2: exclusive prefix sum of the per-block counts (one block; offsets[nblk] = length of the list).
+// List build, pass 2: exclusive prefix sum of the per-block counts (one block; offsets[nblk] = length of the list).  A thread owns a
+// run of `per` consecutive counts (a multiple of four) and moves them as 16-byte vectors, all loads of a run in flight together
+// (one by one, 64 dependent round trips per thread made this 100 us at 512^3).
 static __global__ __launch_bounds__(1024) void k_mb_offsets(const int* __restrict__ counts, long nblk, int* __restrict__ offsets)
 {
     __shared__ int part[1024];
-    const long per = (nblk + 1023) / 1024, lo = (long)threadIdx.x * per, hi = min(lo + per, nblk);
+    const long per = (((nblk + 1023) / 1024) + 3) & ~3L, lo = (long)threadIdx.x * per, hi = min(lo + per, nblk);
+    const bool vec = (((uintptr_t)counts | (uintptr_t)offsets) & 15) == 0;
     int s = 0;
-    for (long q = lo; q < hi; ++q) s += counts[q];
+    if (vec) {
+        for (long q = lo; q < hi; q += 16) {
+            int4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long qq = q + 4 * u;
+                v[u] = qq + 3 < hi ? *(const int4*)(counts + qq) : make_int4(qq < hi ? counts[qq] : 0, qq + 1 < hi ? counts[qq + 1] : 0, qq + 2 < hi ? counts[qq + 2] : 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u].x + v[u].y + v[u].z + v[u].w;
+        }
+    } else {
+        for (long q = lo; q < hi; ++q) s += counts[q];
+    }
     part[threadIdx.x] = s;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) { // inclusive scan
@@ -103,9 +119,24 @@ static __global__ __launch_bounds__(1024) void k_mb_offsets(const int* __restric
         __syncthreads();
     }
     int run = part[threadIdx.x] - s;
-    for (long q = lo; q < hi; ++q) {
-        offsets[q] = run;
-        run += counts[q];
+    if (vec) {
+        for (long q = lo; q < hi; q += 4) {
+            if (q + 3 < hi) {
+                const int4 c = *(const int4*)(counts + q);
+                *(int4*)(offsets + q) = make_int4(run, run + c.x, run + c.x + c.y, run + c.x + c.y + c.z);
+                run += c.x + c.y + c.z + c.w;
+            } else {
+                for (long r = q; r < hi; ++r) {
+                    offsets[r] = run;
+                    run += counts[r];
+                }
+            }
+        }
+    } else {
+        for (long q = lo; q < hi; ++q) {
+            offsets[q] = run;
+            run += counts[q];
+        }
     }
     if (threadIdx.x == 1023) offsets[nblk] = part[1023];
 }
