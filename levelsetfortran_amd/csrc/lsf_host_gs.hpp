@@ -292,6 +292,9 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
             fa.dbg = d_dbg;
             fa.timeout_ticks = FLOW_TIMEOUT_TICKS;
             if (const char* e = getenv("LSF_GS_TIMEOUT_TICKS")) fa.timeout_ticks = strtoull(e, nullptr, 10); // test hook
+#ifdef LSF_EXPERIMENTS
+            if (const char* e = getenv("LSF_PROBE_EARLY_FLAG")) fa.probe_early = atoi(e); // work-term style probe: wrong fields on purpose
+#endif
             // one block per tile; a block takes its tile from the ticket counter, so the grid only has to be large enough
             // (2-D: gridDim.x * blockDim.x must stay below 2^32)
             const dim3 grid((unsigned)std::min<long>(fa.total, 65536), (unsigned)((fa.total + 65535) / 65536));

@@ -296,9 +296,13 @@ __device__ __forceinline__ void sk_lane_offsets1(int si, int sj, int sk, int bc,
 // each with field buffers of its own.  Results within three planes of a cut are stored into the neighbour's buffer as well
 // (same address map), the column's running RMS sum into the colsum of the slab that runs this sweep's epilogue, and the
 // epilogue's verdict into every slab's control words; all of that and every load at system scope.
-template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, bool PUSH = false, class WaitUp>
+// mid(t): called in front of marching step t (a probe of the experiment builds hooks in here; nothing in the product)
+struct SkNoHook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, bool PUSH = false, class WaitUp, class MidHook = SkNoHook>
 __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, const GsArgs& a, uint32_t packed, int g, int si, int sj,
-                                          int sk, const SkPre& pre, WaitUp&& wait_upstream)
+                                          int sk, const SkPre& pre, WaitUp&& wait_upstream, MidHook mid = MidHook{})
 {
     static_assert(TA == 16 || (TA == 32 && BY == 5 && !PUSH), "tiles of 32 marching steps: three lanes per cell, single launch only");
     constexpr int CPN = TA / 16; // the loaders and the write back handle a row 16 entries at a time
@@ -618,6 +622,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         {
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
+                mid(t);
                 const bool active = (bool)((act_bits >> t) & 1u) && axis == 0;
                 double q[7];
 #pragma unroll
@@ -646,6 +651,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
 #pragma unroll
             for (int u = 0; u < CU; ++u) {
                 const int t = t0 + u;
+                mid(t);
                 const bool active = (act_bits >> t) & 1u;
                 const bool weno_ok = (weno_bits >> t) & 1u;
                 double qx[7], qy[7], qz[7];
@@ -1130,8 +1136,19 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
             return uni(sh_task[6]) == 1;
         };
         if (go == 1) {
+#ifdef LSF_EXPERIMENTS
+            // LSF_PROBE_EARLY_FLAG = t: the tile raises its flag in front of marching step t, with nothing of it stored yet -- the
+            // fields come out wrong; the launch's time is a LOWER bound of what a hand-off finer than a tile could reach
+            // (profiles/r05_gs_probes.txt, item 7)
+            auto early = [&](int t) {
+                if (a.probe_early > 0 && t == a.probe_early && tid == 0) __hip_atomic_store(my_flag, 1, __ATOMIC_RELAXED, LSF_FLAG_ST_SCOPE);
+            };
+            if (!skew_tile<TA, WY, WZ, BY, STRICT, true>(sm, a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream, early))
+                go = 2;
+#else
             if (!skew_tile<TA, WY, WZ, BY, STRICT, true>(sm, a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream))
                 go = 2;
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads(); // every wave of the tile has drained its stores (and left the LDS image)
