@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: lower bound of what a hand-off finer than a tile could reach (VERDICT r4 item 2 b).  Experiment build
-# (-DLSF_EXPERIMENTS, build/exp/liblsf_ef.so); LSF_PROBE_EARLY_FLAG = t: every tile of the dataflow launch raises its flag in front of
+# (make -C levelsetfortran_amd/csrc OUT=../../build/exp/liblsf_ef.so EXTRA=-DLSF_EXPERIMENTS); LSF_PROBE_EARLY_FLAG = t: every tile of the dataflow launch raises its flag in front of
 # marching step t, before anything of it is stored -- the fields come out wrong on purpose, only the launch's time is read.
 export LSF_LIB_PATH=$PWD/build/exp/liblsf_ef.so
 for N in ${SIZES:-128 256 512}; do
