@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSF_VERSION 105 /* 0.1.5: lsf_peer_selftest; LSF_GS_STREAM (the dataflow launch with column continuation, opt-in) */
+#define LSF_VERSION 106 /* 0.1.6: no new entry points; the argument block of the exact-ordering kernels no longer carries experiment fields */
 
 /* ---- return codes ---------------------------------------------------------------------- */
 #define LSF_OK 0

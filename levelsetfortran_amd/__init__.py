@@ -6,4 +6,4 @@ from .levelset import (LsfError, LsfNaNError, SweepReport, advectNodes, minmaxFl
                        phi0Init, reinit, reinit_multi)
 from . import fields  # noqa: F401
 
-__version__ = "0.1.5"
+__version__ = "0.1.6"

@@ -207,6 +207,10 @@ struct Ctx {
     std::map<int, uint32_t*> sk_tables;            // skewed tiles: lookup tables per tile shape (SkTile::rel_entry / lane_off)
     std::map<std::array<int, 6>, BatchPlan> plans; // dataflow schedule: batch plans per grid / raster phase / sweep count
     bool checked = false;
+    // min/max flow on the band (lsf_host_minmax.hpp): blocks of its looping launch (resident as a whole: occupancy x CUs, at most
+    // one per CU; 0 = not asked yet) and whether that launch has ever timed out on this device (then the dense executors run)
+    int mm_tail_blocks = 0;
+    bool mm_band_off = false;
 };
 
 std::mutex g_mu;
@@ -460,16 +464,21 @@ static int jacobi_kc(long columns, int cz)
     while (kc > 4 && columns * cdiv(cz, kc) < 2048) kc >>= 1;
     return kc;
 }
-JacPlan jacobi_plan(const int lo[3], const int hi[3], bool strict)
+JacPlan jacobi_plan(const int lo[3], const int hi[3], bool strict, const int ext[3])
 {
     JacPlan p;
     const int cx = hi[0] - lo[0], cy = hi[1] - lo[1], cz = hi[2] - lo[2];
+    // k_reinit_jacobi_strict_sh forms its buffer descriptors three doubles in front of a plane and clamps its operand offsets one
+    // point inside the region's surroundings: every cell of the region needs a point of the LOCAL array on each side (true for
+    // interior cells of the global grid in a box that holds its wall points / ghost layers -- asserted here, not assumed)
+    bool inside = true;
+    for (int d = 0; d < 3; ++d) inside = inside && lo[d] >= 1 && hi[d] <= ext[d] - 1;
     const bool thinx = cx <= 8 && cy >= 32;
     const char* env = getenv("LSF_JAC_SH");
     int fwx = 0, fby = 0;
     const bool off = env && env[0] == '0' && env[1] == 0;
     if (env && !off && sscanf(env, "%dx%d", &fwx, &fby) != 2) fwx = fby = 0;
-    if (strict && !thinx && !off) {
+    if (strict && !thinx && !off && inside) {
         p.kind = 3;
         const int gx = cdiv(cx, JSS_PX * JSS_WX), gy = cdiv(cy, JSS_PY * JSS_WY);
         p.kc = jacobi_kc((long)gx * gy, cz);
@@ -618,7 +627,10 @@ int jacobi_loop(T* d_phi, const T* d_phiS_in, int nx, int ny, int nz, int iter, 
     JacPlan jp;
     long n_sweep_part;
     if constexpr (F32) jp = jacobi_plan_f32(jlo, jhi);
-    else jp = jacobi_plan(jlo, jhi, strict);
+    else {
+        const int jext[3] = {nx + 1, ny + 1, nz + 1};
+        jp = jacobi_plan(jlo, jhi, strict, jext);
+    }
     n_sweep_part = jp.nparts;
     const Box bx{nx + 1, ny + 1, nz + 1, 0, 0, 0, nx, ny, nz};
     const int blo[3] = {0, 0, 0}, bhi[3] = {nx + 1, ny + 1, nz + 1};
@@ -1272,7 +1284,8 @@ int lsf_jacobi_sweep_box(const double* d_in, double* d_out, const double* d_phiS
     hipStream_t st = (hipStream_t)stream;
     // regions a few cells wide in x (the x rim of a decomposed sweep) run with the lanes along y (jacobi_plan)
     const bool strict = (mode & LSF_ARITH_STRICT) != 0;
-    const JacPlan jp = jacobi_plan(lo, hi, strict);
+    const int ext[3] = {box->lx, box->ly, box->lz};
+    const JacPlan jp = jacobi_plan(lo, hi, strict, ext);
     const long np = jp.nparts;
     double* part = nullptr;
     if ((rc = stream_partials(st, (size_t)np, &part))) return rc;

@@ -67,8 +67,10 @@ struct GsArgs {
     unsigned long long timeout_ticks; // bound of every spin of the dataflow launch (100 MHz ticks)
     const uint32_t* tables;  // skewed tiles: lookup tables of the tile shape (SkTile: rel_tab | off_tab), or NULL
     unsigned long long* dbg; // optional phase timers (s_memrealtime ticks): wait, load, march, publish, tasks
-    int probe_us;            // experiment builds only (k_reinit_gs_skew, LSF_PROBE_STAGGER): delay of the second block of a CU
-    int probe_early;         // experiment builds only (k_reinit_gs_persist, LSF_PROBE_EARLY_FLAG): marching step in front of which a tile raises its flag
+#ifdef LSF_EXPERIMENTS       // probes of the experiment builds (profiles/micro); the product's argument block does not carry them
+    int probe_us;            // k_reinit_gs_skew, LSF_PROBE_STAGGER: delay of the second block of a CU
+    int probe_early;         // k_reinit_gs_persist, LSF_PROBE_EARLY_FLAG: marching step in front of which a tile raises its flag
+#endif
     // exact ordering across z slabs (k_reinit_gs_slab, lsf_gs_slabs.hpp): this launch owns the tile columns tk_lo <= tk < tk_hi of
     // the same global tile graph; every slab holds field buffers with the global address map, of which its own planes and the
     // three planes beyond each cut are kept current (the neighbour stores them there)

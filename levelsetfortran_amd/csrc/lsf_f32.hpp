@@ -173,6 +173,7 @@ __global__ __launch_bounds__(F32_BX* F32_BY) void k_reinit_jacobi_f32(const floa
                                                                       const int* __restrict__ done, int xwall, int kc)
 {
     __shared__ double red[F32_BX * F32_BY / 64];
+    static_assert(!THINX || (F32_BX == 64 && F32_BY == 4), "THINX lane map: a block is 64 x 4 threads");
     if (done && *done) return;
     // THINX (x rim of a decomposed sweep, a few cells wide): lanes along the pair index instead of x
     // (a wavefront: 4 cells in x by 16 pairs -- four x neighbours share a cache line; a block covers 4 x 64 pairs either way)

@@ -178,9 +178,13 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     if (n > (size_t)0x7fffffff) return LSF_OK;
     const bool gs = (mode & LSF_ORDER_MASK) == LSF_ORDER_GS;
     Ctx& c = ctx();
+    if (gs && c.mm_band_off) return LSF_OK; // the looping launch timed out on this device before (said once, below)
     int rc;
     const long nblk = (long)((n + MB_SCAN - 1) / MB_SCAN);
-    if ((rc = ws(c.slot[S_PONG], n * sizeof(int)))) return rc; // staging of the list build (the band executor has no second field)
+    // staging of the list build (the band executor has no second field).  Asked for at the size the dense executors want their second
+    // field at (n doubles; the staging uses n ints of it): a call that turns out to need them -- a band above a quarter of the grid,
+    // cube40 as shipped -- does not free and allocate the buffer a second time
+    if ((rc = ws(c.slot[S_PONG], n * sizeof(double)))) return rc;
     if ((rc = ws(c.slot[S_MB_CNT], (size_t)(2 * nblk + 8) * sizeof(int)))) return rc;
     if ((rc = ws(c.slot[S_CTL], 64))) return rc;
     int* staging = (int*)c.slot[S_PONG].p;
@@ -266,8 +270,20 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     int tail_max = MB_EPOCHS - 2;
     if (const char* e = getenv("LSF_MINMAX_TAIL_MAX")) tail_max = std::min(tail_max, std::max(0, atoi(e))); // test hook: too few passes (0: no certifying pass at all)
     int* bar = chg + MB_EPOCHS; // barrier word of the tail launch, behind its per-pass change counts
-    int tail_blocks = MB_TAIL_BLOCKS;
+    // blocks of the looping launch: one per CU (measured best), never more than the device admits at once -- its grid barrier
+    // needs every block resident (a partitioned device, fewer CUs): asked once per device
+    if (gs && c.mm_tail_blocks == 0) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t pr;
+        HIPCHK(hipGetDevice(&dev));
+        HIPCHK(hipGetDeviceProperties(&pr, dev));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_minmax_band_tail, 256, 0));
+        c.mm_tail_blocks = std::max(1, std::min(MB_TAIL_BLOCKS, std::max(1, per_cu) * pr.multiProcessorCount));
+    }
+    int tail_blocks = gs ? c.mm_tail_blocks : MB_TAIL_BLOCKS;
     if (const char* e = getenv("LSF_MINMAX_TAIL_BLOCKS")) tail_blocks = std::min(512, std::max(8, atoi(e))); // measurement aid (all resident: <= 2 per CU)
+    unsigned long long tail_timeout = 200000000ull; // 2 s of the 100 MHz clock
+    if (const char* e = getenv("LSF_MINMAX_TAIL_TIMEOUT_TICKS")) tail_timeout = strtoull(e, nullptr, 10); // test hook
     int host_ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < iter; ++it) { // DO n = 1,iter (set3d.f90:394)
         const MbArgs q = args_of(it);
@@ -276,7 +292,7 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
             const int epoch0 = it * MB_EPOCHS + 1;
             hipLaunchKernelGGL(k_minmax_band_fix, gl, b256, 0, st, q, epoch0, chg);
             hipLaunchKernelGGL(k_minmax_band_tail, dim3(tail_blocks), b256, 0, st, q, epoch0 + 1, tail_max, (const int*)chg, chg + 1, bar,
-                               200000000ull);
+                               tail_timeout);
         }
         hipLaunchKernelGGL((k_minmax_band<2>), gl, b256, 0, st, q);
         if (nchunks > 16384) {
@@ -304,7 +320,15 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     HIPCHK(hipMemcpyAsync(host_ctl, ctl, sizeof host_ctl, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (host_ctl[3]) { // an iteration the tail launch did not certify (never observed): phi and the masks have not been written
-        if (trace) fprintf(stderr, "[lsf] min/max on the band: iteration %d NOT certified -> dense executor\n", host_ctl[1] + 1);
+        if (host_ctl[5]) {
+            // a block waited for the others longer than the bound: the grid was not resident as a whole (a device shared with other
+            // work).  Said once, whatever LSF_TRACE holds, and remembered: later calls go to the dense executors at once instead of
+            // paying the bound and the list build again.
+            c.mm_band_off = true;
+            fprintf(stderr, "[lsf] min/max on the band: the looping launch (%d blocks) timed out waiting for its own blocks -- is the device shared? "
+                            "This and every later exact min/max call on this device use the dense executors.\n", tail_blocks);
+        } else if (trace)
+            fprintf(stderr, "[lsf] min/max on the band: iteration %d NOT certified -> dense executor\n", host_ctl[1] + 1);
         return LSF_OK;
     }
     if (gs && trace) fprintf(stderr, "[lsf] min/max on the band: at most %d fix passes per iteration\n", host_ctl[4] + 1);

@@ -91,6 +91,8 @@ __global__ __launch_bounds__(JAC_BX* JAC_BY, LSF_JAC_WAVES) void k_reinit_jacobi
                                                                    const int* __restrict__ done, int kc)
 {
     __shared__ double red[JAC_BX * JAC_BY / 64];
+    // the THINX lane map below (4 cells in x by 16 in y per wavefront, 4 wavefronts in y per block) is written for 64 x 4 threads
+    static_assert(!THINX || (JAC_BX == 64 && JAC_BY == 4), "THINX lane map: a block is 64 x 4 threads (LSF_JAC_BY must stay 4)");
     if (done && *done) return;
     // THINX: a wavefront is 4 cells in x by 16 in y (four x neighbours share a cache line: a quarter of the lines a column of 64
     // cells touches per load); a block covers 4 x 64 cells either way

@@ -346,7 +346,9 @@ static __global__ __launch_bounds__(256) void k_minmax_band_fix(MbArgs a, int ep
 // dependent sign flips a min/max iteration resolves grows with the flow (two-sphere field at 512^3: 2 passes in the first ten
 // iterations, 17 by the fiftieth).  Stamps, change counts and evolving values travel past the non-coherent caches (sc1 stores
 // drained before the barrier, sc1 loads behind it: cdna_hip_programming.md G16); every spin is bounded: a grid that is not
-// resident as a whole (a device shared with other work) ends with ctl[3] and the host takes the dense executor.
+// resident as a whole (a device shared with other work) ends with ctl[3] and ctl[5] (= timed out, as opposed to "passes exhausted")
+// and the host takes the dense executor -- for this call and, having said so once, for every later one on that device.  The host
+// sizes the grid from the occupancy query: at most one block per CU, never more than the device admits at once.
 // (blocks: one per CU measured best at 512^3 -- 64: 0.177, 128: 0.152, 256: 0.147, 512: 0.172 ms per iteration of a 50-iteration call)
 constexpr int MB_TAIL_BLOCKS = 256;
 static __global__ __launch_bounds__(256) void k_minmax_band_tail(MbArgs a, int epoch_first, int max_passes, const int* __restrict__ changed_first,
@@ -388,6 +390,7 @@ static __global__ __launch_bounds__(256) void k_minmax_band_tail(MbArgs a, int e
             while (ld_flag(bar) < target) {
                 if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
                     go = -1;
+                    st_flag(a.ctl + 5, 1);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);

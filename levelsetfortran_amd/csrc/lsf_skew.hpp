@@ -42,8 +42,12 @@
 #ifndef LSF_STRICT22_WAVES
 #define LSF_STRICT22_WAVES 4
 #endif
-// work-term probes of a smaller LDS image of the one-lane-per-cell tile (experiment builds; the field comes out wrong): row pitches
-// of the bundle / halo rows and the wavefronts per SIMD the kernels are compiled for (profiles/r05_ring_probe.txt)
+// work-term probes of a smaller LDS image of the one-lane-per-cell tile (EXPERIMENT BUILDS ONLY; the field comes out wrong): row
+// pitches of the bundle / halo rows and the wavefronts per SIMD the kernels are compiled for (profiles/r05_ring_probe.txt)
+#if !defined(LSF_EXPERIMENTS)
+#undef LSF_PROBE_RA
+#undef LSF_PROBE_RH
+#endif
 #ifndef LSF_PROBE_RA
 #define LSF_PROBE_RA 0
 #endif
@@ -296,13 +300,22 @@ __device__ __forceinline__ void sk_lane_offsets1(int si, int sj, int sk, int bc,
 // each with field buffers of its own.  Results within three planes of a cut are stored into the neighbour's buffer as well
 // (same address map), the column's running RMS sum into the colsum of the slab that runs this sweep's epilogue, and the
 // epilogue's verdict into every slab's control words; all of that and every load at system scope.
-// mid(t): called in front of marching step t (a probe of the experiment builds hooks in here; nothing in the product)
+#ifdef LSF_EXPERIMENTS
+// experiment builds: mid(t) is called in front of marching step t (the early-flag probe of profiles/micro hooks in here)
 struct SkNoHook {
     __device__ __forceinline__ void operator()(int) const {}
 };
-template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, bool PUSH = false, class WaitUp, class MidHook = SkNoHook>
+#define LSF_SK_MID_TPARAM , class MidHook = SkNoHook
+#define LSF_SK_MID_PARAM , MidHook mid = MidHook{}
+#define LSF_SK_MID(t_) mid(t_)
+#else
+#define LSF_SK_MID_TPARAM
+#define LSF_SK_MID_PARAM
+#define LSF_SK_MID(t_)
+#endif
+template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, bool PUSH = false, class WaitUp LSF_SK_MID_TPARAM>
 __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, const GsArgs& a, uint32_t packed, int g, int si, int sj,
-                                          int sk, const SkPre& pre, WaitUp&& wait_upstream, MidHook mid = MidHook{})
+                                          int sk, const SkPre& pre, WaitUp&& wait_upstream LSF_SK_MID_PARAM)
 {
     static_assert(TA == 16 || (TA == 32 && BY == 5 && !PUSH), "tiles of 32 marching steps: three lanes per cell, single launch only");
     constexpr int CPN = TA / 16; // the loaders and the write back handle a row 16 entries at a time
@@ -622,7 +635,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
         {
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
-                mid(t);
+                LSF_SK_MID(t);
                 const bool active = (bool)((act_bits >> t) & 1u) && axis == 0;
                 double q[7];
 #pragma unroll
@@ -651,7 +664,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
 #pragma unroll
             for (int u = 0; u < CU; ++u) {
                 const int t = t0 + u;
-                mid(t);
+                LSF_SK_MID(t);
                 const bool active = (act_bits >> t) & 1u;
                 const bool weno_ok = (weno_bits >> t) & 1u;
                 double qx[7], qy[7], qz[7];

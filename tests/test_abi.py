@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names  # the Python binding covers the whole header, nothing more
-    assert lib.lsf_version() == 105
+    assert lib.lsf_version() == 106
 
 
 def test_no_cpu_fallback_without_device():
@@ -73,16 +73,58 @@ def test_sweep_report_lines_follow_the_reference_protocol():
     assert len(r.lines(1, "steady")) == 2 and "Iteration:  2" in r.lines(1, "steady")[1]
 
 
-def test_every_environment_switch_of_the_library_is_documented():
-    """every getenv("LSF_...") in levelsetfortran_amd/csrc has its row in INTEGRATION.md."""
-    import glob
-    import re
+def _product_text(src):
+    """The text of a source file as the PRODUCT build sees it: what sits between `#ifdef LSF_EXPERIMENTS` (or
+    `#if defined(LSF_EXPERIMENTS) ...`) and its `#else` / `#endif` is dropped, what sits behind `#ifndef LSF_EXPERIMENTS` kept."""
+    out, stack = [], []  # stack entries: [is an LSF_EXPERIMENTS conditional, currently in its product branch]
+    for line in src.splitlines():
+        t = line.strip()
+        if re.match(r"#\s*if", t):
+            if re.match(r"#\s*ifdef\s+LSF_EXPERIMENTS\b", t) or re.match(r"#\s*if\s+defined\s*\(?\s*LSF_EXPERIMENTS\b", t):
+                stack.append([True, False])
+            elif re.match(r"#\s*ifndef\s+LSF_EXPERIMENTS\b", t) or re.match(r"#\s*if\s+!\s*defined\s*\(?\s*LSF_EXPERIMENTS\b", t):
+                stack.append([True, True])
+            else:
+                stack.append([False, True])
+        elif re.match(r"#\s*else", t) and stack and stack[-1][0]:
+            stack[-1][1] = not stack[-1][1]
+        elif re.match(r"#\s*endif", t) and stack:
+            stack.pop()
+        elif all(keep for _, keep in stack):
+            out.append(line)
+    assert not stack, "unbalanced conditionals"
+    return "\n".join(out)
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+
+def test_product_text_filter():
+    src = "a\n#ifdef LSF_EXPERIMENTS\nb\n#if X\nc\n#endif\n#else\nd\n#endif\n#ifndef LSF_EXPERIMENTS\ne\n#endif\n#if Y\nf\n#endif"
+    assert _product_text(src).split() == ["a", "d", "e", "f"]
+
+
+def _csrc_files():
+    import glob
+
+    return sorted(glob.glob(os.path.join(ROOT, "levelsetfortran_amd", "csrc", "*.h*")))
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """every getenv("LSF_...") of the PRODUCT build of levelsetfortran_amd/csrc has its row in INTEGRATION.md
+    (switches that exist in the experiment builds of profiles/micro only -- code behind LSF_EXPERIMENTS -- are theirs to document)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     names = set()
-    for f in glob.glob(os.path.join(root, "levelsetfortran_amd", "csrc", "*.h*")):
-        names |= set(re.findall(r'getenv\("(LSF_[A-Z0-9_]+)"\)', open(f).read()))
+    for f in _csrc_files():
+        names |= set(re.findall(r'getenv\("(LSF_[A-Z0-9_]+)"\)', _product_text(open(f).read())))
     assert len(names) > 20
     missing = sorted(n for n in names if n not in doc)
     assert not missing, missing
+
+
+def test_experiment_hooks_stay_out_of_the_product_build():
+    """probe fields, probe switches and the marching-step hook exist behind LSF_EXPERIMENTS only."""
+    for f in _csrc_files():
+        txt = _product_text(open(f).read())
+        assert not re.search(r'getenv\("LSF_PROBE_', txt), f
+        assert "probe_us" not in txt and "probe_early" not in txt and "MidHook" not in txt, f
+    # ... and the product library is not an experiment build
+    mk = open(os.path.join(ROOT, "levelsetfortran_amd", "csrc", "Makefile")).read()
+    assert re.search(r"^EXTRA\s*\?=\s*$", mk, flags=re.M), "the default build passes no -D switches"
