@@ -258,6 +258,10 @@ def main() -> None:
             res = lsd.bench_weak_scaling(N, K, W, dev, arith=args.arith, dtype=args.dtype, shared_gpu=shared_gpu)
         cells_total, seconds, prof, parallelism = res["cells_total"], res["seconds"], res["prof"], res["parallelism"]
         order = "jacobi"
+        # the headline's own evidence (outside its timed region): same ranks, transport and decomposition on a grid that can be
+        # compared as a whole with rank 0's single-domain sweep
+        Gp = 64 if min(res["global_grid"]) < 256 else 256
+        headline_parity = lsd.parity_decomposed((Gp, Gp, Gp), 8, dev, arith=args.arith, dtype=args.dtype, shared_gpu=shared_gpu, dims=res["dims"])
     else:
         order = args.mode
         nx = ny = nz = N - 1
@@ -328,6 +332,16 @@ def main() -> None:
 
     src_now = kernel_sources_fingerprint()
 
+    # the roofline "also against a measured device-copy bandwidth" -- a 1 GiB streaming copy (16 bytes per lane
+    # and access) timed in THIS run on THIS device, bytes read + bytes written per second of the fastest of 5 passes
+    peak_measured = None
+    try:
+        g_ = ctypes.c_double(0.0)
+        if lib.lsf_copy_bandwidth(1 << 30, 5, ctypes.byref(g_)) == 0 and g_.value > 0:
+            peak_measured = g_.value
+    except Exception:  # noqa: BLE001
+        peak_measured = None
+
     def roofline(prof_, cells_per_sweep, size=None):
         if not prof_ or not prof_.get("sweeps"):
             return None
@@ -358,8 +372,14 @@ def main() -> None:
                     traffic = ent
             except Exception:  # noqa: BLE001
                 traffic = None
+        # what the memory system really moved: counter bytes per sweep / the kernel's time in THIS run (fabric requests of the L2s;
+        # Infinity-Cache hits are counted, MI355X_MICROARCH.md) -- against the vendor peak and against the copy measured above
+        hbm_meas = traffic / per_sweep_s / 1e9 if traffic else None
         return {
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "peak_measured": peak_measured, "frac_of_measured": (ach / peak_measured) if peak_measured else None,
+            "hbm_measured_GBps": hbm_meas, "hbm_measured_frac_of_peak": (hbm_meas / HBM_PEAK_GBS) if hbm_meas else None,
+            "hbm_measured_frac_of_peak_measured": (hbm_meas / peak_measured) if hbm_meas and peak_measured else None,
             "traffic": traffic / lps if traffic else None, "kernel": kernel, "launches_per_sweep": lps,
             "avg_launch_us": per_sweep_s / lps * 1e6,
             "algorithmic_bytes_per_launch": cells_per_sweep * bytes_per_cell / lps,
@@ -367,7 +387,9 @@ def main() -> None:
             **({"counters_stale": stale} if stale else {}),
             "note": f"achieved = {bytes_per_cell:.0f} B x (N-2)^3 cells / HIP-event time of the sweep kernel launch(es) of one sweep; "
                     "traffic = measured HBM bytes per launch (per sweep / launches per sweep) from the rocprofv3 PMC "
-                    "passes summarised in profiles/, null if not collected for this size",
+                    "passes summarised in profiles/, null if not collected for this size; peak_measured = a 1 GiB streaming device "
+                    "copy timed in this run (read + written bytes per second), frac_of_measured = achieved / that; hbm_measured_GBps "
+                    "= traffic per sweep / this run's kernel time per sweep (what the memory system moved, re-reads included)",
         }
 
     per_gpu_cells_per_sweep = cells_total / K / world
@@ -400,6 +422,8 @@ def main() -> None:
     }
     if world > 1:
         out["rccl_ranks"] = _rccl_ranks(dist)  # world size as the RCCL backend reports it
+    if res is not None:
+        out["parity"] = headline_parity
     if not f32 and args.arith == "fast":
         # how long the FAST arithmetic of `value` stays within north_star's 1e-10 RMS of the reference's field, per BASELINE
         # configuration (profiles/micro/fast_valid.py on the GPU; STRICT holds it for any number of sweeps)
@@ -560,17 +584,36 @@ def main() -> None:
                 del f, nb, sb
             dtm = times[KM]
             slope = (times[KM] - times[KM0]) / (KM - KM0)
+            # Bytes of ONE iteration on the band, from the band kernels' own arguments (csrc/lsf_minmax_band.hpp, compulsory bytes per
+            # list cell and launch; on entry the list IS the band):
+            #   start pass  k_minmax_band<0>   A 8 r, L 4 r, nb 6 x 4 r, isband 1 w, curv 8 w, down 3 x 8 w, X 8 w            = 77
+            #   fix visit   k_minmax_band_fix  isband 1 r, nb 24 r, A 8 r, curv 8 r, down 24 r, L 4 r, X 8 r (exact ordering)  = 77
+            #   RMS pass    k_minmax_band<2>   A 8 r, isband 1 r, X 8 r                                                         = 17
+            # (neighbour gathers re-read A / X: no new bytes; further fix passes touch stamped chunks only and are not counted:
+            # a lower bound of what moves, so the fraction printed cannot be flattered by re-reads)
+            per_cell = (77.0 + 77.0 + 17.0) if order_ == "gs" else (77.0 + 17.0)
+            list_cells = band * float(N) ** 3
+            slope_pos = max(slope, 1e-12)
+            band_gbps = list_cells * per_cell / slope_pos / 1e9
             mm[order_] = {"ms_per_iteration": dtm / KM * 1e3, "iterations_per_call": KM, "points_per_s": float(N) ** 3 * KM / dtm,
-                          "algorithmic_GBps": 16.0 * float(N) ** 3 * KM / dtm / 1e9,
-                          "frac_of_hbm_peak": 16.0 * float(N) ** 3 * KM / dtm / 1e9 / HBM_PEAK_GBS,
+                          "ms_per_iteration_10": times[KM0] / KM0 * 1e3,
+                          "band_cells": list_cells, "band_bytes_per_cell_and_iteration": per_cell,
+                          "band_GBps": band_gbps, "frac_of_hbm_peak": band_gbps / HBM_PEAK_GBS,
+                          "frac_of_peak_measured": (band_gbps / peak_measured) if peak_measured else None,
+                          "dense_equivalent_GBps": 16.0 * float(N) ** 3 * KM / dtm / 1e9,
                           "ms_per_additional_iteration": slope * 1e3, "ms_per_call_overhead": (times[KM0] - KM0 * slope) * 1e3,
                           "band_fraction": band}
         mm["note"] = ("min/max-flow iteration at the same size (set3d.f90:394-462), narrow band = |phi| < 4.1 dx of an exact two-sphere "
                       "distance; gs = the reference's (+,+,+) raster order reproduced exactly, jacobi = double-buffered.  Default executor: "
                       "on the band only (list of band cells built once per call, compact arrays, the field written once at the end): the "
-                      "cost follows band_fraction, so algorithmic_GBps -- 16 B per GRID point per iteration, the dense accounting of "
-                      "SURVEY.md 8d -- can exceed the HBM peak; ms_per_iteration = one call of iterations_per_call iterations, list build "
-                      "and the final narrowBand pass included (ms_per_call_overhead), / iterations_per_call")
+                      "cost follows band_fraction.  band_GBps = band_cells x band_bytes_per_cell_and_iteration (compulsory bytes of the "
+                      "start pass, ONE fix visit -- exact ordering -- and the RMS pass, from the kernels' own arguments) / "
+                      "ms_per_additional_iteration; frac_of_hbm_peak is that against 8 TB/s (a few small launches and grid barriers per "
+                      "iteration: latency, not bandwidth, sets the time).  dense_equivalent_GBps = 16 B per GRID point per iteration, the "
+                      "accounting of SURVEY.md 8d for an executor that streams the whole grid: a rate of work done, not of bytes moved "
+                      "(no fraction is quoted for it).  ms_per_iteration = one call of iterations_per_call iterations, list build and "
+                      "the final narrowBand pass included (ms_per_call_overhead), / iterations_per_call; ms_per_iteration_10 = the "
+                      "same for a 10-iteration call (the figure of rounds 1-4)")
         out["minmax"] = mm
 
     failed = False
@@ -606,10 +649,17 @@ def main() -> None:
                                 "n_gpus": world, "value": r["cells_total"] / sec, "unit": "cell-updates/s",
                                 "ms_per_step": sec / K * 1e3, "roofline": _job_roofline(r["cells_total"] / sec, world, BYTES_PER_CELL_UPDATE),
                                 "rccl_ranks": _rccl_ranks(dist), "transport": (dist.get_backend() if dist.is_initialized() else "none"),
-                                "note": note})
+                                "parity": state.get("parity_td"), "note": note})
                 torch.cuda.empty_cache()
 
             dims = lsd.default_dims(world)
+            # evidence before numbers: the decomposed sweep of THIS job (same ranks, same transport, same decomposition) against rank 0's
+            # single-domain sweep, on a grid small enough to compare as a whole; attached to every entry of the path (collective call)
+            Gp = 64 if N < 128 else 256
+            par = lsd.parity_decomposed((Gp, Gp, Gp), 8, dev, arith=args.arith, shared_gpu=shared_gpu, dims=dims,
+                                        sabotage=os.environ.get("LSF_BENCH_PARITY_SABOTAGE") == "1")
+            state["parity_td"] = par
+            torch.cuda.empty_cache()
             one(tuple(d * N for d in dims), "weak", f"every rank owns a {N}^3-point block")
             for G in ((96,) if N < 128 else (256, 512, 1024)):  # north_star: fixed 256^3, 512^3, 1024^3 at 1, 2, 4, 8 GPUs
                 if all(G // d >= 12 for d in dims):
@@ -645,6 +695,11 @@ def main() -> None:
             decomposed = {"entries": entries, "error": repr(e)[:300]}
             failed = True
     if decomposed is not None:
+        # an entry whose in-run parity record says "not the single-domain field" makes the job fail -- after the line is printed
+        bad = [e.get("path", "?") for e in decomposed.get("entries", []) if isinstance(e.get("parity"), dict) and not e["parity"].get("ok")]
+        if bad:
+            decomposed["parity_failed"] = bad
+            failed = True
         out["decomposed"] = decomposed
         # N > 1: the headline is a path that COMMUNICATES -- the weak-scaling block-decomposed Jacobi sweep over RCCL (every rank a
         # --size^3 block, 3-cell halos per sweep) -- not N replicas, which scale linearly by construction and say nothing about the
@@ -671,6 +726,7 @@ def main() -> None:
                                          "note": "per GPU, from the headline's own value: 505 fp64 flop per cell as written in subs.f90; the "
                                                  "Jacobi ordering needs 259 operations per cell in the cheapest form found (DESIGN.md 4.2)"}
             out["headline_path"] = "decomposed-jacobi-weak"
+            out["parity"] = weak.get("parity")
             out["config"]["workload"] = (f"WENO5 HJ reinit sweep (weno+Godunov+Euler, BC, RMS), global grid {weak['global_grid']} fp64 split "
                                          f"{weak['dims']}, local block {weak['local_block']} points, synthetic two-sphere phi0 (SURVEY.md 8d), HBM-resident")
             out["config"]["grid"] = weak["global_grid"]
@@ -690,6 +746,8 @@ def main() -> None:
         dist.destroy_process_group()
     if watchdog is not None:
         watchdog.cancel()
+    if rank == 0 and isinstance(out.get("parity"), dict) and not out["parity"].get("ok"):
+        failed = True  # the headline's own parity record (mode jacobi, N > 1)
     if failed:
         sys.exit(3)
 
@@ -772,11 +830,53 @@ def _slab_entries(world, G, K, W, arith, devices_of=None):
                         "roofline": _job_roofline(val, len(set(devs)), BYTES_PER_CELL_UPDATE), "call_s": call_s,
                         "blocks_per_slab": v[1].value, "finegrained": bool(v[2].value),
                         "equal_to_first_entry": bool(np.array_equal(a, first)),
+                        "parity": _parity_one_process(devs, 64 if G < 128 else 256, 16, arith, order="gs"),
                         "note": "reference-equal ordering (bit-identical to lsf_reinit on one device); value = cell-updates of the K "
                                 "sweeps / the longest of the slabs' launches (device events)"})
         except Exception as e:  # noqa: BLE001
             out.append({"path": SLAB_PATH, "ordering": "gs", "n_gpus": nd, "value": None, "error": repr(e)[:300]})
     return out
+
+
+_PARITY_SINGLE = {}  # (G, sweeps, arith, order) -> (field, rms) of the single-device run the one-process entries are compared with
+
+
+def _parity_one_process(devs, G, sweeps, arith, order="jacobi", transport="peer"):
+    """In-run evidence for an entry of the one-process drivers (lsf_reinit_multi: blocks of the Jacobi ordering, z slabs of the exact
+    ordering): `sweeps` sweeps of a G^3 two-sphere field on `devs` against the same sweeps by lsf_reinit on ONE device (the call site
+    both stand in for: set3d.f90:308) -- the field by SHA-256, the RMS trace element by element (exact ordering: equal; Jacobi
+    blocks: block sums added in rank order against one fixed-order sum, relative 1e-11).  Outside every timed region."""
+    import hashlib
+
+    import numpy as np
+
+    import levelsetfortran_amd as lsf
+    from levelsetfortran_amd import fields
+
+    try:
+        n = G - 1
+        key = (G, sweeps, arith, order)
+        if key not in _PARITY_SINGLE:
+            phi0, dx = fields.two_sphere_phi0((G, G, G))
+            a = phi0.copy(order="F")
+            r1 = lsf.reinit(a, None, None, n, n, n, sweeps - 1, dx, fields.reinit_step(dx), tol=0.0, order=order, arith=arith)
+            _PARITY_SINGLE.clear()  # one 134 MB field at a time
+            _PARITY_SINGLE[key] = (a, list(r1.rms), phi0, dx)
+        want, rms1, phi0, dx = _PARITY_SINGLE[key]
+        got = phi0.copy(order="F")
+        kw = {} if order == "gs" else {"transport": transport}
+        r = lsf.reinit_multi(got, n, n, n, sweeps - 1, dx, fields.reinit_step(dx), list(devs), tol=0.0, arith=arith, order=order, **kw)
+        sha = lambda f: hashlib.sha256(f.reshape(-1, order="F").tobytes()).hexdigest()  # noqa: E731
+        field_ok = sha(got) == sha(want)
+        rtol = 0.0 if order == "gs" else 1.0e-11
+        worst = max((abs(x - y) / abs(y) if y else abs(x - y)) for x, y in zip(r.rms, rms1)) if r.rms else 0.0
+        trace_ok = r.count == sweeps and len(r.rms) == len(rms1) and worst <= rtol
+        return {"ok": bool(field_ok and trace_ok), "field_sha_equal": bool(field_ok), "rms_trace_equal": bool(trace_ok),
+                "rms_trace_max_rel_diff": worst, "rms_trace_rtol": rtol, "grid": [G, G, G], "sweeps": sweeps, "devices": list(devs),
+                "arith": arith, "ordering": order, "max_abs_field_diff": float(np.abs(got - want).max()),
+                "against": "lsf_reinit on one device, same field and sweeps, outside the timed region"}
+    except Exception as e:  # noqa: BLE001
+        return {"ok": False, "error": repr(e)[:300]}
 
 
 def _rccl_ranks(dist):
@@ -848,10 +948,12 @@ def _single_process_entries(lib, world, G, K, W, arith, transports=("peer",), si
                         "rccl_ranks": rr.value, "value": val, "unit": "cell-updates/s", "ms_per_step": sec / K * 1e3,
                         "roofline": _job_roofline(val, nd, BYTES_PER_CELL_UPDATE),
                         "host_enqueue_ms_per_step": he.value / K * 1e3, "host_calls_ms_per_step": hc.value / K * 1e3,
+                        "parity": None,  # filled in below, after the blocks of the timed run have been released
                         "note": "the call returns after the last sweep has finished on every device (the run includes its own "
                                 "thread start-up and final synchronisation)"})
         finally:
             _lib.check(lib.lsf_multi_destroy(M))
+        out[-1]["parity"] = _parity_one_process(list(range(nd)), 64 if G < 128 else 256, 8, arith, order="jacobi", transport=tp)
 
     for nd, tp in [(c, t) for t in transports for c in counts]:
         try:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSF_VERSION 106 /* 0.1.6: no new entry points; the argument block of the exact-ordering kernels no longer carries experiment fields */
+#define LSF_VERSION 106 /* 0.1.6: lsf_copy_bandwidth (measurement aid); the argument block of the exact-ordering kernels no longer carries experiment fields */
 
 /* ---- return codes ---------------------------------------------------------------------- */
 #define LSF_OK 0
@@ -83,6 +83,11 @@ int lsf_release_workspace(void);
  * tile image of rows_z + 6 planes) can address every point of a tile on an (nx, ny) grid; the kernels test the same expression. */
 int lsf_skew_wide_fits(int nx, int ny, int rows_z);
 int lsf_profile(int enable);
+/* Measurement aid (bench.py "roofline.peak_measured", SURVEY.md section 8d: the roofline "also against a measured device-copy
+ * bandwidth"): copies `bytes` bytes (>= 1 MiB, a multiple of 16) between two fresh device buffers reps + 1 times with a
+ * streaming kernel (16 bytes per lane and access) and returns the rate of the fastest timed pass in GB/s, counting the bytes
+ * read AND the bytes written.  No reference counterpart. */
+int lsf_copy_bandwidth(size_t bytes, int reps, double *gbps);
 int lsf_profile_get(double *sweep_kernel_ms, double *bc_ms, double *finish_ms,
                     long long *sweep_kernel_launches, int *sweeps);
 /* name of the sweep kernel the last profiled call launched (the exact ordering picks its tile shape by

@@ -50,6 +50,7 @@ SIGNATURES = {
     "lsf_release_workspace": (c_int, []),
     "lsf_skew_wide_fits": (c_int, [c_int, c_int, c_int]),
     "lsf_profile": (c_int, [c_int]),
+    "lsf_copy_bandwidth": (c_int, [ctypes.c_size_t, c_int, POINTER(c_double)]),
     "lsf_profile_kernel": (ctypes.c_char_p, []),
     "lsf_profile_get": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_double),
                                 POINTER(ctypes.c_longlong), POINTER(c_int)]),

@@ -981,6 +981,50 @@ int lsf_set_device(int device)
 // of skew_tile's buffer descriptor, evaluated on the host: tests/test_host_logic.py)
 int lsf_skew_wide_fits(int nx, int ny, int rows_z) { return sk_wide_image_fits((long)(nx + 1) * (ny + 1), rows_z) ? 1 : 0; }
 
+int lsf_copy_bandwidth(size_t bytes, int reps, double* gbps)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!gbps || reps < 1 || bytes < (size_t)(1 << 20) || bytes % 16) return fail(LSF_ERR_INVALID, "lsf_copy_bandwidth: bytes >= 1 MiB, a multiple of 16; reps >= 1");
+    uint4 *a = nullptr, *b = nullptr;
+    HIPCHK(hipMalloc((void**)&a, bytes));
+    if (hipMalloc((void**)&b, bytes) != hipSuccess) {
+        (void)hipFree(a);
+        return fail(LSF_ERR_HIP, "lsf_copy_bandwidth: out of device memory");
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float best = 0.f;
+    rc = LSF_OK;
+    do {
+        if (hipMemset(a, 0x3c, bytes) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+            rc = fail(LSF_ERR_HIP, "lsf_copy_bandwidth: set-up failed");
+            break;
+        }
+        const long n16 = (long)(bytes / 16);
+        const dim3 grid((unsigned)std::min<long>((n16 + 1023) / 1024, 256L * 16)); // 16 blocks of 256 lanes per CU, 4 accesses per lane and trip
+        for (int r = 0; r <= reps; ++r) { // the first pass warms up (page tables, clocks) and is not timed
+            (void)hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, 0, (const uint4*)a, b, n16);
+            (void)hipEventRecord(e1, 0);
+            if (hipEventSynchronize(e1) != hipSuccess) {
+                rc = fail(LSF_ERR_HIP, "lsf_copy_bandwidth: the copy kernel failed");
+                break;
+            }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (r > 0 && ms > 0.f && (best == 0.f || ms < best)) best = ms;
+        }
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    if (rc) return rc;
+    if (best <= 0.f) return fail(LSF_ERR_HIP, "lsf_copy_bandwidth: no pass was timed");
+    *gbps = 2.0 * (double)bytes / (best * 1e-3) / 1e9; // bytes read + bytes written per second of the fastest pass
+    return LSF_OK;
+}
+
 int lsf_profile(int enable)
 {
     g_prof.on = enable != 0;

@@ -731,6 +731,20 @@ static __global__ __launch_bounds__(RED_T) void k_accumulate(const double* __res
     if (threadIdx.x == 0) *accum += tot;
 }
 
+// Measurement aid (lsf_copy_bandwidth, bench.py "roofline.peak_measured"): a streaming copy, 16 bytes per lane and access, four
+// accesses in flight per lane -- the denominator SURVEY.md section 8d asks for next to the vendor's 8 TB/s ("also against a measured
+// device-copy bandwidth").  Nothing of the hot path calls it.
+static __global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16)
+{
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
 // =============================================================================================
 // narrowBand, subs.f90:178-207
 // =============================================================================================

@@ -525,3 +525,63 @@ def bench_weak_scaling(N: int, K: int, W: int, device, arith: str = "fast", dtyp
     world = dist.get_world_size() if dist.is_initialized() else 1
     dims = default_dims(world)
     return bench_decomposed(tuple(d * N for d in dims), K, W, device, arith=arith, dtype=dtype, shared_gpu=shared_gpu, dims=dims)
+
+
+def parity_decomposed(global_pts, sweeps: int, device, arith: str = "fast", dtype: str = "f64", shared_gpu: bool = False, dims=None,
+                      rtol: float = 1.0e-11, sabotage: bool = False):
+    """Evidence, inside the job that is being timed, that the decomposed sweep IS the single-domain sweep (the call site the
+    decomposition stands in for: set3d.f90:308).  Every rank runs `sweeps` sweeps of its block of a global_pts grid through
+    DistributedReinit.run (halo exchange, rims, BC, one reduction per window: the timed path), rank 0 runs the same sweeps on the
+    whole grid on its own GPU (lsf_reinit_device, Jacobi ordering, same arithmetic) and compares
+      * the field: SHA-256 of every rank's OWNED points against the same points of the single-domain field, and
+      * the RMS trace (block sums added in rank order against one fixed-order sum: relative tolerance `rtol`).
+    Never inside a timed region.  Returns the record on rank 0, None elsewhere; collective (every rank must call it).
+    sabotage (test aid, bench.py LSF_BENCH_PARITY_SABOTAGE=1): the last rank moves ONE owned value by one unit in the last place
+    before the comparison -- the record must say so and the job must fail."""
+    import hashlib
+
+    import torch
+    import torch.distributed as dist
+
+    from . import fields
+    from .levelset import reinit
+
+    live = dist.is_initialized()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if live else (1, 0)
+    dims = tuple(dims) if dims is not None else default_dims(world)
+    gpts = tuple(int(g) for g in global_pts)
+    n = tuple(g - 1 for g in gpts)
+    b = make_block(rank, dims, n)
+    be = HipBackend(device, arith, host_staging=shared_gpu, dtype=dtype)
+    rng = tuple((g, g + e) for g, e in zip(b.g0, b.ext))
+    phi, dx = fields.two_sphere_phi0_device(gpts, device, ranges=rng)
+    phi = phi.to(be.dtype)
+    h = fields.reinit_step(dx)
+    out, nsw, rms = DistributedReinit(be, b, dx, h).run(phi, sweeps - 1, tol=0.0)
+
+    def digest(t, ext, box):
+        v = t.reshape(ext[2], ext[1], ext[0])[box[2][0]:box[2][1], box[1][0]:box[1][1], box[0][0]:box[0][1]]
+        return hashlib.sha256(v.contiguous().cpu().numpy().tobytes()).hexdigest()
+
+    if sabotage and rank == world - 1:
+        ol = b.own_local
+        at = (ol[0][0] + 1) + b.ext[0] * ((ol[1][0] + 1) + b.ext[1] * (ol[2][0] + 1))
+        out[at:at + 1] = torch.nextafter(out[at:at + 1], out[at:at + 1] + 1)
+    mine = digest(out, b.ext, b.own_local)
+    got = [mine]
+    if live and world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, mine)
+    if rank != 0:
+        return None
+    whole, _ = fields.two_sphere_phi0_device(gpts, device)
+    whole = whole.to(be.dtype)
+    rep = reinit(whole, None, None, n[0], n[1], n[2], sweeps - 1, dx, h, tol=0.0, order="jacobi", arith=arith)
+    want = [digest(whole, gpts, make_block(r, dims, n).own) for r in range(world)]
+    field_ok = got == want
+    worst = max((abs(a - c) / abs(c) if c else abs(a - c)) for a, c in zip(rms, rep.rms)) if rms else 0.0
+    trace_ok = nsw == rep.count == sweeps and len(rms) == len(rep.rms) and worst <= rtol
+    return {"ok": bool(field_ok and trace_ok), "field_sha_equal": bool(field_ok), "rms_trace_equal": bool(trace_ok),
+            "rms_trace_max_rel_diff": worst, "rms_trace_rtol": rtol, "grid": list(gpts), "dims": list(dims), "sweeps": sweeps,
+            "ranks": world, "arith": arith, "dtype": dtype, "blocks_differing": [r for r in range(world) if got[r] != want[r]],
+            "against": "rank 0's single-domain Jacobi sweep of the same grid and sweeps (lsf_reinit_device), outside the timed region"}

@@ -135,7 +135,33 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     # no RCCL rank; on a node with a GPU per rank rccl_ranks = the world size as the RCCL backend reports it)
     for e in weak + strong:
         assert 0 < e["roofline"]["frac"] < 1 and e["roofline"]["peak"] == 2 * 8000.0 and e["rccl_ranks"] == 0 and e["transport"] == "gloo"
+        # every decomposed entry carries the in-run evidence that its path IS the single-domain sweep (same ranks,
+        # transport and decomposition on a 64^3 grid here, 256^3 in a real job: field by SHA-256 per owned block, RMS trace)
+        par = e["parity"]
+        assert par["ok"] is True and par["field_sha_equal"] is True and par["rms_trace_equal"] is True and par["blocks_differing"] == []
+        assert par["grid"] == [64, 64, 64] and par["ranks"] == 2 and par["dims"] == [1, 1, 2] and par["sweeps"] == 8
     assert d["rccl_ranks"] == 0
+    assert d["parity"]["ok"] is True and "parity_failed" not in d["decomposed"]  # the headline is the weak entry: its record on top
+
+
+def test_bench_parity_mismatch_fails_the_job_after_the_line():
+    """a decomposed field that is NOT the single-domain field (one owned value of the last rank moved by one unit in the last place:
+    LSF_BENCH_PARITY_SABOTAGE) must show in the record of every entry of the path and end the job non-zero -- after the line"""
+    import json
+    import subprocess
+
+    env = dict(os.environ, LSF_BENCH_SHARED_GPU="1", LSF_BENCH_PARITY_SABOTAGE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "96", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    par = d["parity"]
+    assert par["ok"] is False and par["field_sha_equal"] is False and par["rms_trace_equal"] is True and par["blocks_differing"] == [1]
+    assert d["decomposed"]["parity_failed"]
 
 
 def test_bench_strong_scaling_headline_on_one_gpu():
@@ -156,6 +182,9 @@ def test_bench_strong_scaling_headline_on_one_gpu():
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 3 - cells) < 1e-6 * cells
     assert d["roofline"]["peak"] == 4 * 8000.0 and abs(d["roofline"]["achieved"] - d["value"] * 24.0 / 1e9) < 1e-6 * d["roofline"]["achieved"]
     assert d["rccl_ranks"] == 0  # gloo rehearsal
+    par = d["parity"]  # the headline's own evidence: 4 ranks, 1 x 2 x 2, against rank 0's single-domain sweep
+    assert par["ok"] is True and par["field_sha_equal"] is True and par["rms_trace_equal"] is True
+    assert par["ranks"] == 4 and par["dims"] == [1, 2, 2] and par["grid"] == [64, 64, 64]
 
 
 def test_sumsq_bracket_equals_per_call_reduction():

@@ -254,3 +254,16 @@ def test_bench_single_process_entries_helper(lsf):
     assert len(ent) == 1 and ent[0]["n_gpus"] == 1 and ent[0]["global_grid"] == [64, 64, 64] and ent[0]["value"] > 0
     assert ent[0]["transport"] == "peer" and ent[0]["rccl_ranks"] == 0 and 0 < ent[0]["roofline"]["frac"] < 1
     assert ent[0]["host_calls_ms_per_step"] > 0
+    # the in-run parity record of the entry: lsf_reinit_multi on the entry's devices against lsf_reinit
+    par = ent[0]["parity"]
+    assert par["ok"] is True and par["field_sha_equal"] is True and par["rms_trace_equal"] is True and par["grid"] == [64, 64, 64]
+    # ... and it can say no: four blocks on device 0 compared with a single-domain field of ANOTHER arithmetic
+    bench._PARITY_SINGLE.clear()
+    good = bench._parity_one_process([0, 0, 0, 0], 64, 4, "fast")
+    assert good["ok"] is True and good["max_abs_field_diff"] == 0.0
+    key = (64, 4, "fast", "jacobi")
+    a, rms, phi0, dx = bench._PARITY_SINGLE[key]
+    a[5, 6, 7] = np.nextafter(a[5, 6, 7], 2.0)
+    badrec = bench._parity_one_process([0, 0], 64, 4, "fast")
+    assert badrec["ok"] is False and badrec["field_sha_equal"] is False and badrec["rms_trace_equal"] is True
+    bench._PARITY_SINGLE.clear()

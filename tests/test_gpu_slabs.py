@@ -172,6 +172,9 @@ def test_bench_slab_entries_helper_and_child(lsf):
         assert e.get("error") is None and e["value"] > 0 and e["ordering"] == "gs" and e["equal_to_first_entry"]
         assert 0 < e["roofline"]["frac"] < 1 and e["roofline"]["peak"] == 8000.0  # one physical device
         assert e["blocks_per_slab"] > 0 and e["call_s"] > e["ms_per_step"] * 5e-3
+        par = e["parity"]  # in-run evidence: the slabs' field and RMS trace ARE lsf_reinit's (exact ordering: equal, no tolerance)
+        assert par["ok"] is True and par["field_sha_equal"] is True and par["rms_trace_equal"] is True and par["rms_trace_rtol"] == 0.0
+        assert par["ordering"] == "gs" and par["grid"] == [64, 64, 64] and par["sweeps"] == 16
     child = bench._slab_entries_in_a_child(1, 64, 3, 1, "strict")
     assert len(child) == 1 and child[0].get("error") is None and child[0]["n_gpus"] == 1 and child[0]["arith"] == "strict"
 
