@@ -1001,7 +1001,11 @@ int lsf_copy_bandwidth(size_t bytes, int reps, double* gbps)
             break;
         }
         const long n16 = (long)(bytes / 16);
-        const dim3 grid((unsigned)std::min<long>((n16 + 1023) / 1024, 256L * 16)); // 16 blocks of 256 lanes per CU, 4 accesses per lane and trip
+        if (n16 / 256 + 1 > 0x7fffffffL) {
+            rc = fail(LSF_ERR_INVALID, "lsf_copy_bandwidth: at most 2^31 blocks of 4 KB");
+            break;
+        }
+        const dim3 grid((unsigned)((n16 + 255) / 256)); // one 16-byte vector per lane
         for (int r = 0; r <= reps; ++r) { // the first pass warms up (page tables, clocks) and is not timed
             (void)hipEventRecord(e0, 0);
             hipLaunchKernelGGL(k_copy16, grid, dim3(256), 0, 0, (const uint4*)a, b, n16);

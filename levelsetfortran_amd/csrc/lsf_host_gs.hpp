@@ -54,19 +54,6 @@ int gs_schedule()
     return -1; // unset: dataflow on skewed tiles
 }
 
-// Hand-off finer than a tile in the dataflow launch (lsf_skew.hpp, HALF): three lanes per cell, 2 x 2 wavefronts, on grids where a
-// sweep is a chain of dependent hand-offs and not a question of throughput -- below LSF_HALF_BELOW cells across.
-// LSF_GS_HALF = 0 / 1: never / wherever the tile shape has it (measurement aid; bit-identical either way).
-#ifndef LSF_HALF_BELOW
-#define LSF_HALF_BELOW 384
-#endif
-bool gs_half(int cells_across, int wy, int wz, int by, int ta)
-{
-    if (!(by == 5 && wy == 2 && wz == 2 && ta == 16)) return false;
-    if (const char* e = getenv("LSF_GS_HALF")) return atoi(e) != 0;
-    return cells_across < LSF_HALF_BELOW;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Exact-GS reinit: the dataflow launch (default) and the slot-synchronous schedules with overlapped sweeps.
 // Slot schedules: one launch per time slot; a slot holds the tile hyperplane P = slot - start[g] of every sweep g in
@@ -104,11 +91,6 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         nyc = by * wy, nzc = 4 * wz; // rows of a tile in y and z
         ta = gs_skew_ta(std::min(std::min(nx, ny), nz) - 1, wy, wz, by);
     }
-#ifndef LSF_EXPERIMENTS
-    const bool half = persist && gs_half(std::min(std::min(nx, ny), nz) - 1, wy, wz, by, ta);
-#else
-    const bool half = false; // (the experiment builds' marching-step hook and the HALF instances do not combine)
-#endif
     // Dataflow launch: the kernel marches along ITS x axis; run it on the x <-> y transposed field so that the march axis
     // is the reference's y, the axis the raster cycle flips in six of its eight transitions (a flip of the march axis
     // spaces two sweeps by n / 16 time slots, a flip of a cross-section axis by n / 16 + its number of tiles: 70 instead of
@@ -329,12 +311,7 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
                 else hipLaunchKernelGGL((k_reinit_gs_persist<32, 2, 2, 5, false>), grid, dim3(256), 0, st, fa);
             } else
 #endif
-            if (half) { // the hand-off finer than a tile (small grids; lsf_skew.hpp)
-#ifndef LSF_EXPERIMENTS
-                if (strict) hipLaunchKernelGGL((k_reinit_gs_persist<16, 2, 2, 5, true, true>), grid, dim3(256), 0, st, fa);
-                else hipLaunchKernelGGL((k_reinit_gs_persist<16, 2, 2, 5, false, true>), grid, dim3(256), 0, st, fa);
-#endif
-            } else {
+            {
                 LSF_SK_SHAPES(LSF_LAUNCH_DF, wy, wz, by);
             }
 #undef LSF_LAUNCH_DF
@@ -483,8 +460,8 @@ int reinit_slot_core(double* d_phi, const double* d_phiS_in, int nx, int ny, int
         g_prof.bc_ms = g_prof.finish_ms = 0;
         g_prof.sweeps = nsw;
         g_prof.sweep_launches = launches;
-        if (skew) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "%s<%d,%d,%d,%d,%s%s>", !slots_loop ? "k_reinit_gs_persist" : "k_reinit_gs_skew",
-                           ta, wy, wz, by, strict ? "true" : "false", (half && !slots_loop) ? ",true" : "");
+        if (skew) snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "%s<%d,%d,%d,%d,%s>", !slots_loop ? "k_reinit_gs_persist" : "k_reinit_gs_skew",
+                           ta, wy, wz, by, strict ? "true" : "false");
         else snprintf(g_prof.kernel_buf, sizeof g_prof.kernel_buf, "k_reinit_gs_box<%d,%d,%s>", ta, nyc, strict ? "true" : "false");
         g_prof.kernel = g_prof.kernel_buf;
     }

@@ -731,18 +731,16 @@ static __global__ __launch_bounds__(RED_T) void k_accumulate(const double* __res
     if (threadIdx.x == 0) *accum += tot;
 }
 
-// Measurement aid (lsf_copy_bandwidth, bench.py "roofline.peak_measured"): a streaming copy, 16 bytes per lane and access, four
-// accesses in flight per lane -- the denominator SURVEY.md section 8d asks for next to the vendor's 8 TB/s ("also against a measured
-// device-copy bandwidth").  Nothing of the hot path calls it.
+// Measurement aid (lsf_copy_bandwidth, bench.py "roofline.peak_measured"): a streaming copy -- the denominator SURVEY.md section 8d
+// asks for next to the vendor's 8 TB/s ("also against a measured device-copy bandwidth").  One 16-byte vector per lane, non-temporal
+// load and store, a block per 4 KB: the fastest of the forms tried on this chip (profiles/micro/copy_bw.hip, 1 GiB: 6.5 TB/s read +
+// written; the same with plain accesses 6.2, grid-stride loops with four accesses in flight per lane 4.1-5.0, eight vectors per lane
+// 4.2-4.3, hipMemcpyAsync 5.4; read only 5.7, write only 6.9).  Nothing of the hot path calls it.
 static __global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16)
 {
-    const long stride = (long)gridDim.x * 256;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
-    }
-    for (; i < n16; i += stride) dst[i] = src[i];
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load((const v4u*)src + i), (v4u*)dst + i);
 }
 
 // =============================================================================================

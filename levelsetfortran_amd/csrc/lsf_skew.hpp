@@ -313,29 +313,11 @@ struct SkNoHook {
 #define LSF_SK_MID_PARAM
 #define LSF_SK_MID(t_)
 #endif
-//
-// HALF (dataflow launch, three lanes per cell, grids where a sweep is a chain of dependent hand-offs -- below ~384 cells across): a
-// hand-off finer than a tile.  A tile's downstream neighbours across y and z run ONE to THREE marching steps behind it (row b - d of
-// the same skew range is d cells ahead), so they need its first eight steps long before its last: in front of step 8 the tile stores
-// what those neighbours read of its steps 0..7 (the last three rows in y and in z, entries 3..10), drains them behind the next steps and
-// raises its flag to 1 (publish_half); the complete tile raises it to 2.  A consumer starts on flag >= 1 of its y / z upstream tiles
-// (2 of the tile before it in its own row bundle, whose LAST steps it reads), loads the upstream halo up to entry 10 (= producer step
-// 7), marches steps 0..8, and takes a second load stage -- entries 11..17, behind wait_upstream(1) = flag 2 -- in front of step 9.
-// wait_upstream(stage) returns 0 = abandon the tile, 1 = go on, 2 (stage 0 only) = go on and the upstream tiles are complete
-// already: everything is loaded at once and the march is the plain one.  Same values, same order of operations: bit-identical.
-struct SkNoPublish {
-    __device__ __forceinline__ void operator()() const {}
-};
-#ifndef LSF_HALF_PUB_STEP
-#define LSF_HALF_PUB_STEP 10 // the first-half stores (issued in front of step 8) are waited for at the end of step PUB - 1, the flag follows
-#endif
-template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, bool PUSH = false, bool HALF = false, class WaitUp, class PubHalf = SkNoPublish LSF_SK_MID_TPARAM>
+template <int TA, int WY, int WZ, int BY, bool STRICT, bool SC1, bool PUSH = false, class WaitUp LSF_SK_MID_TPARAM>
 __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, const GsArgs& a, uint32_t packed, int g, int si, int sj,
-                                          int sk, const SkPre& pre, WaitUp&& wait_upstream, PubHalf publish_half = PubHalf{} LSF_SK_MID_PARAM)
+                                          int sk, const SkPre& pre, WaitUp&& wait_upstream LSF_SK_MID_PARAM)
 {
     static_assert(TA == 16 || (TA == 32 && BY == 5 && !PUSH), "tiles of 32 marching steps: three lanes per cell, single launch only");
-    static_assert(!HALF || (TA == 16 && BY == 5 && SC1 && !PUSH), "half-tile hand-off: dataflow launch, three lanes per cell");
-    static_assert(LSF_HALF_PUB_STEP >= 9 && LSF_HALF_PUB_STEP <= 15, "the first half is announced between steps 9 and 15");
     constexpr int CPN = TA / 16; // the loaders and the write back handle a row 16 entries at a time
     using T = SkTile<TA, WY, WZ, BY>;
     constexpr int NYT = T::NYT, NZT = T::NZT, W = T::W, NT = 64 * W;
@@ -478,10 +460,9 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     // odd entries per bundle row no longer cost separate scattered requests.
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));
     constexpr int AUX_SC1 = SYS ? 17 : (SC1 ? 16 : 0); // cache policy of the buffer instructions: sc1 = bit 4, sc0 = bit 0 (system scope: both)
-    const bool widex = !HALF && TA == 16 && (LSF_SKEW_WIDE == 2 || (LSF_SKEW_WIDE == 1 && BY == 16)) && deep && X0 - (NYT + NZT + 4) >= 0 && X0 + 22 <= nxi - 1 &&
+    const bool widex = TA == 16 && (LSF_SKEW_WIDE == 2 || (LSF_SKEW_WIDE == 1 && BY == 16)) && deep && X0 - (NYT + NZT + 4) >= 0 && X0 + 22 <= nxi - 1 &&
                        sk_wide_image_fits(sxy, NZT);
     bool loaded = true;
-    [[maybe_unused]] bool second_pending = false; // HALF: the upstream halo beyond entry 10 is still to come (second load stage in the march)
     auto load_wide = [&]() {
         const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(in_t), 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out_t, 0, 0x7fffffff, 0x00020000);
@@ -515,7 +496,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
 #pragma unroll
         for (int t = 0; t < NPS; ++t) ps[t] = ps_load(t);
         if constexpr (BY == 16) sk_lane_offsets1<T>(si, sj, sk, bc, cc, nj, nk, ox, oy, oz);
-        if (!wait_upstream(0)) {
+        if (!wait_upstream()) {
             loaded = false;
             return;
         }
@@ -600,20 +581,17 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
 #pragma unroll
         for (int t = 0; t < NPS; ++t) ps[t] = ps_load(t);
         if constexpr (BY == 16) sk_lane_offsets1<T>(si, sj, sk, bc, cc, nj, nk, ox, oy, oz);
-        const int up_state = wait_upstream(0);
-        if (!up_state) {
+        if (!wait_upstream()) {
             loaded = false;
             return;
         }
-        if constexpr (HALF) second_pending = up_state == 1; // the y / z upstream tiles have announced their first eight steps only
         // the running RMS sum of this tile column, left by the previous tile of the column (one of the upstream tiles):
         // requested now, used by thread 0 after the march (the dependent load used to sit between the tile's stores and its flag)
         if (tid == 0 && m != (NYT * fB + NZT * fC) / TA) colsum_prev = ldp(a.colsum + (long)gb * ncol + (tj + (long)a.nTj * tk));
         // ---- stage 2: what the upstream tiles of this sweep wrote (rows or entries outside the interior: the walls, from `in`)
 #pragma unroll
         for (int u = 0; u < NU; ++u, ++n_) {
-            // (HALF, second half pending: entries 2 .. 10 -- producer steps up to 7; the lanes beyond re-load entry 10)
-            const int r = min(T::YU0 + RPI * (u / CPN) + rsub, T::YD0 - 1), k = 2 + ((HALF && second_pending) ? min(xx, 8) : xx) + 16 * (u % CPN);
+            const int r = min(T::YU0 + RPI * (u / CPN) + rsub, T::YD0 - 1), k = 2 + xx + 16 * (u % CPN);
             const int2 e = rowtab[r];
             const int gi_r = gi_of(e, k);
             const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 1);
@@ -649,49 +627,6 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
     __syncthreads();
     LSF_PHASE(2);
 
-    // HALF, in front of step 8: the first eight steps of the rows the downstream tiles across y and z read (their upstream halo: the
-    // last three rows in y of every c, the last three in z of the other b), entries 3 .. 10, write-through like the write back (which
-    // stores them again with the rest of their rows: same values)
-    [[maybe_unused]] auto half_store = [&]() {
-        constexpr int NYE = 3 * NZT, NZE = 3 * (NYT - 3), NE = NYE + NZE, NI = (8 * NE + NT - 1) / NT;
-#pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int idx = tid + NT * u, q = idx >> 3, t = idx & 7;
-            int bq, cq;
-            if (q < NYE) {
-                cq = q / 3, bq = nj - 3 + (q - 3 * cq);
-            } else {
-                const int q2 = q - NYE, z3 = q2 / (NYT - 3);
-                cq = nk - 3 + z3, bq = q2 - (NYT - 3) * z3;
-            }
-            const bool ok = q < NE && bq >= 0 && bq < nj && cq >= 0 && cq < nk && (q < NYE || bq < nj - 3);
-            const int r = ok ? cq * NYT + bq : 0;
-            const int2 e = rowtab[r];
-            const int gi = e.y + (si > 0 ? t : -t);
-            if (ok && (unsigned)(gi - 1) <= (unsigned)(nx - 2)) stp(out_t + ((unsigned)(e.x >> 2) + (unsigned)gi), lds[T::core_at(r) + 3 + t]);
-        }
-    };
-    // HALF, in front of step 9 (the first step that reads an upstream halo entry beyond 10): the rest of the upstream halo, entries
-    // 11 .. 17, once the y / z upstream tiles are complete
-    [[maybe_unused]] auto second_load = [&]() -> bool {
-        if (!wait_upstream(1)) return false;
-        constexpr int NH = T::YD0 - T::YU0, NI = (8 * NH + NT - 1) / NT;
-        double v[NI];
-        int dst[NI];
-#pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int idx = min(tid + NT * u, 8 * NH - 1), r = T::YU0 + (idx >> 3), k = 11 + min(idx & 7, 6);
-            const int2 e = rowtab[r];
-            const int gi_r = e.y + (si > 0 ? k - 3 : 3 - k);
-            const bool fresh = ((unsigned)(gi_r - 1) <= (unsigned)(nx - 2)) & (bool)(e.x & 1);
-            dst[u] = T::HB + (r - T::NCORE) * T::RH + k;
-            v[u] = ldp((fresh ? (const double*)out_t : in_t) + ((unsigned)(e.x >> 2) + (unsigned)min(max(gi_r, 0), nx)));
-        }
-#pragma unroll
-        for (int u = 0; u < NI; ++u) lds[dst[u]] = v[u];
-        __syncthreads();
-        return true;
-    };
     if constexpr (BY == 5) {
         // ---- march: TA steps, every lane busy; the wavefronts of a tile meet after every step -----------------
         // (one instance, fully unrolled: a second instance without step masks for tiles whose every cell takes the WENO branch,
@@ -701,17 +636,6 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
                 LSF_SK_MID(t);
-                if constexpr (HALF) {
-#ifdef LSF_HALF_PROBE
-                    if (t == 8 && tid == 0) publish_half();
-#if LSF_HALF_PROBE == 1
-                    if (t == 9 && second_pending && !second_load()) return false;
-#endif
-#else
-                    if (t == 8) half_store();
-                    if (t == 9 && second_pending && !second_load()) return false;
-#endif
-                }
                 const bool active = (bool)((act_bits >> t) & 1u) && axis == 0;
                 double q[7];
 #pragma unroll
@@ -729,14 +653,7 @@ __device__ __forceinline__ bool skew_tile(SkShared<SkTile<TA, WY, WZ, BY>>& sm, 
                     const double dlt = newv - q[3];
                     acc = STRICT ? acc + dlt * dlt : __builtin_fma(dlt, dlt, acc);
                 }
-                // (HALF: every wavefront's first-half stores are at the memory side before the barrier, the flag follows it)
-#ifndef LSF_HALF_PROBE
-                if constexpr (HALF) if (t == LSF_HALF_PUB_STEP - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
                 __syncthreads();
-#ifndef LSF_HALF_PROBE
-                if constexpr (HALF) if (t == LSF_HALF_PUB_STEP - 1 && tid == 0) publish_half();
-#endif
             }
         }
     } else {
@@ -1078,7 +995,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
     const SkPre pre = sk_prefetch<TA, WY, WZ, BY>(a);
     __shared__ SkShared<SkTile<TA, WY, WZ, BY>> sm;
     skew_tile<TA, WY, WZ, BY, STRICT, false>(sm, a, packed, a.seg_g[seg], a.seg_sign[seg][0], a.seg_sign[seg][1], a.seg_sign[seg][2], pre,
-                                             [](int) { return 1; }); // every predecessor ran in an earlier launch
+                                             [] { return true; }); // every predecessor ran in an earlier launch
 }
 
 // Dataflow schedule: ONE launch per batch of sweeps, one block per tile.  The tiles of the batch form a list in slot
@@ -1091,15 +1008,9 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
 // is no deadlock whatever the dispatch order or the number of resident blocks; every spin is bounded (ctl[2] = 2 on
 // time-out).  A finished tile drains its write-through stores, raises its flag and counts itself into
 // plane_cnt[s][P]; the last tile of a hyperplane publishes planes_done[s] = P + 1.
-// HALF: the hand-off finer than a tile (skew_tile): tile_done holds 1 once a tile's first eight steps are announced, 2 once it is
-// complete (without HALF: 1 = complete).
-#ifndef LSF_HALF_WAVES
-#define LSF_HALF_WAVES 4 // wavefronts per SIMD the HALF instances are compiled for (the grids they run on do not fill the chip)
-#endif
-template <int TA, int WY, int WZ, int BY, bool STRICT, bool HALF = false>
-__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : LSF_WAVES16) : (WY == 2 && WZ == 2 ? (TA == 32 ? 2 : (HALF ? LSF_HALF_WAVES : (STRICT ? LSF_STRICT22_WAVES : 5))) : 1)))) void k_reinit_gs_persist(GsArgs a)
+template <int TA, int WY, int WZ, int BY, bool STRICT>
+__global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY == 16 ? (WY * WZ == 1 ? 1 : LSF_WAVES16) : (WY == 2 && WZ == 2 ? (TA == 32 ? 2 : (STRICT ? LSF_STRICT22_WAVES : 5)) : 1)))) void k_reinit_gs_persist(GsArgs a)
 {
-    constexpr int DONE = HALF ? 2 : 1; // value of a complete tile's flag
     using T = SkTile<TA, WY, WZ, BY>;
     __shared__ SkShared<T> sm;
     __shared__ int sh_task[8]; // packed tile, s | P << DF_SWEEP_BITS, go flag, raster signs of the sweep, go flag of stage 2
@@ -1116,7 +1027,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
         const int* const set_word = a.ctl + 4; // a word that is never 0 (host): stands in for an upstream tile that does not exist
         const int *w0 = set_word, *w1 = set_word, *w2 = set_word;
         unsigned long long t0 = 0;
-        int up_ready = 0; // 1: what the first marching steps need of the upstream tiles is there; 2: the upstream tiles are complete
+        bool up_ready = false;
         auto give_up = [&]() { // converged, NaN or time-out elsewhere: skip, and let the blocks still to come leave at once
             __hip_atomic_fetch_max(a.ticket, (int)a.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
@@ -1154,8 +1065,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                     // 2.600-2.602 ms per 512^3 sweep, STRICT 4.531-4.533 against 4.543-4.552: the upstream tiles are rarely done
                     // that early -- a sweep advances as a front -- but the look is free)
                     const int u0 = ld_flag(w0), u1 = ld_flag(w1), u2 = ld_flag(w2);
-                    // (the tile before this one in its row bundle, w0, hands over its LAST steps: complete or nothing)
-                    up_ready = ((u0 >= DONE) & (u1 != 0) & (u2 != 0)) ? (((u1 >= DONE) & (u2 >= DONE)) ? 2 : 1) : 0;
+                    up_ready = (u0 != 0) & (u1 != 0) & (u2 != 0);
                     // (the spacing of the sweep is first used HERE, behind the flag loads: computed in front of the loop it made the
                     // table load a round trip of its own between the order entry and the first look)
                     int h = swp.w;
@@ -1187,7 +1097,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 }
                 sh_task[3] = swp.x, sh_task[4] = swp.y, sh_task[5] = swp.z;
             }
-            sh_task[0] = (int)e.x, sh_task[1] = (int)e.y, sh_task[2] = go, sh_task[7] = up_ready;
+            sh_task[0] = (int)e.x, sh_task[1] = (int)e.y, sh_task[2] = go, sh_task[7] = up_ready ? 1 : 0;
         }
         __syncthreads();
         // wave-uniform values: keep them in scalar registers (an LDS read alone would make them look divergent)
@@ -1195,7 +1105,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
         const uint32_t packed = (uint32_t)uni(sh_task[0]);
         const int sP = uni(sh_task[1]);
         int go = uni(sh_task[2]);
-        const int upstream_seen = uni(sh_task[7]); // seen by thread 0 before the first load stage: nothing to wait for (1; 2: see up_ready)
+        const bool upstream_done = uni(sh_task[7]) != 0; // seen by thread 0 before the first load stage: nothing to wait for
         const int s = sP & (DF_BATCH - 1), P = (int)((unsigned)sP >> DF_SWEEP_BITS);
         if (go == 0) return;
         // the tile's own flag: its address is formed HERE and kept (scalar registers) -- formed behind the drain of the tile's stores
@@ -1209,9 +1119,8 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
         }
         const unsigned long long tsB = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
         // stage 2, called by skew_tile with its stage-1 loads in flight: condition (a) -- the upstream tiles of this sweep
-        // (stage 1, HALF only: called from the middle of the march for the second load stage -- the y / z upstream tiles complete)
-        auto wait_upstream = [&](int stage) -> int {
-            if (stage == 0 && upstream_seen) return upstream_seen; // (uniform over the block: no barrier needed either)
+        auto wait_upstream = [&]() -> bool {
+            if (upstream_done) return true; // (uniform over the block: no barrier needed either)
             if (tid == 0) {
                 int go2 = 1;
                 for (;;) {
@@ -1224,11 +1133,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                         give_up();
                         break;
                     }
-                    const bool full = (v1 >= DONE) & (v2 >= DONE);
-                    if (stage == 0 ? (v0 >= DONE) & (v1 != 0) & (v2 != 0) : full) {
-                        if (HALF && stage == 0 && full) go2 = 3;
-                        break;
-                    }
+                    if ((v0 != 0) & (v1 != 0) & (v2 != 0)) break;
                     if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
                         st_flag(a.ctl + 2, 2);
                         st_flag(a.ctl + 0, 1);
@@ -1241,11 +1146,8 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
             }
             // LDS hand-off of the verdict only: the stage-1 loads stay in flight across the barrier
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const int r = uni(sh_task[6]);
-            // (HALF, stage 1: thread 0 rewrites the word in the next call at the earliest -- a marching step and its barrier later)
-            return r == 2 ? 0 : (r == 3 ? 2 : 1);
+            return uni(sh_task[6]) == 1;
         };
-        [[maybe_unused]] auto publish_half = [&]() { __hip_atomic_store(my_flag, 1, __ATOMIC_RELAXED, LSF_FLAG_ST_SCOPE); };
         if (go == 1) {
 #ifdef LSF_EXPERIMENTS
             // LSF_PROBE_EARLY_FLAG = t: the tile raises its flag in front of marching step t, with nothing of it stored yet -- the
@@ -1254,22 +1156,17 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
             auto early = [&](int t) {
                 if (a.probe_early > 0 && t == a.probe_early && tid == 0) __hip_atomic_store(my_flag, 1, __ATOMIC_RELAXED, LSF_FLAG_ST_SCOPE);
             };
-            if (!skew_tile<TA, WY, WZ, BY, STRICT, true>(sm, a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream, SkNoPublish{}, early))
+            if (!skew_tile<TA, WY, WZ, BY, STRICT, true>(sm, a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream, early))
                 go = 2;
 #else
-            if constexpr (HALF) {
-                if (!skew_tile<TA, WY, WZ, BY, STRICT, true, false, true>(sm, a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream, publish_half))
-                    go = 2;
-            } else {
-                if (!skew_tile<TA, WY, WZ, BY, STRICT, true>(sm, a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream))
-                    go = 2;
-            }
+            if (!skew_tile<TA, WY, WZ, BY, STRICT, true>(sm, a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), uni(sh_task[5]), pre, wait_upstream))
+                go = 2;
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads(); // every wave of the tile has drained its stores (and left the LDS image)
         if (tid == 0 && go == 1) {
-            __hip_atomic_store(my_flag, DONE, __ATOMIC_RELAXED, LSF_FLAG_ST_SCOPE);
+            __hip_atomic_store(my_flag, 1, __ATOMIC_RELAXED, LSF_FLAG_ST_SCOPE);
             const int done = __hip_atomic_fetch_add(a.plane_cnt + s * np + P, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             if (done == a.plane_size[P]) {
                 // Hyperplanes may complete out of order now; planes_done[s] counts the LEADING complete ones.  Whoever
@@ -1440,7 +1337,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
         const int s = sP & (DF_BATCH - 1), P = (int)((unsigned)sP >> DF_SWEEP_BITS);
         if (go == 0) return; // the list is exhausted (or was cut short: stop, time-out)
         const int sk = uni(sh_task[5]);
-        auto wait_upstream = [&](int) -> int { // stage 2: condition (a)
+        auto wait_upstream = [&]() -> bool { // stage 2: condition (a)
             if (tid == 0) {
                 int go2 = 1;
                 const int *w0 = (const int*)sh_wait[0], *w1 = (const int*)sh_wait[1], *w2 = (const int*)sh_wait[2];
@@ -1464,7 +1361,7 @@ __global__ __launch_bounds__(64 * WY * WZ) __attribute__((amdgpu_waves_per_eu(BY
                 sh_task[6] = go2;
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            return uni(sh_task[6]) == 1 ? 1 : 0;
+            return uni(sh_task[6]) == 1;
         };
         if (go == 1) {
             if (!skew_tile<TA, WY, WZ, BY, STRICT, true, true>(sm, a, packed, a.g0 + s, uni(sh_task[3]), uni(sh_task[4]), sk, pre, wait_upstream))
