@@ -482,8 +482,9 @@ JacPlan jacobi_plan(const int lo[3], const int hi[3], bool strict, const int ext
         p.kind = 3;
         const int gx = cdiv(cx, JSS_PX * JSS_WX), gy = cdiv(cy, JSS_PY * JSS_WY);
         p.kc = jacobi_kc((long)gx * gy, cz);
-        p.grid = dim3(gx, gy, cdiv(cz, p.kc));
-        p.nparts = (long)p.grid.x * p.grid.y * p.grid.z;
+        p.nbx = gx, p.nby = gy, p.nbz = cdiv(cz, p.kc);
+        p.nparts = (long)gx * gy * p.nbz;                    // one partial sum per logical block, in block order
+        p.grid = dim3((unsigned)((p.nparts + 7) / 8 * 8));   // one-dimensional, padded to the 8 XCDs (k_reinit_jacobi_strict_sh)
         return p;
     }
     if (strict || thinx || off) {
@@ -522,7 +523,7 @@ void jacobi_launch(const JacPlan& p, bool strict, const double* A, double* B, co
                        hi[0], hi[1], hi[2], dx, h, part, done, p.nbx, p.nby, p.nbz, p.kc)
     if (p.kind == 3) {
         hipLaunchKernelGGL(k_reinit_jacobi_strict_sh, p.grid, dim3(64 * JSS_WX * JSS_WY), 0, st, A, B, phiS, bx, lo[0], lo[1], lo[2], hi[0],
-                           hi[1], hi[2], dx, h, part, done, p.kc);
+                           hi[1], hi[2], dx, h, part, done, p.kc, p.nbx, p.nby, p.nbz);
     } else if (p.kind == 2) {
         const int sh = p.wx * 16 + p.by;
         if (sh == 0x14) LSF_JAC_SH(1, 4);

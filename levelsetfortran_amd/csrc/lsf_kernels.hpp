@@ -248,18 +248,28 @@ __global__ __launch_bounds__(64 * JSS_WX * JSS_WY) void k_reinit_jacobi_strict_s
                                                                                  const double* __restrict__ phiS, Box bx, int lo0, int lo1,
                                                                                  int lo2, int hi0, int hi1, int hi2, double dx, double h,
                                                                                  double* __restrict__ partials, const int* __restrict__ done,
-                                                                                 int kc)
+                                                                                 int kc, int nbx, int nby, int nbz)
 {
 #pragma clang fp contract(off)
     __shared__ double red[JSS_WX * JSS_WY];
     __shared__ double lds[JSS_WX * JSS_WY * JSS_WAVE];
     if (done && *done) return;
+    // XCD-aware numbering (as k_reinit_jacobi_sh): the launch is one-dimensional and padded to a multiple of 8; the 8 XCDs take the
+    // launch indices round robin, XCD x gets the logical blocks [x * per, (x + 1) * per) -- a contiguous range of patches (x fastest,
+    // then y, then the chunks along z), so that the points a patch reaches beyond its edge (the edge jobs' operands, the +-1 loads)
+    // are what another block of the SAME XCD loads too and come from its L2 instead of the fabric.  Round 6, VERDICT r5 item 7:
+    // fabric traffic 1.96 x algorithmic with a three-dimensional grid dealt out block by block (neighbouring patches on eight
+    // different XCDs).  The partial sums keep their order (index = logical block): the RMS bits do not change.
+    const unsigned per = gridDim.x >> 3;
+    const unsigned L = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (L >= (unsigned)nbx * (unsigned)nby * (unsigned)nbz) return; // padding
+    const int bxi = (int)(L % (unsigned)nbx), byi = (int)((L / (unsigned)nbx) % (unsigned)nby), bzi = (int)(L / ((unsigned)nbx * (unsigned)nby));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lx = lane & (JSS_PX - 1), ly = lane / JSS_PX;
-    const int i0 = lo0 + ((int)blockIdx.x * JSS_WX + (wave % JSS_WX)) * JSS_PX; // the patch's first column
-    const int j0 = lo1 + ((int)blockIdx.y * JSS_WY + (wave / JSS_WX)) * JSS_PY;
+    const int i0 = lo0 + (bxi * JSS_WX + (wave % JSS_WX)) * JSS_PX; // the patch's first column
+    const int j0 = lo1 + (byi * JSS_WY + (wave / JSS_WX)) * JSS_PY;
     const int li = i0 + lx, lj = j0 + ly;
-    const int k0 = lo2 + blockIdx.z * kc, k1 = min(k0 + kc, hi2);
+    const int k0 = lo2 + bzi * kc, k1 = min(k0 + kc, hi2);
     const long sx = bx.lx, sxy = (long)bx.lx * bx.ly;
     const bool cell = li < hi0 && lj < hi1; // lanes beyond the region still evaluate the differences their neighbours read (hi <= l - 1)
     const int gi = li + bx.gx0, gj = lj + bx.gy0;
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(64 * JSS_WX * JSS_WY) void k_reinit_jacobi_strict_s
     if (tid == 0) {
         double t = 0.0;
         for (int q = 0; q < JSS_WX * JSS_WY; ++q) t += red[q];
-        partials[blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)] = t;
+        partials[L] = t;
     }
 }
 
