@@ -134,6 +134,14 @@ def load() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  levelsetfortran_amd has no CPU fallback."
             )
+        # One HIP runtime per process: torch ships a libamdhip64 of its own, and whichever copy is loaded first serves every later
+        # `libamdhip64.so` dependency.  Every test, the bench and the drivers run with torch imported first; a process that loaded this
+        # library first and initialised torch.cuda afterwards found "No HIP GPUs are available" (round 6, profiles/micro/time_entries.py).
+        # So: torch first, always -- the package needs it for device memory and streams anyway.
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # host-only use (lsf_stl_read, the ABI checks): nothing to keep consistent
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol

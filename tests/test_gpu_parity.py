@@ -914,3 +914,23 @@ def test_node_advection_matches_reference(lsf, cube40):
         bad = XX.copy(order="F")
         bad[0, 0] = 99.0  # a node outside the grid would make the reference read outside phi
         lsf.advectNodes(phi, sb, nx, ny, nz, float(cube40["dx"]), adv["xLo"], bad)
+
+
+def test_library_before_torch_in_a_fresh_process():
+    """One HIP runtime per process whatever the import order: a process that uses the library through host arrays FIRST and touches
+    torch.cuda afterwards (torch ships its own libamdhip64) once found "No HIP GPUs are available" -- _lib.load() imports torch first."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, levelsetfortran_amd as lsf\n"
+            "from levelsetfortran_amd import fields\n"
+            "phi, dx = fields.two_sphere_phi0((24, 24, 24))\n"
+            "r = lsf.reinit(phi, None, None, 23, 23, 23, 3, dx, fields.reinit_step(dx), tol=0.0)\n"
+            "import torch\n"
+            "t = torch.ones(8, device='cuda:0', dtype=torch.float64)\n"
+            "print('ok', r.count, float(t.sum().item()))\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok 4 8.0" in out.stdout, out.stderr[-1500:]
