@@ -127,15 +127,18 @@ int lsf_write_vti(const char* path, const double* phi, int nx, int ny, int nz, d
     (void)hipGetLastError();
     if (d) {
         // stream from the device twin: chunk n + 1 is copied into one pinned buffer while chunk n is written from the other
-        const size_t CH = 64u << 20;
+        // (buffers no larger than the payload, the second one only when there is a second chunk: pinning 2 x 64 MB for the 1.9 MB of
+        // the reference's default grid was most of this call's 40-55 ms there)
+        const size_t CH = std::min<size_t>(64u << 20, (bytes + 4095) & ~(size_t)4095);
+        const size_t nch = (bytes + CH - 1) / CH;
         void* pin[2] = {nullptr, nullptr};
         hipStream_t st = nullptr;
         hipEvent_t ev[2] = {nullptr, nullptr};
-        if (hipHostMalloc(&pin[0], CH, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&pin[1], CH, hipHostMallocDefault) != hipSuccess ||
+        if (hipHostMalloc(&pin[0], CH, hipHostMallocDefault) != hipSuccess ||
+            (nch > 1 && hipHostMalloc(&pin[1], CH, hipHostMallocDefault) != hipSuccess) ||
             hipStreamCreate(&st) != hipSuccess || hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) {
             ok = false;
         } else {
-            const size_t nch = (bytes + CH - 1) / CH;
             auto issue = [&](size_t q) {
                 const size_t off = q * CH, len = std::min(CH, bytes - off);
                 return hipMemcpyAsync(pin[q & 1], (const char*)d + off, len, hipMemcpyDeviceToHost, st) == hipSuccess &&

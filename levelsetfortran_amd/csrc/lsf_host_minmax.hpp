@@ -167,7 +167,7 @@ int minmax_core_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
 
 // The min/max flow on the narrow band only (lsf_minmax_band.hpp): the list of cells that can ever be in the band is built once
 // per call and the flow runs on compact arrays; the field is written once, at the end.  Both orderings (the Jacobi ordering is
-// the start pass and the RMS pass alone).  *dense = true: not run (band above a quarter of the grid, no band cell at all, a
+// the start pass and the RMS pass alone).  *dense = true: not run (a list beyond 3.5 M cells + 30 % of the grid, no band cell at all, a
 // field beyond 32-bit point indices or brick keys, or an iteration that 62 fix passes did not certify -- never observed) and phi, the masks
 // untouched: the caller takes the dense executors.
 int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny, int nz, int iter, double dx, double h1, double tol,
@@ -198,10 +198,15 @@ int minmax_band_impl(double* d_phi, int32_t* d_nb, int32_t* d_sb, int nx, int ny
     int nL = 0;
     HIPCHK(hipMemcpyAsync(&nL, offsets + nblk, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    // a band above a quarter of the grid: the dense executor streams it as fast (LSF_MINMAX_BAND_MAX, per cent: test hook)
-    double band_max = 25.0;
-    if (const char* e = getenv("LSF_MINMAX_BAND_MAX")) band_max = std::min(100.0, std::max(0.0, atof(e)));
-    if (nL <= 0 || (double)nL * 100.0 > band_max * (double)n) return LSF_OK;
+    // Which executor is faster is a question of list cells against grid points (round 6, profiles/r06_minmax_small.txt: two-sphere
+    // fields of 48^3 ... 384^3 with 2 ... 57 % of the grid in the band, ms per exact iteration): this executor costs ~0.02 ms + 0.035 ms
+    // per million LIST cells, the dense one ~0.15 ms (its launches) + 0.0105 ms per million GRID points -- so the band executor takes
+    // every list up to 3.5 M cells + 30 % of the grid.  (Rounds 5: "a quarter of the grid", which sent the reference's default run --
+    // 62^3, band 35 % -- to the dense executor: 0.17 ms per iteration against 0.022.)  LSF_MINMAX_BAND_MAX (per cent of the grid)
+    // replaces the rule: test hook.
+    bool take = nL > 0 && (double)nL <= 3.5e6 + 0.30 * (double)n;
+    if (const char* e = getenv("LSF_MINMAX_BAND_MAX")) take = nL > 0 && (double)nL * 100.0 <= std::min(100.0, std::max(0.0, atof(e))) * (double)n;
+    if (!take) return LSF_OK;
     const int nchunks = (nL + MB_CH - 1) / MB_CH;
     if ((rc = ws(c.slot[S_MB_L], (size_t)nL * sizeof(int)))) return rc;
     if ((rc = ws(c.slot[S_MB_NB6], (size_t)nL * 6 * sizeof(int)))) return rc;
